@@ -1,0 +1,45 @@
+# Top-level build: everything lands in-tree so it travels to the GPU box.
+#   make            all of the below
+#   make hip        fast-feedback-service_amd/libffs_hip.so   (hipcc, gfx950)
+#   make synth      fast-feedback-service_amd/libffs_synth.so (gcc)
+#   make cli        fast-feedback-service_amd/bin/spotfinder  (g++, links libffs_hip)
+#   make oracle     oracle/liboracle.so (+ oracle/_ref when /root/reference exists)
+PKG     := fast-feedback-service_amd
+HIPCC   ?= /opt/rocm/bin/hipcc
+CC      ?= gcc
+CXX     ?= g++
+ARCH    ?= gfx950
+HIPFLAGS = -std=c++20 -O3 --offload-arch=$(ARCH) -fPIC -Iinclude -I$(PKG)/csrc \
+           -ffp-contract=off -Wall -Wno-unused-function
+HIP_SRCS := $(wildcard $(PKG)/csrc/*.hip)
+HIP_HDRS := $(wildcard $(PKG)/csrc/*.h) $(wildcard $(PKG)/csrc/*.hpp) include/ffs_hip.h
+
+all: oracle synth hip cli
+
+oracle:
+	$(MAKE) -C oracle
+
+synth: $(PKG)/libffs_synth.so
+$(PKG)/libffs_synth.so: $(PKG)/host/ffs_synth.c include/ffs_synth.h
+	$(CC) -std=c11 -O2 -ffp-contract=off -fPIC -shared -Iinclude -o $@ $< -lm
+
+hip: $(PKG)/libffs_hip.so
+$(PKG)/libffs_hip.so: $(HIP_SRCS) $(HIP_HDRS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
+
+CLI_SRCS := $(wildcard $(PKG)/host/*.cc)
+CLI_HDRS := $(wildcard $(PKG)/host/*.hpp) $(wildcard include/*.h)
+cli: $(PKG)/bin/spotfinder
+$(PKG)/bin/spotfinder: $(CLI_SRCS) $(CLI_HDRS) $(PKG)/libffs_hip.so $(PKG)/libffs_synth.so
+	@if [ -n "$(CLI_SRCS)" ]; then mkdir -p $(PKG)/bin && \
+	$(CXX) -std=c++20 -O2 -Iinclude -I$(PKG)/host -o $@ $(CLI_SRCS) \
+	    -L$(PKG) -lffs_hip -lffs_synth -Wl,-rpath,'$$ORIGIN/..' -lpthread -ldl && \
+	ln -sf spotfinder $(PKG)/bin/spotfinder32; \
+	else echo "no CLI sources yet"; fi
+
+clean:
+	rm -f $(PKG)/libffs_hip.so $(PKG)/libffs_synth.so
+	rm -rf $(PKG)/bin
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle synth hip cli clean
