@@ -1,0 +1,891 @@
+// ffs_api.hip -- host side of libffs_hip.so: contexts, streams, launches, result assembly.
+// The C ABI is declared in include/ffs_hip.h; every entry point there names the reference
+// interface it replaces.  No exceptions leave this file.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ffs_hip.h"
+#include "kernels_ccl.hpp"
+#include "kernels_threshold.hpp"
+
+using namespace ffsamd;
+
+static_assert(sizeof(ReflOut) == sizeof(ffs_reflection), "record layout");
+static_assert(offsetof(ReflOut, sum_intensity) == offsetof(ffs_reflection, sum_intensity), "record layout");
+
+static thread_local std::string g_create_error;
+
+struct ffs_ctx {
+    int device = 0;
+    Layout L{};
+    int pixel_bytes = 2;
+    uint32_t max_batch = 1;
+    uint32_t cap = 0;       // strong pixels per frame
+    uint32_t max_comp = 0;  // components per frame
+    int n_tiles = 0, n_strips = 0;
+    ffs_params params{};
+    uint8_t* d_maskbits = nullptr;
+    mutable std::string err;
+};
+
+#define HIP_TRY(ctx, expr)                                                              \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);             \
+            return e_ == hipErrorOutOfMemory ? FFS_ERR_NOMEM : FFS_ERR_DEVICE;          \
+        }                                                                               \
+    } while (0)
+
+struct ffs_stream {
+    ffs_ctx* ctx = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[6] = {};
+    // device
+    uint8_t* d_img = nullptr;
+    uint8_t* d_bits = nullptr;
+    uint8_t* d_sbytes = nullptr;
+    uint32_t *d_tile_counts = nullptr, *d_tile_offsets = nullptr, *d_num_strong = nullptr;
+    uint32_t *d_list_k = nullptr, *d_list_i = nullptr, *d_parent = nullptr, *d_comp_id = nullptr;
+    uint32_t *d_n_comp = nullptr, *d_overflow = nullptr, *d_summary = nullptr;
+    CompAcc* d_acc = nullptr;
+    ReflOut* d_recs = nullptr;
+    // pinned host
+    uint8_t* h_img = nullptr;
+    size_t h_img_bytes = 0;
+    uint32_t* h_counts = nullptr;  // [max_batch] num_strong | [max_batch] n_comp | [max_batch*8] summary | [1] overflow
+    ReflOut* h_recs = nullptr;
+    uint32_t *h_list_k = nullptr, *h_list_i = nullptr;
+    uint8_t* h_mask = nullptr;
+    // state of the batch in flight
+    bool busy = false;
+    uint32_t n_frames = 0;
+    int64_t first_id = 0;
+    const void* cur_img = nullptr;
+    size_t cur_pitch = 0, cur_fstride = 0;
+    ffs_params batch_params{};
+    float timings[5] = {0, 0, 0, 0, 0};
+    // results
+    std::vector<ffs_frame_result> results;
+    std::vector<ffs_box> boxes;
+    std::vector<ffs_reflection> refls;
+};
+
+struct ffs_stack3d {
+    ffs_ctx* ctx = nullptr;
+    uint64_t max_total = 0;
+    struct Slice {
+        std::vector<uint32_t> k, inten;
+    };
+    std::map<int64_t, Slice> slices;
+    std::vector<ffs_reflection> out;
+    // device scratch (allocated in finish)
+};
+
+// ---------------------------------------------------------------------------------------------------
+
+extern "C" void ffs_default_params(ffs_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->min_count = 2;  // baseline/spotfinder/standalone.cc:17
+    p->nsig_b = 6.0;   // :19
+    p->nsig_s = 3.0;   // :20
+    p->threshold = 0.0;
+    p->max_valid = -1;
+    p->min_spot_size = 3;     // spotfinder/spotfinder.cc:321
+    p->min_spot_size_3d = 3;  // :327
+    p->max_peak_centroid_separation = 2.0f;  // :335
+    p->want_reflections = 1;
+    p->want_strong_list = 0;
+    p->want_strong_mask = 0;
+}
+
+extern "C" int ffs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int ffs_device_name(int device, char* buf, size_t buflen) {
+    hipDeviceProp_t prop;
+    if (!buf || buflen == 0) return FFS_ERR_INVALID;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return FFS_ERR_NODEVICE;
+    std::snprintf(buf, buflen, "%s (%s)", prop.name, prop.gcnArchName);
+    return FFS_OK;
+}
+
+extern "C" int ffs_device_total_mem(int device, uint64_t* bytes) {
+    hipDeviceProp_t prop;
+    if (!bytes) return FFS_ERR_INVALID;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return FFS_ERR_NODEVICE;
+    *bytes = prop.totalGlobalMem;
+    return FFS_OK;
+}
+
+extern "C" const char* ffs_last_error(const ffs_ctx* ctx) {
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+extern "C" int ffs_ctx_create(int device, uint32_t width, uint32_t height, int pixel_bytes,
+                              uint32_t max_batch, uint32_t max_strong, ffs_ctx** out) {
+    if (!out) return FFS_ERR_INVALID;
+    *out = nullptr;
+    if (width == 0 || height == 0 || (pixel_bytes != 2 && pixel_bytes != 4) || max_batch == 0
+        || width > 10240 || (uint64_t)width * height >= (1ull << 32)) {
+        g_create_error = "ffs_ctx_create: need 0 < width <= 10240, width*height < 2^32, pixel_bytes 2 or 4, max_batch > 0";
+        return FFS_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        g_create_error = "no HIP device visible (libffs_hip.so has no CPU fallback)";
+        return FFS_ERR_NODEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        g_create_error = "ffs_ctx_create: device index out of range";
+        return FFS_ERR_NODEVICE;
+    }
+    ffs_ctx* c = new (std::nothrow) ffs_ctx();
+    if (!c) return FFS_ERR_NOMEM;
+    c->device = device;
+    c->pixel_bytes = pixel_bytes;
+    c->max_batch = max_batch;
+    Layout& L = c->L;
+    L.W = (int)width;
+    L.H = (int)height;
+    L.pitch_px = round_up((int)width, 64);
+    L.pitch = (uint32_t)L.pitch_px * (uint32_t)pixel_bytes;
+    L.mpitch = (uint32_t)L.pitch_px / 8;
+    L.bpitch = (uint32_t)L.pitch_px;
+    L.frame_stride = (uint64_t)L.pitch * height;
+    L.plane_frame_stride = (uint64_t)L.mpitch * height;
+    L.bytes_frame_stride = (uint64_t)L.bpitch * height;
+    if (L.frame_stride >= (1ull << 32)) {
+        g_create_error = "frame larger than 4 GiB";
+        delete c;
+        return FFS_ERR_INVALID;
+    }
+    const uint64_t npx = (uint64_t)width * height;
+    c->cap = max_strong ? max_strong : (uint32_t)std::min<uint64_t>(npx, 1u << 18);
+    c->cap = (uint32_t)std::min<uint64_t>(c->cap, npx);
+    c->max_comp = std::min<uint32_t>(c->cap, 1u << 16);
+    c->n_tiles = ((int)height + kTileRows - 1) / kTileRows;
+    const int owned_px = pixel_bytes == 2 ? kStripOwnedPx : kStripOwnedPx32;
+    c->n_strips = (L.pitch_px + owned_px - 1) / owned_px;
+    ffs_default_params(&c->params);
+    if (hipSetDevice(device) != hipSuccess) {
+        g_create_error = "hipSetDevice failed";
+        delete c;
+        return FFS_ERR_DEVICE;
+    }
+    hipError_t e = hipMalloc(&c->d_maskbits, L.plane_frame_stride + 256);
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipMalloc(mask): ") + hipGetErrorString(e);
+        delete c;
+        return FFS_ERR_NOMEM;
+    }
+    *out = c;
+    int rc = ffs_ctx_set_mask(c, nullptr);
+    if (rc != FFS_OK) {
+        g_create_error = c->err;
+        ffs_ctx_destroy(c);
+        *out = nullptr;
+        return rc;
+    }
+    return FFS_OK;
+}
+
+extern "C" void ffs_ctx_destroy(ffs_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_maskbits) (void)hipFree(c->d_maskbits);
+    delete c;
+}
+
+extern "C" int ffs_ctx_set_mask(ffs_ctx* c, const uint8_t* host_mask) {
+    if (!c) return FFS_ERR_INVALID;
+    const Layout& L = c->L;
+    std::vector<uint8_t> bits(L.plane_frame_stride, 0);
+    for (int y = 0; y < L.H; ++y) {
+        uint8_t* row = bits.data() + (size_t)y * L.mpitch;
+        if (host_mask) {
+            const uint8_t* m = host_mask + (size_t)y * L.W;
+            for (int x = 0; x < L.W; ++x)
+                if (m[x]) row[x >> 3] |= (uint8_t)(1u << (x & 7));
+        } else {
+            for (int x = 0; x < L.W; ++x) row[x >> 3] |= (uint8_t)(1u << (x & 7));
+        }
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpy(c->d_maskbits, bits.data(), bits.size(), hipMemcpyHostToDevice));
+    return FFS_OK;
+}
+
+extern "C" int ffs_ctx_get_mask(ffs_ctx* c, uint8_t* host_mask) {
+    if (!c || !host_mask) return FFS_ERR_INVALID;
+    const Layout& L = c->L;
+    std::vector<uint8_t> bits(L.plane_frame_stride);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpy(bits.data(), c->d_maskbits, bits.size(), hipMemcpyDeviceToHost));
+    for (int y = 0; y < L.H; ++y)
+        for (int x = 0; x < L.W; ++x)
+            host_mask[(size_t)y * L.W + x] = (bits[(size_t)y * L.mpitch + (x >> 3)] >> (x & 7)) & 1;
+    return FFS_OK;
+}
+
+// Resolution mask: spotfinder/kernels/masking.cu:37-73 (float32 distance / d-spacing), :99-147.
+// One thread per mask byte (8 pixels); only clears bits, as the reference only ever masks.
+__global__ void k_resolution_mask(uint8_t* maskbits, uint32_t mpitch, int W, int H, float wavelength,
+                                  float distance, float cx, float cy, float psx, float psy,
+                                  float dmin, float dmax) {
+    const int bx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (bx * 8 >= W || y >= H) return;
+    uint8_t* p = maskbits + (uint64_t)y * mpitch + bx;
+    uint32_t b = *p;
+    for (int j = 0; j < 8; ++j) {
+        const int x = bx * 8 + j;
+        if (x >= W || !((b >> j) & 1u)) continue;  // masking.cu:120-126
+        const float dx = (((float)x + 0.5f) - cx) * psx;  // :50-52
+        const float dy = (((float)y + 0.5f) - cy) * psy;
+        const float r = sqrtf(dx * dx + dy * dy);
+        const float theta = 0.5f * atanf(r / distance);  // :71
+        const float res = wavelength / (2.0f * sinf(theta));  // :72
+        if ((dmin > 0 && res < dmin) || (dmax > 0 && res > dmax)) b &= ~(1u << j);  // :133-142
+    }
+    *p = (uint8_t)b;
+}
+
+extern "C" int ffs_ctx_apply_resolution_mask(ffs_ctx* c, float wavelength, float distance_m,
+                                             float bcx, float bcy, float psx, float psy, float dmin,
+                                             float dmax) {
+    if (!c) return FFS_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const Layout& L = c->L;
+    dim3 block(64, 1), grid((L.mpitch + 63) / 64, L.H);
+    hipLaunchKernelGGL(k_resolution_mask, grid, block, 0, 0, c->d_maskbits, L.mpitch, L.W, L.H,
+                       wavelength, distance_m, bcx, bcy, psx, psy, dmin, dmax);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipDeviceSynchronize());
+    return FFS_OK;
+}
+
+extern "C" int ffs_ctx_set_params(ffs_ctx* c, const ffs_params* p) {
+    if (!c || !p) return FFS_ERR_INVALID;
+    if (p->min_count < 2 || p->min_count > 49 || p->nsig_b < 0 || p->nsig_s < 0 || p->threshold < 0) {
+        c->err = "ffs_ctx_set_params: need 2 <= min_count <= 49, nsig_b >= 0, nsig_s >= 0, threshold >= 0";
+        return FFS_ERR_INVALID;  // the asserts of standalone.cc:52-63
+    }
+    c->params = *p;
+    return FFS_OK;
+}
+
+extern "C" int ffs_ctx_device_layout(const ffs_ctx* c, size_t* pitch, size_t* fstride) {
+    if (!c) return FFS_ERR_INVALID;
+    if (pitch) *pitch = c->L.pitch;
+    if (fstride) *fstride = c->L.frame_stride;
+    return FFS_OK;
+}
+
+// ---- streams ---------------------------------------------------------------------------------------
+
+template <typename T>
+static hipError_t dmalloc(T** p, size_t n_bytes) {
+    return hipMalloc(reinterpret_cast<void**>(p), n_bytes + 256);
+}
+
+extern "C" void ffs_stream_destroy(ffs_stream* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    if (s->st) (void)hipStreamSynchronize(s->st);
+    void* dev[] = {s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_tile_offsets, s->d_num_strong,
+                   s->d_list_k, s->d_list_i, s->d_parent, s->d_comp_id, s->d_n_comp, s->d_overflow,
+                   s->d_summary, s->d_acc, s->d_recs};
+    for (void* p : dev)
+        if (p) (void)hipFree(p);
+    void* host[] = {s->h_img, s->h_counts, s->h_recs, s->h_list_k, s->h_list_i, s->h_mask};
+    for (void* p : host)
+        if (p) (void)hipHostFree(p);
+    for (auto& e : s->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (s->st) (void)hipStreamDestroy(s->st);
+    delete s;
+}
+
+extern "C" int ffs_stream_create(ffs_ctx* c, ffs_stream** out) {
+    if (!c || !out) return FFS_ERR_INVALID;
+    *out = nullptr;
+    HIP_TRY(c, hipSetDevice(c->device));
+    ffs_stream* s = new (std::nothrow) ffs_stream();
+    if (!s) return FFS_ERR_NOMEM;
+    s->ctx = c;
+    const Layout& L = c->L;
+    const size_t B = c->max_batch;
+#define STREAM_TRY(expr)                                                        \
+    do {                                                                        \
+        hipError_t e_ = (expr);                                                 \
+        if (e_ != hipSuccess) {                                                 \
+            c->err = std::string(#expr) + ": " + hipGetErrorString(e_);         \
+            ffs_stream_destroy(s);                                              \
+            return e_ == hipErrorOutOfMemory ? FFS_ERR_NOMEM : FFS_ERR_DEVICE;  \
+        }                                                                       \
+    } while (0)
+    STREAM_TRY(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+    for (auto& e : s->ev) STREAM_TRY(hipEventCreate(&e));
+    STREAM_TRY(dmalloc(&s->d_img, B * L.frame_stride));
+    STREAM_TRY(dmalloc(&s->d_bits, B * L.plane_frame_stride));
+    STREAM_TRY(dmalloc(&s->d_sbytes, B * L.bytes_frame_stride));
+    STREAM_TRY(dmalloc(&s->d_tile_counts, B * c->n_tiles * 4));
+    STREAM_TRY(dmalloc(&s->d_tile_offsets, B * c->n_tiles * 4));
+    STREAM_TRY(dmalloc(&s->d_num_strong, B * 4));
+    STREAM_TRY(dmalloc(&s->d_list_k, B * (size_t)c->cap * 4));
+    STREAM_TRY(dmalloc(&s->d_list_i, B * (size_t)c->cap * 4));
+    STREAM_TRY(dmalloc(&s->d_parent, B * (size_t)c->cap * 4));
+    STREAM_TRY(dmalloc(&s->d_comp_id, B * (size_t)c->cap * 4));
+    STREAM_TRY(dmalloc(&s->d_n_comp, B * 4));
+    STREAM_TRY(dmalloc(&s->d_overflow, 4));
+    STREAM_TRY(dmalloc(&s->d_summary, B * 8 * 4));
+    STREAM_TRY(dmalloc(&s->d_acc, B * (size_t)c->max_comp * sizeof(CompAcc)));
+    STREAM_TRY(dmalloc(&s->d_recs, B * (size_t)c->max_comp * sizeof(ReflOut)));
+    s->h_img_bytes = B * (size_t)L.W * L.H * c->pixel_bytes;
+    STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_img), s->h_img_bytes, hipHostMallocDefault));
+    STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), (B * 10 + 1) * 4, hipHostMallocDefault));
+    STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_recs), B * (size_t)c->max_comp * sizeof(ReflOut),
+                             hipHostMallocDefault));
+    STREAM_TRY(hipMemsetAsync(s->d_overflow, 0, 4, s->st));
+    STREAM_TRY(hipStreamSynchronize(s->st));
+#undef STREAM_TRY
+    *out = s;
+    return FFS_OK;
+}
+
+extern "C" int ffs_stream_host_buffer(ffs_stream* s, void** ptr, size_t* bytes) {
+    if (!s) return FFS_ERR_INVALID;
+    if (ptr) *ptr = s->h_img;
+    if (bytes) *bytes = s->h_img_bytes;
+    return FFS_OK;
+}
+
+static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t pitch, size_t fstride,
+                                         uint32_t n_frames) {
+    const ffs_ctx* c = s->ctx;
+    const Layout& L = c->L;
+    const ffs_params& p = s->batch_params;
+    ThresholdArgs a{};
+    a.image = img;
+    a.frame_stride = fstride;
+    a.pitch = (uint32_t)pitch;
+    a.maskbits = c->d_maskbits;
+    a.bits = s->d_bits;
+    a.strong_bytes = s->d_sbytes;
+    a.tile_counts = s->d_tile_counts;
+    a.W = L.W;
+    a.H = L.H;
+    a.pitch_px = L.pitch_px;
+    a.mpitch = L.mpitch;
+    a.bpitch = L.bpitch;
+    a.plane_frame_stride = L.plane_frame_stride;
+    a.bytes_frame_stride = L.bytes_frame_stride;
+    a.n_strips = c->n_strips;
+    a.n_tiles = c->n_tiles;
+    // enough waves to fill 256 CUs several times over, bands no shorter than 24 rows
+    const long long target_waves = 8192;
+    long long rows = ((long long)L.H * c->n_strips * n_frames + target_waves - 1) / target_waves;
+    rows = std::max<long long>(24, std::min<long long>(rows, 512));
+    a.band_rows = (int)rows;
+    a.n_bands = (L.H + a.band_rows - 1) / a.band_rows;
+    a.kS = (float)(p.nsig_s * p.nsig_s * (1.0 - 1.0 / 65536.0));
+    a.min_count = p.min_count;
+    a.nsig_b = p.nsig_b;
+    a.nsig_s = p.nsig_s;
+    a.threshold = p.threshold;
+    a.max_valid = p.max_valid;
+    return a;
+}
+
+static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
+    dim3 grid((unsigned)(a.n_strips * a.n_bands), n_frames), block(64);
+    if (s->ctx->pixel_bytes == 2)
+        hipLaunchKernelGGL(k_candidates_u16, grid, block, 0, s->st, a);
+    else
+        hipLaunchKernelGGL(k_candidates_u32, grid, block, 0, s->st, a);
+}
+
+static void launch_exact(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
+    dim3 grid((unsigned)a.n_tiles, n_frames), block(256);
+    if (s->ctx->pixel_bytes == 2)
+        hipLaunchKernelGGL(k_exact<uint16_t>, grid, block, 0, s->st, a);
+    else
+        hipLaunchKernelGGL(k_exact<uint32_t>, grid, block, 0, s->st, a);
+}
+
+static int check_layout(ffs_stream* s, size_t pitch, size_t fstride, uint32_t n_frames) {
+    ffs_ctx* c = s->ctx;
+    if (n_frames == 0 || n_frames > c->max_batch) {
+        c->err = "n_frames must be in 1..max_batch";
+        return FFS_ERR_INVALID;
+    }
+    if (pitch % 16 || pitch < (size_t)c->L.pitch_px * c->pixel_bytes || pitch >= (1ull << 32)
+        || fstride < pitch * c->L.H || (pitch * c->L.H) >= (1ull << 32)) {
+        c->err = "device layout: pitch must be a multiple of 16 bytes and >= round_up(width,64)*pixel_bytes; "
+                 "frame_stride >= pitch*height";
+        return FFS_ERR_INVALID;
+    }
+    return FFS_OK;
+}
+
+static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride, uint32_t n) {
+    ffs_ctx* c = s->ctx;
+    const Layout& L = c->L;
+    s->batch_params = c->params;
+    const ffs_params& p = s->batch_params;
+    s->cur_img = d_img;
+    s->cur_pitch = pitch;
+    s->cur_fstride = fstride;
+
+    const ThresholdArgs ta = make_threshold_args(s, d_img, pitch, fstride, n);
+    launch_candidates(s, ta, n);
+    launch_exact(s, ta, n);
+    HIP_TRY(c, hipEventRecord(s->ev[2], s->st));
+
+    CclArgs ca{};
+    ca.image = d_img;
+    ca.frame_stride = fstride;
+    ca.pitch = (uint32_t)pitch;
+    ca.bits = s->d_bits;
+    ca.tile_counts = s->d_tile_counts;
+    ca.tile_offsets = s->d_tile_offsets;
+    ca.num_strong = s->d_num_strong;
+    ca.list_k = s->d_list_k;
+    ca.list_i = s->d_list_i;
+    ca.parent = s->d_parent;
+    ca.comp_id = s->d_comp_id;
+    ca.n_comp = s->d_n_comp;
+    ca.overflow = s->d_overflow;
+    ca.W = L.W;
+    ca.H = L.H;
+    ca.pitch_px = L.pitch_px;
+    ca.mpitch = L.mpitch;
+    ca.plane_frame_stride = L.plane_frame_stride;
+    ca.n_tiles = c->n_tiles;
+    ca.cap = c->cap;
+    ca.max_comp = c->max_comp;
+    ca.pixel_bytes = c->pixel_bytes;
+    hipLaunchKernelGGL(k_scan_tiles, dim3(n), dim3(256), 0, s->st, ca);
+    if (c->pixel_bytes == 2)
+        hipLaunchKernelGGL(k_emit_list<uint16_t>, dim3(c->n_tiles, n), dim3(256), 0, s->st, ca);
+    else
+        hipLaunchKernelGGL(k_emit_list<uint32_t>, dim3(c->n_tiles, n), dim3(256), 0, s->st, ca);
+
+    SegArgs sa{};
+    sa.list_k = s->d_list_k;
+    sa.list_i = s->d_list_i;
+    sa.parent = s->d_parent;
+    sa.comp_id = s->d_comp_id;
+    sa.seg_n = s->d_num_strong;
+    sa.seg_stride = c->cap;
+    sa.n_comp = s->d_n_comp;
+    sa.acc = s->d_acc;
+    sa.max_comp = c->max_comp;
+    sa.overflow = s->d_overflow;
+    sa.W = (uint32_t)L.W;
+    sa.slice_begin = nullptr;
+    sa.n_slices = 1;
+    sa.min_spot_size = p.min_spot_size;
+    sa.max_sep = p.max_peak_centroid_separation;
+    sa.recs = s->d_recs;
+    sa.summary = s->d_summary;
+    const dim3 gseg(32, n), b256(256);
+    hipLaunchKernelGGL(k_union<false>, gseg, b256, 0, s->st, sa);
+    hipLaunchKernelGGL(k_flatten, gseg, b256, 0, s->st, sa);
+    hipLaunchKernelGGL(k_label, dim3(n), dim3(1024), 0, s->st, sa);
+    hipLaunchKernelGGL(k_reduce<false>, gseg, b256, 0, s->st, sa);
+    hipLaunchKernelGGL(k_finalize<false>, dim3(8, n), b256, 0, s->st, sa);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(s->ev[3], s->st));
+
+    // small counts first; ffs_wait() sizes the record copy from them
+    const size_t B = c->max_batch;
+    HIP_TRY(c, hipMemcpyAsync(s->h_counts, s->d_num_strong, n * 4, hipMemcpyDeviceToHost, s->st));
+    HIP_TRY(c, hipMemcpyAsync(s->h_counts + B, s->d_n_comp, n * 4, hipMemcpyDeviceToHost, s->st));
+    HIP_TRY(c, hipMemcpyAsync(s->h_counts + 2 * B, s->d_summary, n * 8 * 4, hipMemcpyDeviceToHost, s->st));
+    HIP_TRY(c, hipMemcpyAsync(s->h_counts + 10 * B, s->d_overflow, 4, hipMemcpyDeviceToHost, s->st));
+    HIP_TRY(c, hipEventRecord(s->ev[4], s->st));
+    s->busy = true;
+    s->n_frames = n;
+    return FFS_OK;
+}
+
+extern "C" int ffs_submit_device(ffs_stream* s, const void* device_pixels, size_t pitch, size_t fstride,
+                                 uint32_t n_frames, int64_t first_frame_id) {
+    if (!s || !device_pixels) return FFS_ERR_INVALID;
+    ffs_ctx* c = s->ctx;
+    if (s->busy) {
+        c->err = "stream already has a batch in flight: call ffs_wait() first";
+        return FFS_ERR_INVALID;
+    }
+    int rc = check_layout(s, pitch, fstride, n_frames);
+    if (rc != FFS_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventRecord(s->ev[0], s->st));
+    HIP_TRY(c, hipEventRecord(s->ev[1], s->st));
+    s->first_id = first_frame_id;
+    return enqueue_batch(s, device_pixels, pitch, fstride, n_frames);
+}
+
+extern "C" int ffs_submit(ffs_stream* s, const void* host_pixels, uint32_t n_frames, int64_t first_frame_id) {
+    if (!s || !host_pixels) return FFS_ERR_INVALID;
+    ffs_ctx* c = s->ctx;
+    if (s->busy) {
+        c->err = "stream already has a batch in flight: call ffs_wait() first";
+        return FFS_ERR_INVALID;
+    }
+    if (n_frames == 0 || n_frames > c->max_batch) {
+        c->err = "n_frames must be in 1..max_batch";
+        return FFS_ERR_INVALID;
+    }
+    const Layout& L = c->L;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventRecord(s->ev[0], s->st));
+    // one 2D copy: the default device layout keeps frames contiguous (frame_stride = H * pitch)
+    const size_t row = (size_t)L.W * c->pixel_bytes;
+    HIP_TRY(c, hipMemcpy2DAsync(s->d_img, L.pitch, host_pixels, row, row, (size_t)L.H * n_frames,
+                                hipMemcpyHostToDevice, s->st));
+    HIP_TRY(c, hipEventRecord(s->ev[1], s->st));
+    s->first_id = first_frame_id;
+    return enqueue_batch(s, s->d_img, L.pitch, L.frame_stride, n_frames);
+}
+
+static int ensure_list_host(ffs_stream* s) {
+    ffs_ctx* c = s->ctx;
+    if (!s->h_list_k) {
+        const size_t bytes = (size_t)c->max_batch * c->cap * 4;
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&s->h_list_k), bytes, hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&s->h_list_i), bytes, hipHostMallocDefault));
+    }
+    return FFS_OK;
+}
+
+extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_results) {
+    if (!s) return FFS_ERR_INVALID;
+    ffs_ctx* c = s->ctx;
+    if (!s->busy) {
+        c->err = "ffs_wait: nothing submitted";
+        return FFS_ERR_INVALID;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(s->ev[4]));
+    const uint32_t n = s->n_frames;
+    const size_t B = c->max_batch;
+    const Layout& L = c->L;
+    const ffs_params& p = s->batch_params;
+    const uint32_t* h_ns = s->h_counts;
+    const uint32_t* h_nc = s->h_counts + B;
+    const uint32_t* h_sm = s->h_counts + 2 * B;
+    const uint32_t overflow = s->h_counts[10 * B];
+    s->busy = false;
+    if (overflow) {
+        (void)hipMemsetAsync(s->d_overflow, 0, 4, s->st);
+        (void)hipStreamSynchronize(s->st);
+        c->err = (overflow & 1u) ? "a frame has more strong pixels than max_strong_per_frame"
+                                 : "a frame has more connected components than the context holds";
+        return FFS_ERR_OVERFLOW;
+    }
+    uint64_t total_recs = 0;
+    uint32_t max_ns = 0;
+    for (uint32_t f = 0; f < n; ++f) {
+        total_recs += h_nc[f];
+        max_ns = std::max(max_ns, h_ns[f]);
+    }
+    if (total_recs)
+        HIP_TRY(c, hipMemcpyAsync(s->h_recs, s->d_recs, total_recs * sizeof(ReflOut), hipMemcpyDeviceToHost, s->st));
+    if (p.want_strong_list && max_ns) {
+        int rc = ensure_list_host(s);
+        if (rc != FFS_OK) return rc;
+        HIP_TRY(c, hipMemcpy2DAsync(s->h_list_k, (size_t)c->cap * 4, s->d_list_k, (size_t)c->cap * 4,
+                                    (size_t)max_ns * 4, n, hipMemcpyDeviceToHost, s->st));
+        HIP_TRY(c, hipMemcpy2DAsync(s->h_list_i, (size_t)c->cap * 4, s->d_list_i, (size_t)c->cap * 4,
+                                    (size_t)max_ns * 4, n, hipMemcpyDeviceToHost, s->st));
+    }
+    if (p.want_strong_mask) {
+        if (!s->h_mask)
+            HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&s->h_mask), B * (size_t)L.W * L.H, hipHostMallocDefault));
+        // the reference's full-mask D2H (spotfinder.cc:887-894), all frames of the batch in one 2D copy
+        HIP_TRY(c, hipMemcpy2DAsync(s->h_mask, L.W, s->d_sbytes, L.bpitch, L.W, (size_t)L.H * n,
+                                    hipMemcpyDeviceToHost, s->st));
+    }
+    HIP_TRY(c, hipEventRecord(s->ev[5], s->st));
+    HIP_TRY(c, hipEventSynchronize(s->ev[5]));
+    (void)hipEventElapsedTime(&s->timings[0], s->ev[0], s->ev[1]);
+    (void)hipEventElapsedTime(&s->timings[1], s->ev[1], s->ev[2]);
+    (void)hipEventElapsedTime(&s->timings[2], s->ev[2], s->ev[3]);
+    (void)hipEventElapsedTime(&s->timings[3], s->ev[3], s->ev[5]);
+    (void)hipEventElapsedTime(&s->timings[4], s->ev[0], s->ev[5]);
+
+    // assemble: boxes = components surviving the min-size filter (connected_components.cc:122-135),
+    // reflections = components surviving filter_reflections (:207-236); both keep label order.
+    s->results.assign(n, ffs_frame_result{});
+    s->boxes.clear();
+    s->refls.clear();
+    std::vector<size_t> box_at(n), refl_at(n);
+    const ReflOut* rec = s->h_recs;
+    for (uint32_t f = 0; f < n; ++f) {
+        box_at[f] = s->boxes.size();
+        refl_at[f] = s->refls.size();
+        for (uint32_t q = 0; q < h_nc[f]; ++q, ++rec) {
+            if (p.min_spot_size == 0 || (uint32_t)rec->num_pixels >= p.min_spot_size)
+                s->boxes.push_back(ffs_box{rec->x_min, rec->y_min, rec->x_max, rec->y_max, rec->num_pixels});
+            if (p.want_reflections && rec->flags == 0) {
+                ffs_reflection r;
+                std::memcpy(&r, rec, sizeof(r));
+                s->refls.push_back(r);
+            }
+        }
+    }
+    for (uint32_t f = 0; f < n; ++f) {
+        ffs_frame_result& r = s->results[f];
+        const uint32_t* sm = h_sm + (size_t)f * 8;
+        r.frame_id = s->first_id + f;
+        r.num_strong_pixels = h_ns[f];
+        r.num_strong_pixels_filtered = sm[1];
+        r.n_components = h_nc[f];
+        r.n_boxes = sm[0];
+        r.boxes = s->boxes.data() + box_at[f];
+        r.n_reflections = p.want_reflections ? sm[2] : 0;
+        r.reflections = p.want_reflections ? s->refls.data() + refl_at[f] : nullptr;
+        r.n_filtered_size = sm[3];
+        r.n_filtered_sep = sm[4];
+        if (p.want_strong_list) {
+            r.strong_k = s->h_list_k ? s->h_list_k + (size_t)f * c->cap : nullptr;
+            r.strong_intensity = s->h_list_i ? s->h_list_i + (size_t)f * c->cap : nullptr;
+        }
+        if (p.want_strong_mask) r.strong_mask = s->h_mask + (size_t)f * L.W * L.H;
+    }
+    if (results) *results = s->results.data();
+    if (n_results) *n_results = n;
+    return FFS_OK;
+}
+
+extern "C" int ffs_stream_timings(ffs_stream* s, float ms[5]) {
+    if (!s || !ms) return FFS_ERR_INVALID;
+    std::memcpy(ms, s->timings, sizeof(s->timings));
+    return FFS_OK;
+}
+
+extern "C" int ffs_stream_debug_planes(ffs_stream* s, const uint8_t** strong_bytes, size_t* mask_pitch,
+                                       size_t* mask_fstride) {
+    if (!s) return FFS_ERR_INVALID;
+    if (strong_bytes) *strong_bytes = s->d_sbytes;
+    if (mask_pitch) *mask_pitch = s->ctx->L.bpitch;
+    if (mask_fstride) *mask_fstride = s->ctx->L.bytes_frame_stride;
+    return FFS_OK;
+}
+
+extern "C" int ffs_bench_threshold(ffs_stream* s, const void* device_pixels, size_t pitch, size_t fstride,
+                                   uint32_t n_frames, uint32_t iters, float* ms_candidate, float* ms_exact) {
+    if (!s || !device_pixels || iters == 0) return FFS_ERR_INVALID;
+    ffs_ctx* c = s->ctx;
+    if (s->busy) {
+        c->err = "stream busy";
+        return FFS_ERR_INVALID;
+    }
+    int rc = check_layout(s, pitch, fstride, n_frames);
+    if (rc != FFS_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    s->batch_params = c->params;
+    const ThresholdArgs ta = make_threshold_args(s, device_pixels, pitch, fstride, n_frames);
+    // (1) `iters` launches of the candidate kernel back to back, HIP events on this stream
+    HIP_TRY(c, hipEventRecord(s->ev[0], s->st));
+    for (uint32_t i = 0; i < iters; ++i) launch_candidates(s, ta, n_frames);
+    HIP_TRY(c, hipEventRecord(s->ev[1], s->st));
+    // (2) candidate + exact pairs (the exact kernel filters the plane in place, so it must
+    //     always be preceded by the candidate kernel); exact = (pair - candidate)
+    for (uint32_t i = 0; i < iters; ++i) {
+        launch_candidates(s, ta, n_frames);
+        launch_exact(s, ta, n_frames);
+    }
+    HIP_TRY(c, hipEventRecord(s->ev[2], s->st));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventSynchronize(s->ev[2]));
+    float t1 = 0, t2 = 0;
+    HIP_TRY(c, hipEventElapsedTime(&t1, s->ev[0], s->ev[1]));
+    HIP_TRY(c, hipEventElapsedTime(&t2, s->ev[1], s->ev[2]));
+    if (ms_candidate) *ms_candidate = t1 / iters;
+    if (ms_exact) *ms_exact = std::max(0.0f, (t2 - t1) / iters);
+    return FFS_OK;
+}
+
+// ---- 3D stack ------------------------------------------------------------------------------------------
+
+extern "C" int ffs_stack3d_create(ffs_ctx* c, uint64_t max_total, ffs_stack3d** out) {
+    if (!c || !out) return FFS_ERR_INVALID;
+    ffs_stack3d* st = new (std::nothrow) ffs_stack3d();
+    if (!st) return FFS_ERR_NOMEM;
+    st->ctx = c;
+    st->max_total = max_total ? max_total : (1ull << 26);
+    *out = st;
+    return FFS_OK;
+}
+
+extern "C" void ffs_stack3d_destroy(ffs_stack3d* st) { delete st; }
+
+extern "C" int ffs_stack3d_add_slice(ffs_stack3d* st, int64_t frame_id, const uint32_t* k,
+                                     const uint32_t* inten, uint32_t n) {
+    if (!st || (n && (!k || !inten))) return FFS_ERR_INVALID;
+    auto& sl = st->slices[frame_id];
+    sl.k.assign(k, k + n);
+    sl.inten.assign(inten, inten + n);
+    return FFS_OK;
+}
+
+extern "C" int ffs_stack3d_add_batch(ffs_stack3d* st, ffs_stream* s) {
+    if (!st || !s || s->ctx != st->ctx) return FFS_ERR_INVALID;
+    ffs_ctx* c = s->ctx;
+    if (s->busy || s->results.empty()) {
+        c->err = "ffs_stack3d_add_batch: call after ffs_wait()";
+        return FFS_ERR_INVALID;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (uint32_t f = 0; f < s->n_frames; ++f) {
+        const uint32_t n = s->results[f].num_strong_pixels;
+        auto& sl = st->slices[s->results[f].frame_id];
+        sl.k.resize(n);
+        sl.inten.resize(n);
+        if (n) {
+            HIP_TRY(c, hipMemcpyAsync(sl.k.data(), s->d_list_k + (size_t)f * c->cap, (size_t)n * 4,
+                                      hipMemcpyDeviceToHost, s->st));
+            HIP_TRY(c, hipMemcpyAsync(sl.inten.data(), s->d_list_i + (size_t)f * c->cap, (size_t)n * 4,
+                                      hipMemcpyDeviceToHost, s->st));
+        }
+    }
+    HIP_TRY(c, hipStreamSynchronize(s->st));
+    return FFS_OK;
+}
+
+extern "C" int ffs_stack3d_finish(ffs_stack3d* st, const ffs_reflection** reflections, uint32_t* n_refl,
+                                  uint32_t* n_calculated, uint32_t* n_f_size, uint32_t* n_f_sep) {
+    if (!st) return FFS_ERR_INVALID;
+    ffs_ctx* c = st->ctx;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // z = rank of the frame id among the slices held (std::map order, spotfinder.cc:1105-1108)
+    const int nz = (int)st->slices.size();
+    std::vector<uint32_t> begin(nz + 1, 0), hk, hi;
+    uint64_t total = 0;
+    {
+        int z = 0;
+        for (auto& kv : st->slices) {
+            begin[z] = (uint32_t)total;
+            total += kv.second.k.size();
+            ++z;
+        }
+        begin[nz] = (uint32_t)total;
+    }
+    st->out.clear();
+    if (total >= (1ull << 32) - 1 || total > st->max_total) {
+        c->err = "ffs_stack3d_finish: too many strong pixels in the stack";
+        return FFS_ERR_OVERFLOW;
+    }
+    uint32_t n_calc = 0, fs = 0, fp = 0;
+    if (total > 0) {
+        hk.reserve(total);
+        hi.reserve(total);
+        for (auto& kv : st->slices) {
+            hk.insert(hk.end(), kv.second.k.begin(), kv.second.k.end());
+            hi.insert(hi.end(), kv.second.inten.begin(), kv.second.inten.end());
+        }
+        const uint32_t N = (uint32_t)total;
+        uint32_t *d_k = nullptr, *d_i = nullptr, *d_par = nullptr, *d_cid = nullptr, *d_begin = nullptr;
+        uint32_t *d_n = nullptr, *d_nc = nullptr, *d_ovf = nullptr, *d_sum = nullptr;
+        CompAcc* d_acc = nullptr;
+        ReflOut* d_recs = nullptr;
+        std::vector<void*> to_free;
+        auto cleanup = [&]() {
+            for (void* p : to_free) (void)hipFree(p);
+        };
+#define ST_TRY(expr)                                                            \
+    do {                                                                        \
+        hipError_t e_ = (expr);                                                 \
+        if (e_ != hipSuccess) {                                                 \
+            c->err = std::string(#expr) + ": " + hipGetErrorString(e_);         \
+            cleanup();                                                          \
+            return e_ == hipErrorOutOfMemory ? FFS_ERR_NOMEM : FFS_ERR_DEVICE;  \
+        }                                                                       \
+    } while (0)
+#define ST_ALLOC(ptr, bytes)            \
+    ST_TRY(dmalloc(&ptr, (bytes)));     \
+    to_free.push_back(ptr)
+        ST_ALLOC(d_k, (size_t)N * 4);
+        ST_ALLOC(d_i, (size_t)N * 4);
+        ST_ALLOC(d_par, (size_t)N * 4);
+        ST_ALLOC(d_cid, (size_t)N * 4);
+        ST_ALLOC(d_begin, (size_t)(nz + 1) * 4);
+        ST_ALLOC(d_n, 4);
+        ST_ALLOC(d_nc, 4);
+        ST_ALLOC(d_ovf, 4);
+        ST_ALLOC(d_sum, 32);
+        ST_ALLOC(d_acc, (size_t)N * sizeof(CompAcc));
+        ST_ALLOC(d_recs, (size_t)N * sizeof(ReflOut));
+        std::vector<uint32_t> iota(N);
+        for (uint32_t i = 0; i < N; ++i) iota[i] = i;
+        ST_TRY(hipMemcpy(d_k, hk.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+        ST_TRY(hipMemcpy(d_i, hi.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+        ST_TRY(hipMemcpy(d_par, iota.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+        ST_TRY(hipMemcpy(d_begin, begin.data(), (size_t)(nz + 1) * 4, hipMemcpyHostToDevice));
+        ST_TRY(hipMemcpy(d_n, &N, 4, hipMemcpyHostToDevice));
+        ST_TRY(hipMemset(d_ovf, 0, 4));
+        SegArgs sa{};
+        sa.list_k = d_k;
+        sa.list_i = d_i;
+        sa.parent = d_par;
+        sa.comp_id = d_cid;
+        sa.seg_n = d_n;
+        sa.seg_stride = N;
+        sa.n_comp = d_nc;
+        sa.acc = d_acc;
+        sa.max_comp = N;
+        sa.overflow = d_ovf;
+        sa.W = (uint32_t)c->L.W;
+        sa.slice_begin = d_begin;
+        sa.n_slices = nz;
+        sa.min_spot_size = c->params.min_spot_size_3d;
+        sa.max_sep = c->params.max_peak_centroid_separation;
+        sa.recs = d_recs;
+        sa.summary = d_sum;
+        const unsigned nb = (unsigned)std::min<uint64_t>(2048, ((uint64_t)N + 255) / 256);
+        hipLaunchKernelGGL(k_union<true>, dim3(nb, 1), dim3(256), 0, 0, sa);
+        hipLaunchKernelGGL(k_flatten, dim3(nb, 1), dim3(256), 0, 0, sa);
+        hipLaunchKernelGGL(k_label, dim3(1), dim3(1024), 0, 0, sa);
+        hipLaunchKernelGGL(k_reduce<true>, dim3(nb, 1), dim3(256), 0, 0, sa);
+        hipLaunchKernelGGL(k_finalize<true>, dim3(nb, 1), dim3(256), 0, 0, sa);
+        ST_TRY(hipGetLastError());
+        ST_TRY(hipDeviceSynchronize());
+        ST_TRY(hipMemcpy(&n_calc, d_nc, 4, hipMemcpyDeviceToHost));
+        std::vector<ReflOut> recs(n_calc);
+        if (n_calc) ST_TRY(hipMemcpy(recs.data(), d_recs, (size_t)n_calc * sizeof(ReflOut), hipMemcpyDeviceToHost));
+        cleanup();
+#undef ST_TRY
+#undef ST_ALLOC
+        for (const ReflOut& r : recs) {
+            if (r.flags & 1u) ++fs;
+            else if (r.flags & 2u) ++fp;
+            else {
+                ffs_reflection o;
+                std::memcpy(&o, &r, sizeof(o));
+                st->out.push_back(o);
+            }
+        }
+    }
+    if (reflections) *reflections = st->out.data();
+    if (n_refl) *n_refl = (uint32_t)st->out.size();
+    if (n_calculated) *n_calculated = n_calc;
+    if (n_f_size) *n_f_size = fs;
+    if (n_f_sep) *n_f_sep = fp;
+    return FFS_OK;
+}

@@ -1,0 +1,136 @@
+// ffs_device.h -- shared host/device definitions for libffs_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ffsamd {
+
+// ---- frame layout in HBM ---------------------------------------------------------------------
+// Pixels:      [frame][y][pitch_px] of PixelT, rows `pitch` bytes apart (multiple of 128 B).
+// Bit planes:  [frame][y][mpitch] bytes, 1 bit per pixel, LSB first (bit x&7 of byte x>>3);
+//              bits for x >= W are always 0.  Used for: valid-pixel mask (one plane per
+//              context, frame-invariant), candidate plane, strong plane (candidate plane
+//              filtered in place).
+// Byte mask:   [frame][y][bpitch] bytes 0/1 -- the reference kernel's result_strong layout
+//              (spotfinder/kernels/thresholding.cu:233), kept as the drop-in contract.
+struct Layout {
+    int W, H;
+    int pitch_px;        // multiple of 64, >= W
+    uint32_t pitch;      // bytes per pixel row (default layout)
+    uint32_t mpitch;     // bytes per bit-plane row  = pitch_px / 8
+    uint32_t bpitch;     // bytes per byte-mask row  = pitch_px
+    uint64_t frame_stride;       // bytes between frames (default layout)
+    uint64_t plane_frame_stride; // bytes between frames of a bit plane = H * mpitch
+    uint64_t bytes_frame_stride; // bytes between frames of the byte mask = H * bpitch
+};
+
+// ---- candidate kernel geometry -----------------------------------------------------------------
+// One wave64 marches down a column strip of 64 lanes x 8 px = 512 px.  Lanes 0 and 63 are halo
+// (their windows are incomplete), lanes 1..62 own 496 px of output.  Strip s covers
+// x in [496 s - 8, 496 s + 504).
+constexpr int kLanePx = 8;
+constexpr int kStripOwnedPx = 62 * kLanePx;  // 496
+constexpr int kStripStartOffset = -kLanePx;  // strip 0 starts at x = -8 (lane 0 inactive)
+
+// Exact-stage tiles: one 256-thread workgroup per 8 rows.
+constexpr int kTileRows = 8;
+constexpr int kExactListCap = 8192;  // candidate entries staged in LDS per flush
+
+struct ThresholdArgs {
+    const void* image;         // device pixels
+    uint64_t frame_stride;     // bytes
+    uint32_t pitch;            // bytes
+    const uint8_t* maskbits;   // valid-pixel bit plane [H][mpitch]
+    uint8_t* bits;             // candidate / strong bit planes [n][H][mpitch]
+    uint8_t* strong_bytes;     // byte masks [n][H][bpitch]
+    uint32_t* tile_counts;     // [n][n_tiles] strong pixels per exact-stage tile
+    int W, H, pitch_px;
+    uint32_t mpitch, bpitch;
+    uint64_t plane_frame_stride, bytes_frame_stride;
+    int n_strips, band_rows, n_bands, n_tiles;
+    // parameters
+    float kS;                  // nsig_s^2 (1 - 2^-16): conservative signal pre-filter
+    int min_count;
+    double nsig_b, nsig_s, threshold;
+    long long max_valid;       // < 0: no test
+};
+
+// ---- strong-pixel lists and connected components -------------------------------------------------
+struct CclArgs {
+    const void* image;
+    uint64_t frame_stride;
+    uint32_t pitch;
+    const uint8_t* bits;       // strong bit planes
+    const uint32_t* tile_counts;
+    uint32_t* tile_offsets;    // [n][n_tiles]
+    uint32_t* num_strong;      // [n]
+    uint32_t* list_k;          // [n][cap] ascending linear index y*W + x
+    uint32_t* list_i;          // [n][cap] intensity
+    uint32_t* parent;          // [n][cap]
+    uint32_t* comp_id;         // [n][cap] component number of each ROOT entry
+    uint32_t* n_comp;          // [n]
+    uint32_t* overflow;        // [1] set if any frame exceeded cap / max_comp
+    int W, H, pitch_px;
+    uint32_t mpitch;
+    uint64_t plane_frame_stride;
+    int n_tiles;
+    uint32_t cap;              // list capacity per frame
+    uint32_t max_comp;         // record capacity per frame
+    int pixel_bytes;
+};
+
+// Per-component accumulator (device) -- reduced with 64-bit integer atomics so the result
+// is independent of arrival order (the reference's double sums of half-integer * integer
+// terms are exact, connected_components.hpp:86-90, so integer sums reproduce them bit for bit).
+struct CompAcc {
+    unsigned long long sum_i;    // sum I
+    unsigned long long sum_xi;   // sum (2x+1) I
+    unsigned long long sum_yi;   // sum (2y+1) I
+    unsigned long long sum_zi;   // sum (2z+1) I
+    unsigned long long peak;     // (I << 32) | ~(position rank): max => highest I, then smallest (z,y,x)
+    uint32_t x_min, x_max, y_min, y_max;
+    int32_t z_min, z_max;
+    uint32_t num_pixels;
+    uint32_t root;               // list index of the minimum vertex (label order key)
+};
+
+// A segment is one independent labelling problem: a frame (2D) or a whole z-stack (3D).
+struct SegArgs {
+    const uint32_t* list_k;   // per segment: ascending (z, k)
+    const uint32_t* list_i;
+    uint32_t* parent;
+    uint32_t* comp_id;
+    const uint32_t* seg_n;    // [n_seg] entries per segment
+    uint64_t seg_stride;      // entries between segment starts
+    uint32_t* n_comp;         // [n_seg]
+    CompAcc* acc;             // [n_seg][max_comp]
+    uint32_t max_comp;
+    uint32_t* overflow;
+    uint32_t W;
+    // 3D only
+    const uint32_t* slice_begin;  // [n_slices + 1] entry offsets of each slice inside the segment
+    int n_slices;
+    // finalize
+    uint32_t min_spot_size;
+    float max_sep;
+    void* recs;               // ffs_reflection, packed: segment s starts at sum_{q<s} n_comp[q]
+    uint32_t* summary;        // [n_seg][8]: n_boxes, n_strong_filtered, n_refl, n_filt_size, n_filt_sep
+};
+
+
+// Matches ffs_reflection in include/ffs_hip.h
+struct ReflOut {
+    uint32_t x_min, x_max, y_min, y_max;
+    int32_t z_min, z_max;
+    int32_t num_pixels;
+    float com_x, com_y, com_z;
+    uint32_t peak_x, peak_y;
+    int32_t peak_z;
+    uint32_t peak_intensity;
+    float peak_centroid_distance;
+    uint32_t flags;
+    unsigned long long sum_intensity;
+};
+
+
+}  // namespace ffsamd

@@ -1,0 +1,349 @@
+// kernels_ccl.hpp (included by ffs_api.hip) -- strong-pixel compaction and 2D/3D connected components on gfx950.
+//
+// Replaces the reference's host stage (spotfinder/connected_components/connected_components.cc):
+// a std::map of strong pixels, a Boost adjacency_list with edges to k+1 and k+width, and
+// boost::connected_components (DFS => components numbered by their minimum vertex).  Here:
+//   k_scan_tiles / k_emit_list : strong bit plane -> per-frame list sorted by linear index
+//                                (popcount + wave/block prefix sums; no sort needed)
+//   k_union                    : lock-free union-find, union-by-minimum-index (atomicMin hooks),
+//                                neighbours found by binary search in the sorted list
+//   k_flatten, k_label         : roots, component numbers in order of minimum vertex
+//   k_reduce                   : per-component bbox / sums / peak with integer atomics
+//   k_finalize                 : centre of mass, peak-centroid distance, filters
+// The same kernels serve the 3D case (a z-stack of per-frame lists, one extra edge to the same
+// linear index in the next slice, connected_components.cc:352-370).
+#pragma once
+#include "ffs_device.h"
+
+namespace ffsamd {
+
+// ---- block-wide exclusive prefix sum (256 or 1024 threads) ---------------------------------------
+template <int NT>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_wave, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+        const uint32_t c = s_wave[w];
+        if (w < wave) base += c;
+        tot += c;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+// ---- compaction ------------------------------------------------------------------------------------
+
+// One block per frame: exclusive scan of the exact stage's per-tile strong counts.
+__global__ __launch_bounds__(256) void k_scan_tiles(const CclArgs a) {
+    __shared__ uint32_t s_wave[4];
+    const int frame = blockIdx.x;
+    const uint32_t* cnt = a.tile_counts + (uint64_t)frame * a.n_tiles;
+    uint32_t* off = a.tile_offsets + (uint64_t)frame * a.n_tiles;
+    uint32_t running = 0;
+    for (int t0 = 0; t0 < a.n_tiles; t0 += 256) {
+        const int t = t0 + threadIdx.x;
+        const uint32_t v = t < a.n_tiles ? cnt[t] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan<256>(v, s_wave, total);
+        if (t < a.n_tiles) off[t] = running + ex;
+        running += total;
+    }
+    if (threadIdx.x == 0) {
+        a.num_strong[frame] = running;
+        if (running > a.cap) atomicOr(a.overflow, 1u);
+    }
+}
+
+// One block per (tile, frame): bits -> (k, intensity) in raster order; parent[i] = i.
+template <typename PixelT>
+__global__ __launch_bounds__(256) void k_emit_list(const CclArgs a) {
+    __shared__ uint32_t s_wave[4];
+    const int tile = blockIdx.x, frame = blockIdx.y;
+    const uint32_t count = a.tile_counts[(uint64_t)frame * a.n_tiles + tile];
+    if (count == 0) return;  // block-uniform
+    const int y0 = tile * kTileRows;
+    const int rows = min(kTileRows, a.H - y0);
+    const int dpr = a.mpitch >> 2;
+    const int ndw = rows * dpr;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(
+        a.bits + (uint64_t)frame * a.plane_frame_stride + (uint64_t)y0 * a.mpitch);
+    const uint8_t* img = (const uint8_t*)a.image + (uint64_t)frame * a.frame_stride;
+    uint32_t* lk = a.list_k + (uint64_t)frame * a.cap;
+    uint32_t* li = a.list_i + (uint64_t)frame * a.cap;
+    uint32_t* par = a.parent + (uint64_t)frame * a.cap;
+    uint32_t running = a.tile_offsets[(uint64_t)frame * a.n_tiles + tile];
+    for (int pos = 0; pos < ndw; pos += 256) {
+        const int g = pos + threadIdx.x;
+        uint32_t w = g < ndw ? words[g] : 0u;
+        uint32_t total;
+        uint32_t at = running + block_exclusive_scan<256>(__popc(w), s_wave, total);
+        running += total;
+        if (w) {
+            const int row = g / dpr;
+            const int xb = (g - row * dpr) * 32;
+            const int y = y0 + row;
+            while (w) {
+                const int bit = __ffs(w) - 1;
+                w &= w - 1;
+                const int x = xb + bit;
+                if (at < a.cap) {
+                    lk[at] = (uint32_t)y * (uint32_t)a.W + (uint32_t)x;
+                    li[at] = *reinterpret_cast<const PixelT*>(img + (uint64_t)y * a.pitch
+                                                               + (uint64_t)x * sizeof(PixelT));
+                    par[at] = at;
+                }
+                ++at;
+            }
+        }
+    }
+}
+template __global__ void k_emit_list<uint16_t>(const CclArgs);
+template __global__ void k_emit_list<uint32_t>(const CclArgs);
+
+// ---- union-find --------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t ld_parent(const uint32_t* p) {
+    // agent-scope load: bypasses this CU's L1, which other CUs' atomics never refresh
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t v) {
+    uint32_t p = ld_parent(parent + v);
+    while (p != v) {
+        v = p;
+        p = ld_parent(parent + v);
+    }
+    return v;
+}
+
+// Union by minimum index: the root of every tree is its smallest member, so
+// label order = order of the minimum vertex = Boost's DFS discovery order.
+__device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t b) {
+    for (;;) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a > b) {
+            const uint32_t t = a;
+            a = b;
+            b = t;
+        }
+        const uint32_t old = atomicMin(parent + b, a);  // hook the larger root under the smaller
+        if (old == b) return;
+        b = old;  // somebody else re-parented b meanwhile: retry from there
+    }
+}
+
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_union(const SegArgs a) {
+    const int seg = blockIdx.y;
+    const uint32_t n = min(a.seg_n[seg], (uint32_t)a.seg_stride);
+    const uint32_t* k = a.list_k + (uint64_t)seg * a.seg_stride;
+    uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
+    uint32_t z = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        uint32_t s_end = n, nb = 0, ne = 0;
+        if (IS3D) {
+            // slice of entry i (slices ascending; advance monotonically within this thread)
+            while (a.slice_begin[z + 1] <= i) ++z;
+            s_end = a.slice_begin[z + 1];
+            if ((int)z + 1 < a.n_slices) { nb = a.slice_begin[z + 1]; ne = a.slice_begin[z + 2]; }
+        }
+        const uint32_t ki = k[i];
+        // right neighbour: k + 1, with NO row-end check (connected_components.cc:62-70)
+        if (i + 1 < s_end && k[i + 1] == ki + 1) uf_union(parent, i, i + 1);
+        // neighbour below: k + width (:63, :73-78)
+        {
+            uint32_t lo = i + 1, hi = min(s_end, i + 1 + a.W);
+            const uint32_t key = ki + a.W;
+            while (lo < hi) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (k[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            if (lo < s_end && k[lo] == key) uf_union(parent, i, lo);
+        }
+        if (IS3D && nb < ne) {  // same pixel in the next slice (:352-370)
+            uint32_t lo = nb, hi = ne;
+            while (lo < hi) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (k[mid] < ki) lo = mid + 1; else hi = mid;
+            }
+            if (lo < ne && k[lo] == ki) uf_union(parent, i, lo);
+        }
+    }
+}
+template __global__ void k_union<false>(const SegArgs);
+template __global__ void k_union<true>(const SegArgs);
+
+__global__ __launch_bounds__(256) void k_flatten(const SegArgs a) {
+    const int seg = blockIdx.y;
+    const uint32_t n = min(a.seg_n[seg], (uint32_t)a.seg_stride);
+    uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t r = uf_find(parent, i);
+        if (r != i) __hip_atomic_store(parent + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// One block per segment: number the roots in ascending order and reset their accumulators.
+__global__ __launch_bounds__(1024) void k_label(const SegArgs a) {
+    __shared__ uint32_t s_wave[16];
+    const int seg = blockIdx.x;
+    const uint32_t n = min(a.seg_n[seg], (uint32_t)a.seg_stride);
+    const uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
+    uint32_t* comp_id = a.comp_id + (uint64_t)seg * a.seg_stride;
+    CompAcc* acc = a.acc + (uint64_t)seg * a.max_comp;
+    uint32_t running = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool root = i < n && parent[i] == i;
+        uint32_t total;
+        const uint32_t c = running + block_exclusive_scan<1024>(root ? 1u : 0u, s_wave, total);
+        running += total;
+        if (root) {
+            comp_id[i] = c;
+            if (c < a.max_comp) {
+                CompAcc z;
+                z.sum_i = z.sum_xi = z.sum_yi = z.sum_zi = 0ull;
+                z.peak = 0ull;
+                z.x_min = 0xFFFFFFFFu; z.x_max = 0u;
+                z.y_min = 0xFFFFFFFFu; z.y_max = 0u;
+                z.z_min = 0x7FFFFFFF; z.z_max = (int32_t)0x80000000;
+                z.num_pixels = 0u;
+                z.root = i;
+                acc[c] = z;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        a.n_comp[seg] = running;
+        if (running > a.max_comp) atomicOr(a.overflow, 2u);
+        uint32_t* sm = a.summary + (uint64_t)seg * 8;
+        for (int q = 0; q < 8; ++q) sm[q] = 0;
+    }
+}
+
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_reduce(const SegArgs a) {
+    const int seg = blockIdx.y;
+    const uint32_t n = min(a.seg_n[seg], (uint32_t)a.seg_stride);
+    const uint32_t* k = a.list_k + (uint64_t)seg * a.seg_stride;
+    const uint32_t* inten = a.list_i + (uint64_t)seg * a.seg_stride;
+    const uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
+    const uint32_t* comp_id = a.comp_id + (uint64_t)seg * a.seg_stride;
+    CompAcc* acc = a.acc + (uint64_t)seg * a.max_comp;
+    uint32_t z = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        if (IS3D) {
+            while (a.slice_begin[z + 1] <= i) ++z;
+        }
+        const uint32_t c = comp_id[parent[i]];
+        if (c >= a.max_comp) continue;
+        CompAcc* r = acc + c;
+        const uint32_t ki = k[i];
+        const uint32_t y = ki / a.W, x = ki - y * a.W;
+        const unsigned long long I = inten[i];
+        atomicMin(&r->x_min, x);
+        atomicMax(&r->x_max, x);
+        atomicMin(&r->y_min, y);
+        atomicMax(&r->y_max, y);
+        if (IS3D) {
+            atomicMin(&r->z_min, (int32_t)z);
+            atomicMax(&r->z_max, (int32_t)z);
+            atomicAdd(&r->sum_zi, (2ull * z + 1ull) * I);
+        }
+        atomicAdd(&r->num_pixels, 1u);
+        atomicAdd(&r->sum_i, I);
+        atomicAdd(&r->sum_xi, (2ull * x + 1ull) * I);
+        atomicAdd(&r->sum_yi, (2ull * y + 1ull) * I);
+        // highest intensity, ties -> smallest (z, y, x) = smallest list index
+        // (connected_components.hpp:125-170, connected_components.cc:143-157)
+        atomicMax(&r->peak, (I << 32) | (unsigned long long)(0xFFFFFFFFu - i));
+    }
+}
+template __global__ void k_reduce<false>(const SegArgs);
+template __global__ void k_reduce<true>(const SegArgs);
+
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_finalize(const SegArgs a) {
+    const int seg = blockIdx.y;
+    const uint32_t nc = min(a.n_comp[seg], a.max_comp);
+    const uint32_t* k = a.list_k + (uint64_t)seg * a.seg_stride;
+    const CompAcc* acc = a.acc + (uint64_t)seg * a.max_comp;
+    __shared__ uint32_t s_base;
+    if (threadIdx.x == 0) {
+        uint32_t b = 0;
+        for (int q = 0; q < seg; ++q) b += min(a.n_comp[q], a.max_comp);
+        s_base = b;
+    }
+    __syncthreads();
+    ReflOut* recs = reinterpret_cast<ReflOut*>(a.recs) + s_base;
+    uint32_t* sm = a.summary + (uint64_t)seg * 8;
+    for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < nc; c += gridDim.x * 256) {
+        const CompAcc r = acc[c];
+        ReflOut o;
+        o.x_min = r.x_min; o.x_max = r.x_max; o.y_min = r.y_min; o.y_max = r.y_max;
+        o.z_min = IS3D ? r.z_min : 0; o.z_max = IS3D ? r.z_max : 0;
+        o.num_pixels = (int32_t)r.num_pixels;
+        o.sum_intensity = r.sum_i;
+        // center_of_mass(): double sums of (c + 0.5) * I, quotient narrowed to float
+        // (connected_components.hpp:81-100).  sum (2c+1) I is an exact integer; * 0.5 is exact.
+        const double tot = (double)r.sum_i;
+        const double wx = (double)r.sum_xi * 0.5, wy = (double)r.sum_yi * 0.5;
+        const double wz = IS3D ? (double)r.sum_zi * 0.5 : 0.5 * tot;  // z = 0 for 2D (:247)
+        o.com_x = (float)(wx / tot);
+        o.com_y = (float)(wy / tot);
+        o.com_z = (float)(wz / tot);
+        const uint32_t pi = 0xFFFFFFFFu - (uint32_t)(r.peak & 0xFFFFFFFFull);
+        const uint32_t pk = k[pi];
+        o.peak_y = pk / a.W;
+        o.peak_x = pk - o.peak_y * a.W;
+        o.peak_intensity = (uint32_t)(r.peak >> 32);
+        int pz = 0;
+        if (IS3D) {
+            int lo = 0, hi = a.n_slices;  // slice containing entry pi
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (a.slice_begin[mid] <= pi) lo = mid; else hi = mid;
+            }
+            pz = lo;
+        }
+        o.peak_z = pz;
+        // peak_centroid_distance(): float arithmetic, connected_components.hpp:194-198.
+        // Each product/sum rounds to float (no contraction in this library); the float sqrt is
+        // taken through the correctly rounded double sqrt (double rounding is harmless for sqrt).
+        const float dx = ((float)o.peak_x + 0.5f) - o.com_x;
+        const float dy = ((float)o.peak_y + 0.5f) - o.com_y;
+        const float dz = ((float)pz + 0.5f) - o.com_z;
+        const float s2 = (dx * dx + dy * dy) + dz * dz;
+        o.peak_centroid_distance = (float)__builtin_sqrt((double)s2);
+        uint32_t flags = 0;
+        // filter_reflections(): size first, then separation (connected_components.cc:207-236)
+        if (a.min_spot_size > 0 && r.num_pixels < a.min_spot_size) flags |= 1u;
+        else if (a.max_sep > 0.0f && o.peak_centroid_distance > a.max_sep) flags |= 2u;
+        o.flags = flags;
+        recs[c] = o;
+        // generate_boxes() filter (connected_components.cc:122-138)
+        if (a.min_spot_size == 0 || r.num_pixels >= a.min_spot_size) {
+            atomicAdd(&sm[0], 1u);
+            atomicAdd(&sm[1], r.num_pixels);
+        }
+        if (flags == 0) atomicAdd(&sm[2], 1u);
+        if (flags & 1u) atomicAdd(&sm[3], 1u);
+        if (flags & 2u) atomicAdd(&sm[4], 1u);
+    }
+}
+template __global__ void k_finalize<false>(const SegArgs);
+template __global__ void k_finalize<true>(const SegArgs);
+
+}  // namespace ffsamd

@@ -1,0 +1,495 @@
+// kernels_threshold.hpp (included by ffs_api.hip) -- dispersion thresholding for gfx950 (CDNA4), two kernels.
+//
+// What the reference does: one 7x7 masked window sum per pixel from a shared-memory tile and a
+// float32 test (spotfinder/kernels/thresholding.cu:60-125, :145-234).  What "bit-exact" is judged
+// against: the float64 summed-area-table predicate of baseline/spotfinder/standalone.cc:113-174.
+//
+// MI355X design:
+//   K1 `k_candidates`  streams the frame once.  A wave64 marches down a 512-px column strip with a
+//      7-row register ring; the masked pixel value and the valid count share ONE 32-bit word
+//      (value + 2^22 per valid pixel: 49*65535 < 2^22, 49 < 2^6), so the exact integer window
+//      sums {sum p, n} cost one running vertical add/sub and one sliding horizontal add/sub per
+//      pixel; neighbours across lanes come from DPP wave shifts.  It evaluates a CONSERVATIVE
+//      float32 form of the signal test (b > nsig_s sqrt(x m)) and emits a 1-bit/pixel candidate
+//      plane (never misses a strong pixel; typically ~0.5 % of pixels pass) and zero-fills the
+//      byte mask.  No sum of squares, no fp64, no LDS in this kernel: it is a pure HBM stream.
+//   K2 `k_exact`       visits only the candidates: exact integer 7x7 sums {n, sum p, sum p^2}
+//      and the oracle's fp64 predicate, operation for operation; clears failed candidates in the
+//      bit plane (it becomes the strong plane) and sets the byte mask.
+#pragma once
+#include "ffs_device.h"
+
+namespace ffsamd {
+
+// ================================================================================================
+// K1: candidates, uint16 pixels
+// ================================================================================================
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    // raw buffer, stride 0; DST_SEL/format word as in the CDNA guides (0x00020000)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+
+constexpr uint32_t kFlag = 1u << 22;       // one valid pixel
+constexpr uint32_t kXMask = kFlag - 1u;    // low 22 bits: sum of pixel values
+
+// lane i <- lane i-1 (lane 0 gets 0)
+__device__ __forceinline__ uint32_t from_left(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+}
+// lane i <- lane i+1 (lane 63 gets 0)
+__device__ __forceinline__ uint32_t from_right(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
+}
+
+struct RowRegsU16 {
+    uint4 raw;     // 8 pixels
+    uint32_t mb;   // 8 valid bits
+};
+
+__device__ __forceinline__ void unpack_u16(const RowRegsU16& r, uint32_t (&A)[8]) {
+    const uint32_t w[4] = {r.raw.x, r.raw.y, r.raw.z, r.raw.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t lo = (w[q] & 0xFFFFu) | kFlag;
+        const uint32_t hi = (w[q] >> 16) | kFlag;
+        const uint32_t vlo = (uint32_t)__builtin_amdgcn_sbfe((int)r.mb, 2 * q, 1);  // 0 / ~0
+        const uint32_t vhi = (uint32_t)__builtin_amdgcn_sbfe((int)r.mb, 2 * q + 1, 1);
+        A[2 * q] = lo & vlo;
+        A[2 * q + 1] = hi & vhi;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_candidates_u16(const ThresholdArgs a) {
+    const int lane = threadIdx.x;
+    const int strip = blockIdx.x % a.n_strips;
+    const int band = blockIdx.x / a.n_strips;
+    const int frame = blockIdx.y;
+    const int yb0 = band * a.band_rows;
+    const int yb1 = min(yb0 + a.band_rows, a.H);
+    const int lx0 = strip * kStripOwnedPx + kStripStartOffset + lane * kLanePx;
+    const bool active = lx0 >= 0 && lx0 + kLanePx <= a.pitch_px;
+    const bool owned = active && lane >= 1 && lane <= 62;
+    const int cx = active ? lx0 : 0;  // inactive lanes read column 0 and get their valid bits zeroed
+
+    // Buffer resources (wave-uniform, SGPRs): per-lane column offset in a VGPR, row offset in an
+    // SGPR, so no per-row VALU address arithmetic; out-of-range accesses are dropped by hardware.
+    const rsrc_t r_img = make_rsrc((const uint8_t*)a.image + (uint64_t)frame * a.frame_stride,
+                                   (uint32_t)a.H * a.pitch);
+    const rsrc_t r_mask = make_rsrc(a.maskbits, (uint32_t)a.H * a.mpitch);
+    const rsrc_t r_sb = make_rsrc(a.strong_bytes + (uint64_t)frame * a.bytes_frame_stride,
+                                  (uint32_t)a.H * a.bpitch);
+    const rsrc_t r_cb = make_rsrc(a.bits + (uint64_t)frame * a.plane_frame_stride,
+                                  (uint32_t)a.H * a.mpitch);
+    const uint32_t off_px = (uint32_t)cx * 2u, off_bit = (uint32_t)cx >> 3, off_byte = (uint32_t)cx;
+
+    const int total = (yb1 - yb0) + 6;  // incoming rows yb0-3 .. yb1+2
+    const float kS = a.kS;
+
+    uint32_t ring[7][8];
+    uint32_t col[8];
+    RowRegsU16 pre[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ring[s][j] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) col[j] = 0;
+
+    // issue the loads of incoming row number i (image row yb0 - 3 + i) into slot `s`
+    auto fetch = [&](RowRegsU16& dst, int i) {
+        const int yin = yb0 - 3 + i;
+        if (i < total && yin >= 0 && yin < a.H) {  // wave-uniform
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_img, off_px, (uint32_t)yin * a.pitch, 0);
+            dst.raw = make_uint4(v[0], v[1], v[2], v[3]);
+            const uint32_t mb = __builtin_amdgcn_raw_buffer_load_b8(r_mask, off_bit, (uint32_t)yin * a.mpitch, 0);
+            dst.mb = active ? mb : 0u;
+        } else {
+            dst.raw = make_uint4(0, 0, 0, 0);
+            dst.mb = 0u;
+        }
+    };
+
+    // vertical running sum: add incoming row, retire the row that left the 7-row window
+    auto push = [&](int s, const uint32_t (&A)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            col[j] += A[j] - ring[s][j];
+            ring[s][j] = A[j];
+        }
+    };
+
+#pragma unroll
+    for (int s = 0; s < 7; ++s) fetch(pre[s], s);
+
+    // warm-up: rows 0..5 of the band's input only fill the window
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        uint32_t A[8];
+        unpack_u16(pre[s], A);
+        fetch(pre[s], s + 7);
+        push(s, A);
+    }
+
+    for (int base = 6; base < total; base += 7) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const int s = (6 + t) % 7;   // slot of incoming row i (i % 7 == s)
+            const int sc = (s + 4) % 7;  // slot of the centre row i - 3
+            const int i = base + t;
+            if (i < total) {
+                uint32_t A[8];
+                unpack_u16(pre[s], A);
+                fetch(pre[s], i + 7);
+                push(s, A);
+
+                // horizontal 7-tap over column sums c[-3..10] = L5 L6 L7 c0..c7 R0 R1 R2
+                const uint32_t L5 = from_left(col[5]), L6 = from_left(col[6]), L7 = from_left(col[7]);
+                const uint32_t R0 = from_right(col[0]), R1 = from_right(col[1]), R2 = from_right(col[2]);
+                uint32_t Wn[8];
+                Wn[0] = (L5 + L6 + L7) + (col[0] + col[1] + col[2]) + col[3];
+                Wn[1] = Wn[0] - L5 + col[4];
+                Wn[2] = Wn[1] - L6 + col[5];
+                Wn[3] = Wn[2] - L7 + col[6];
+                Wn[4] = Wn[3] - col[0] + col[7];
+                Wn[5] = Wn[4] - col[1] + R0;
+                Wn[6] = Wn[5] - col[2] + R1;
+                Wn[7] = Wn[6] - col[3] + R2;
+
+                // conservative signal test on the centre row:
+                //   oracle: b = m p - x > nsig_s sqrt(x m)   (standalone.cc:167,169-170)
+                //   here:   b |b| > nsig_s^2 (1 - 2^-16) x m  in float32 (b exact, |b| < 2^22).
+                // An invalid centre has A = 0 -> p = 0 -> b <= 0 -> never a candidate; m < 2
+                // gives b = 0 likewise.
+                // e = kS x m - b|b| is negative exactly for candidates; its sign bit is shifted
+                // into the lane's candidate byte with one v_alignbit per pixel (j = 7 first).
+                uint32_t cb = 0;
+#pragma unroll
+                for (int j = 7; j >= 0; --j) {
+                    const uint32_t x = Wn[j] & kXMask;
+                    const uint32_t m = Wn[j] >> 22;
+                    const uint32_t pv = ring[sc][j] & kXMask;
+                    const int32_t b = (int32_t)(m * pv) - (int32_t)x;  // 24-bit multiplies
+                    const uint32_t tq = x * m;
+                    const float bf = (float)b;
+                    const float tf = (float)tq;
+                    const float lhs = bf * __builtin_fabsf(bf);
+                    const float e = __builtin_fmaf(kS, tf, -lhs);
+                    cb = __builtin_amdgcn_alignbit(cb, __float_as_uint(e), 31);
+                }
+
+                const int yout = yb0 + (i - 6);
+                if (owned) {
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte, (uint32_t)yout * a.bpitch, 0);
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)cb, r_cb, off_bit, (uint32_t)yout * a.mpitch, 0);
+                }
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// K1: candidates, uint32 pixels (the reference's PIXEL_DATA_32BIT build, h5read.h:16-20)
+// ================================================================================================
+// Same structure with 4 pixels (16 B) per lane.  The oracle only sums pixels < 2^24
+// (standalone.cc:78,90), so sum p < 2^30 and the count no longer shares a word with it: two
+// running words per pixel (X = sum p, M = count).  Lanes 0,1 and 62,63 are halo; lanes 2..61 own
+// 240 px, so that an (even, odd) lane pair owns exactly one byte of the candidate plane.
+constexpr int kLanePx32 = 4;
+constexpr int kStripOwnedPx32 = 60 * kLanePx32;  // 240
+constexpr int kStripStartOffset32 = -8;
+
+struct RowRegsU32 {
+    uint4 raw;     // 4 pixels
+    uint32_t mb;   // 4 valid bits
+};
+
+__global__ __launch_bounds__(64) void k_candidates_u32(const ThresholdArgs a) {
+    const int lane = threadIdx.x;
+    const int strip = blockIdx.x % a.n_strips;
+    const int band = blockIdx.x / a.n_strips;
+    const int frame = blockIdx.y;
+    const int yb0 = band * a.band_rows;
+    const int yb1 = min(yb0 + a.band_rows, a.H);
+    const int lx0 = strip * kStripOwnedPx32 + kStripStartOffset32 + lane * kLanePx32;
+    const bool active = lx0 >= 0 && lx0 + kLanePx32 <= a.pitch_px;
+    const bool owned = active && lane >= 2 && lane <= 61;
+    const int cx = active ? lx0 : 0;
+
+    const rsrc_t r_img = make_rsrc((const uint8_t*)a.image + (uint64_t)frame * a.frame_stride,
+                                   (uint32_t)a.H * a.pitch);
+    const rsrc_t r_mask = make_rsrc(a.maskbits, (uint32_t)a.H * a.mpitch);
+    const rsrc_t r_sb = make_rsrc(a.strong_bytes + (uint64_t)frame * a.bytes_frame_stride,
+                                  (uint32_t)a.H * a.bpitch);
+    const rsrc_t r_cb = make_rsrc(a.bits + (uint64_t)frame * a.plane_frame_stride,
+                                  (uint32_t)a.H * a.mpitch);
+    const uint32_t off_px = (uint32_t)cx * 4u, off_bit = (uint32_t)cx >> 3, off_byte = (uint32_t)cx;
+    const uint32_t nib = (uint32_t)cx & 4u;
+
+    const int total = (yb1 - yb0) + 6;
+    const float kS = a.kS;
+
+    uint32_t ringX[7][4], ringF[7];  // masked pixel values; flags: bits 0-3 summed, bits 4-7 mask
+    uint32_t colX[4], colM[4];
+    RowRegsU32 pre[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        ringF[s] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ringX[s][j] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { colX[j] = 0; colM[j] = 0; }
+
+    auto fetch = [&](RowRegsU32& dst, int i) {
+        const int yin = yb0 - 3 + i;
+        if (i < total && yin >= 0 && yin < a.H) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_img, off_px, (uint32_t)yin * a.pitch, 0);
+            dst.raw = make_uint4(v[0], v[1], v[2], v[3]);
+            const uint32_t mb = __builtin_amdgcn_raw_buffer_load_b8(r_mask, off_bit, (uint32_t)yin * a.mpitch, 0);
+            dst.mb = active ? ((mb >> nib) & 0xFu) : 0u;
+        } else {
+            dst.raw = make_uint4(0, 0, 0, 0);
+            dst.mb = 0u;
+        }
+    };
+
+    auto push = [&](int s, const RowRegsU32& r) {
+        const uint32_t p[4] = {r.raw.x, r.raw.y, r.raw.z, r.raw.w};
+        uint32_t fl = r.mb << 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool sm = ((r.mb >> j) & 1u) && p[j] < (1u << 24);  // mm, standalone.cc:90
+            const uint32_t X = sm ? p[j] : 0u;
+            const uint32_t Mn = sm ? 1u : 0u;
+            const uint32_t Mo = (ringF[s] >> j) & 1u;
+            colX[j] += X - ringX[s][j];
+            colM[j] += Mn - Mo;
+            ringX[s][j] = X;
+            fl |= Mn << j;
+        }
+        ringF[s] = fl;
+    };
+
+#pragma unroll
+    for (int s = 0; s < 7; ++s) fetch(pre[s], s);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const RowRegsU32 r = pre[s];
+        fetch(pre[s], s + 7);
+        push(s, r);
+    }
+
+    for (int base = 6; base < total; base += 7) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const int s = (6 + t) % 7;
+            const int sc = (s + 4) % 7;
+            const int i = base + t;
+            if (i < total) {
+                const RowRegsU32 r = pre[s];
+                fetch(pre[s], i + 7);
+                push(s, r);
+
+                // c[-3..6] = L1 L2 L3 c0..c3 R0 R1 R2 for both words
+                uint32_t WX[4], WM[4];
+                {
+                    const uint32_t L1 = from_left(colX[1]), L2 = from_left(colX[2]), L3 = from_left(colX[3]);
+                    const uint32_t R0 = from_right(colX[0]), R1 = from_right(colX[1]), R2 = from_right(colX[2]);
+                    WX[0] = (L1 + L2 + L3) + (colX[0] + colX[1] + colX[2]) + colX[3];
+                    WX[1] = WX[0] - L1 + R0;
+                    WX[2] = WX[1] - L2 + R1;
+                    WX[3] = WX[2] - L3 + R2;
+                }
+                {
+                    const uint32_t L1 = from_left(colM[1]), L2 = from_left(colM[2]), L3 = from_left(colM[3]);
+                    const uint32_t R0 = from_right(colM[0]), R1 = from_right(colM[1]), R2 = from_right(colM[2]);
+                    WM[0] = (L1 + L2 + L3) + (colM[0] + colM[1] + colM[2]) + colM[3];
+                    WM[1] = WM[0] - L1 + R0;
+                    WM[2] = WM[1] - L2 + R1;
+                    WM[3] = WM[2] - L3 + R2;
+                }
+
+                // Conservative signal test.  b = m p - x is evaluated in float32 with an explicit
+                // error bound E = 2^-22 (m p + x) added (|fl(b) - b| < E); a valid centre pixel
+                // >= 2^24 (outside the sums, but a legal centre) is passed on unconditionally.
+                uint32_t cb = 0;
+                const uint32_t fc = ringF[sc];
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {
+                    const float xf = (float)WX[j];
+                    const float mf = (float)WM[j];
+                    const float pf = (float)ringX[sc][j];
+                    const float sp = __builtin_fmaf(mf, pf, xf);
+                    const float bf = __builtin_fmaf(mf, pf, -xf);
+                    const float u = __builtin_fmaf(sp, 2.384185791015625e-07f, bf);
+                    const float lhs = u * __builtin_fabsf(u);
+                    const float tf = xf * mf;
+                    const float e = __builtin_fmaf(kS, tf, -lhs);
+                    const uint32_t big = ((fc >> (4 + j)) & ~(fc >> j)) & 1u;  // masked-in but not summed
+                    cb = (cb << 1) | ((__float_as_uint(e) >> 31) | big);
+                }
+
+                // an (even, odd) lane pair shares one byte of the candidate plane
+                const uint32_t hi = from_right(cb);
+                const int yout = yb0 + (i - 6);
+                if (owned) {
+                    __builtin_amdgcn_raw_buffer_store_b32(0u, r_sb, off_byte, (uint32_t)yout * a.bpitch, 0);
+                    if (!(lane & 1))
+                        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(cb | (hi << 4)), r_cb, off_bit,
+                                                             (uint32_t)yout * a.mpitch, 0);
+                }
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// K2: exact predicate on candidates
+// ================================================================================================
+
+// Exact integer window sums + the oracle predicate, standalone.cc:113-174 operation for operation.
+template <typename PixelT>
+__device__ bool exact_strong(const ThresholdArgs& a, const uint8_t* img, int x, int y) {
+    const int W = a.W, H = a.H;
+    const uint8_t* mrow = a.maskbits + (uint64_t)y * a.mpitch;
+    if (!((mrow[x >> 3] >> (x & 7)) & 1)) return false;  // mask[k], :165
+    const PixelT pc = *reinterpret_cast<const PixelT*>(img + (uint64_t)y * a.pitch + (uint64_t)x * sizeof(PixelT));
+
+    const int xs = max(x - 3, 0), xe = min(x + 3, W - 1);  // window clipped to the image, :126-130
+    const int ys = max(y - 3, 0), ye = min(y + 3, H - 1);
+    uint32_t m = 0;
+    unsigned long long sx = 0, sy = 0;
+    // 8 pixels starting at an even column cover the (<= 7 wide) window row
+    const int bx = min(xs & ~1, a.pitch_px - 8);
+    const uint32_t rm = ((1u << (xe - bx + 1)) - 1u) & ~((1u << (xs - bx)) - 1u);
+    for (int yy = ys; yy <= ye; ++yy) {
+        const uint8_t* mp = a.maskbits + (uint64_t)yy * a.mpitch + (bx >> 3);
+        uint32_t mb = mp[0];
+        if (bx & 7) mb |= (uint32_t)mp[1] << 8;
+        mb = (mb >> (bx & 7)) & rm;
+        const uint8_t* rp = img + (uint64_t)yy * a.pitch + (uint64_t)bx * sizeof(PixelT);
+        uint32_t p[8];
+        if constexpr (sizeof(PixelT) == 2) {
+            const uint4 r = *reinterpret_cast<const uint4*>(rp);  // 4-byte aligned
+            p[0] = r.x & 0xFFFFu; p[1] = r.x >> 16; p[2] = r.y & 0xFFFFu; p[3] = r.y >> 16;
+            p[4] = r.z & 0xFFFFu; p[5] = r.z >> 16; p[6] = r.w & 0xFFFFu; p[7] = r.w >> 16;
+        } else {
+            const uint4 r0 = *reinterpret_cast<const uint4*>(rp);
+            const uint4 r1 = *reinterpret_cast<const uint4*>(rp + 16);
+            p[0] = r0.x; p[1] = r0.y; p[2] = r0.z; p[3] = r0.w;
+            p[4] = r1.x; p[5] = r1.y; p[6] = r1.z; p[7] = r1.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            // mm = mask && src < 2^24, standalone.cc:78,90
+            const bool inc = ((mb >> q) & 1u) && (sizeof(PixelT) == 2 || p[q] < (1u << 24));
+            if (inc) {
+                m += 1;
+                sx += p[q];
+                sy += (unsigned long long)p[q] * p[q];
+            }
+        }
+    }
+
+    // :165  mask[k] && m >= min_count && x >= 0 && src[k] > threshold
+    const double src = (double)pc;
+    if (!((int)m >= a.min_count && src > a.threshold)) return false;
+    if (a.max_valid >= 0 && (long long)pc > a.max_valid) return false;  // GPU reference only, thresholding.cu:208-215
+    const double md = (double)m, xd = (double)sx, yd = (double)sy;
+    // :166-170, each operation rounded separately (contraction is off for this library)
+    const double t0 = md * yd;
+    const double t1 = xd * xd;
+    const double t2 = xd * (md - 1.0);
+    const double av = (t0 - t1) - t2;
+    const double bv = md * src - xd;
+    const double cv = (xd * a.nsig_b) * __builtin_sqrt(2.0 * (md - 1.0));
+    const double dv = a.nsig_s * __builtin_sqrt(xd * md);
+    return av > cv && bv > dv;
+}
+
+template <typename PixelT>
+__global__ __launch_bounds__(256) void k_exact(const ThresholdArgs a) {
+    __shared__ uint32_t s_words[kTileRows * 320];  // tile bit-plane words (pitch_px <= 10240)
+    __shared__ uint32_t s_list[kExactListCap];
+    __shared__ uint32_t s_cnt, s_chunk, s_strong;
+
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x, frame = blockIdx.y;
+    const int y0 = tile * kTileRows;
+    const int rows = min(kTileRows, a.H - y0);
+    const int dpr = a.mpitch >> 2;  // dwords per row
+    const int ndw = rows * dpr;
+    const uint8_t* img = (const uint8_t*)a.image + (uint64_t)frame * a.frame_stride;
+    uint32_t* gwords = reinterpret_cast<uint32_t*>(a.bits + (uint64_t)frame * a.plane_frame_stride
+                                                   + (uint64_t)y0 * a.mpitch);
+    uint8_t* sbytes = a.strong_bytes + (uint64_t)frame * a.bytes_frame_stride;
+
+    if (tid == 0) { s_cnt = 0; s_strong = 0; }
+    for (int g = tid; g < ndw; g += 256) s_words[g] = gwords[g];
+    __syncthreads();
+
+    auto flush = [&]() {
+        const uint32_t n = s_cnt;
+        for (uint32_t e = tid; e < n; e += 256) {
+            const uint32_t idx = s_list[e];
+            const uint32_t g = idx >> 5, bit = idx & 31u;
+            const int row = g / dpr;
+            const int x = (int)((g - row * dpr) * 32u + bit);
+            const int y = y0 + row;
+            if (exact_strong<PixelT>(a, img, x, y)) {
+                sbytes[(uint64_t)y * a.bpitch + x] = 1;
+            } else {
+                atomicAnd(&s_words[g], ~(1u << bit));
+            }
+        }
+    };
+
+    for (int pos = 0; pos < ndw; pos += 256) {
+        const int g = pos + tid;
+        const uint32_t w = g < ndw ? s_words[g] : 0u;
+        const uint32_t n = __popc(w);
+        if (tid == 0) s_chunk = 0;
+        __syncthreads();
+        if (n) atomicAdd(&s_chunk, n);
+        __syncthreads();
+        if (s_cnt + s_chunk > (uint32_t)kExactListCap) {  // block-uniform
+            flush();
+            __syncthreads();
+            if (tid == 0) s_cnt = 0;
+            __syncthreads();
+        }
+        if (n) {
+            uint32_t at = atomicAdd(&s_cnt, n);
+            uint32_t ww = w;
+            while (ww) {
+                const uint32_t bit = __ffs(ww) - 1;
+                ww &= ww - 1;
+                s_list[at++] = ((uint32_t)g << 5) | bit;
+            }
+        }
+        __syncthreads();
+    }
+    flush();
+    __syncthreads();
+
+    uint32_t cnt = 0;
+    for (int g = tid; g < ndw; g += 256) {
+        const uint32_t w = s_words[g];
+        gwords[g] = w;
+        cnt += __popc(w);
+    }
+    if (cnt) atomicAdd(&s_strong, cnt);
+    __syncthreads();
+    if (tid == 0) a.tile_counts[(uint64_t)frame * a.n_tiles + tile] = s_strong;
+}
+
+template __global__ void k_exact<uint16_t>(const ThresholdArgs);
+template __global__ void k_exact<uint32_t>(const ThresholdArgs);
+
+}  // namespace ffsamd

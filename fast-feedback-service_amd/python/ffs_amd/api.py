@@ -1,0 +1,355 @@
+"""ctypes binding of include/ffs_hip.h (one class per opaque handle)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def lib_path() -> str:
+    return os.path.join(_PKG, "libffs_hip.so")
+
+
+class FfsError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libffs_hip error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    """ffs_params (include/ffs_hip.h)."""
+    _fields_ = [("min_count", C.c_int32), ("nsig_b", C.c_double), ("nsig_s", C.c_double),
+                ("threshold", C.c_double), ("max_valid", C.c_int64),
+                ("min_spot_size", C.c_uint32), ("min_spot_size_3d", C.c_uint32),
+                ("max_peak_centroid_separation", C.c_float),
+                ("want_reflections", C.c_int32), ("want_strong_list", C.c_int32),
+                ("want_strong_mask", C.c_int32)]
+
+
+class _Box(C.Structure):
+    _fields_ = [("l", C.c_uint32), ("t", C.c_uint32), ("r", C.c_uint32), ("b", C.c_uint32),
+                ("num_pixels", C.c_int32)]
+
+
+class _Refl(C.Structure):
+    _fields_ = [("x_min", C.c_uint32), ("x_max", C.c_uint32), ("y_min", C.c_uint32), ("y_max", C.c_uint32),
+                ("z_min", C.c_int32), ("z_max", C.c_int32), ("num_pixels", C.c_int32),
+                ("com_x", C.c_float), ("com_y", C.c_float), ("com_z", C.c_float),
+                ("peak_x", C.c_uint32), ("peak_y", C.c_uint32), ("peak_z", C.c_int32),
+                ("peak_intensity", C.c_uint32), ("peak_centroid_distance", C.c_float),
+                ("flags", C.c_uint32), ("sum_intensity", C.c_uint64)]
+
+
+class _FrameResult(C.Structure):
+    _fields_ = [("frame_id", C.c_int64), ("num_strong_pixels", C.c_uint32),
+                ("num_strong_pixels_filtered", C.c_uint32), ("n_components", C.c_uint32),
+                ("n_boxes", C.c_uint32), ("boxes", C.POINTER(_Box)),
+                ("n_reflections", C.c_uint32), ("reflections", C.POINTER(_Refl)),
+                ("n_filtered_size", C.c_uint32), ("n_filtered_sep", C.c_uint32),
+                ("strong_k", C.POINTER(C.c_uint32)), ("strong_intensity", C.POINTER(C.c_uint32)),
+                ("strong_mask", C.POINTER(C.c_uint8))]
+
+
+BOX_DT = np.dtype([("l", "<u4"), ("t", "<u4"), ("r", "<u4"), ("b", "<u4"), ("num_pixels", "<i4")])
+REFL_DT = np.dtype([("x_min", "<u4"), ("x_max", "<u4"), ("y_min", "<u4"), ("y_max", "<u4"),
+                    ("z_min", "<i4"), ("z_max", "<i4"), ("num_pixels", "<i4"),
+                    ("com_x", "<f4"), ("com_y", "<f4"), ("com_z", "<f4"),
+                    ("peak_x", "<u4"), ("peak_y", "<u4"), ("peak_z", "<i4"),
+                    ("peak_intensity", "<u4"), ("peak_centroid_distance", "<f4"),
+                    ("flags", "<u4"), ("sum_intensity", "<u8")])
+assert REFL_DT.itemsize == C.sizeof(_Refl) and BOX_DT.itemsize == C.sizeof(_Box)
+
+# every symbol include/ffs_hip.h declares (tests check the library exports them all)
+EXPORTS = [
+    "ffs_default_params", "ffs_device_count", "ffs_device_name", "ffs_device_total_mem",
+    "ffs_ctx_create", "ffs_ctx_destroy", "ffs_last_error", "ffs_ctx_set_mask",
+    "ffs_ctx_apply_resolution_mask", "ffs_ctx_get_mask", "ffs_ctx_set_params",
+    "ffs_stream_create", "ffs_stream_destroy", "ffs_stream_host_buffer", "ffs_submit",
+    "ffs_submit_device", "ffs_ctx_device_layout", "ffs_wait", "ffs_stream_timings",
+    "ffs_bench_threshold", "ffs_stream_debug_planes", "ffs_stack3d_create",
+    "ffs_stack3d_destroy", "ffs_stack3d_add_batch", "ffs_stack3d_add_slice", "ffs_stack3d_finish",
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen libffs_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise RuntimeError(f"{p} is missing: run `make hip` or __graft_entry__.build(). "
+                               "There is no CPU fallback for the product path.")
+        L = C.CDLL(p)
+        L.ffs_last_error.restype = C.c_char_p
+        L.ffs_last_error.argtypes = [C.c_void_p]
+        L.ffs_ctx_create.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32,
+                                     C.POINTER(C.c_void_p)]
+        L.ffs_ctx_destroy.argtypes = [C.c_void_p]
+        L.ffs_ctx_set_mask.argtypes = [C.c_void_p, C.c_void_p]
+        L.ffs_ctx_get_mask.argtypes = [C.c_void_p, C.c_void_p]
+        L.ffs_ctx_set_params.argtypes = [C.c_void_p, C.POINTER(Params)]
+        L.ffs_ctx_apply_resolution_mask.argtypes = [C.c_void_p] + [C.c_float] * 8
+        L.ffs_ctx_device_layout.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.ffs_stream_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.ffs_stream_destroy.argtypes = [C.c_void_p]
+        L.ffs_stream_host_buffer.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.ffs_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64]
+        L.ffs_submit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_int64]
+        L.ffs_wait.argtypes = [C.c_void_p, C.POINTER(C.POINTER(_FrameResult)), C.POINTER(C.c_uint32)]
+        L.ffs_stream_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.ffs_bench_threshold.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32,
+                                          C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.ffs_stream_debug_planes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                              C.POINTER(C.c_size_t)]
+        L.ffs_device_name.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+        L.ffs_device_total_mem.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
+        L.ffs_stack3d_create.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+        L.ffs_stack3d_destroy.argtypes = [C.c_void_p]
+        L.ffs_stack3d_add_batch.argtypes = [C.c_void_p, C.c_void_p]
+        L.ffs_stack3d_add_slice.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.ffs_stack3d_finish.argtypes = [C.c_void_p, C.POINTER(C.POINTER(_Refl)), C.POINTER(C.c_uint32),
+                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        _lib = L
+    return _lib
+
+
+def device_count() -> int:
+    return load_library().ffs_device_count()
+
+
+def device_name(device: int = 0) -> str:
+    buf = C.create_string_buffer(256)
+    rc = load_library().ffs_device_name(device, buf, 256)
+    if rc != 0:
+        raise FfsError(rc, "no such device")
+    return buf.value.decode()
+
+
+def default_params() -> Params:
+    p = Params()
+    load_library().ffs_default_params(C.byref(p))
+    return p
+
+
+@dataclass
+class FrameResult:
+    frame_id: int
+    num_strong_pixels: int
+    num_strong_pixels_filtered: int
+    n_components: int
+    boxes: np.ndarray                      # BOX_DT, label order
+    reflections: np.ndarray | None         # REFL_DT, after both filters
+    n_filtered_size: int
+    n_filtered_sep: int
+    strong_k: np.ndarray | None = None
+    strong_intensity: np.ndarray | None = None
+    strong_mask: np.ndarray | None = None
+    extra: dict = field(default_factory=dict)
+
+    @property
+    def n_spots_total(self) -> int:        # JSON key, spotfinder.cc:1002
+        return len(self.boxes)
+
+
+def _copy_array(ptr, n, ctype_struct, dt):
+    if n == 0 or not ptr:
+        return np.zeros(0, dt)
+    raw = C.string_at(C.cast(ptr, C.c_void_p), n * C.sizeof(ctype_struct))
+    return np.frombuffer(raw, dtype=dt).copy()
+
+
+class Context:
+    def __init__(self, width: int, height: int, dtype=np.uint16, max_batch: int = 1,
+                 device: int = 0, max_strong_per_frame: int = 0):
+        self._lib = load_library()
+        self.W, self.H = int(width), int(height)
+        self.dtype = np.dtype(dtype)
+        assert self.dtype in (np.dtype(np.uint16), np.dtype(np.uint32))
+        self.max_batch = int(max_batch)
+        self.device = device
+        h = C.c_void_p()
+        rc = self._lib.ffs_ctx_create(device, self.W, self.H, self.dtype.itemsize, self.max_batch,
+                                      max_strong_per_frame, C.byref(h))
+        if rc != 0:
+            raise FfsError(rc, self._lib.ffs_last_error(None).decode())
+        self._h = h
+        self.params = default_params()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise FfsError(rc, self._lib.ffs_last_error(self._h).decode())
+
+    def set_mask(self, mask: np.ndarray | None):
+        if mask is None:
+            self._check(self._lib.ffs_ctx_set_mask(self._h, None))
+            return
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert m.shape == (self.H, self.W)
+        self._check(self._lib.ffs_ctx_set_mask(self._h, m.ctypes.data_as(C.c_void_p)))
+
+    def get_mask(self) -> np.ndarray:
+        m = np.empty((self.H, self.W), np.uint8)
+        self._check(self._lib.ffs_ctx_get_mask(self._h, m.ctypes.data_as(C.c_void_p)))
+        return m
+
+    def apply_resolution_mask(self, wavelength, distance_m, beam_center_x_px, beam_center_y_px,
+                              pixel_size_x_m, pixel_size_y_m, dmin=-1.0, dmax=-1.0):
+        self._check(self._lib.ffs_ctx_apply_resolution_mask(
+            self._h, wavelength, distance_m, beam_center_x_px, beam_center_y_px,
+            pixel_size_x_m, pixel_size_y_m, dmin, dmax))
+
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self.params, k):
+                raise AttributeError(k)
+            setattr(self.params, k, v)
+        self._check(self._lib.ffs_ctx_set_params(self._h, C.byref(self.params)))
+
+    def device_layout(self):
+        pitch, stride = C.c_size_t(), C.c_size_t()
+        self._check(self._lib.ffs_ctx_device_layout(self._h, C.byref(pitch), C.byref(stride)))
+        return pitch.value, stride.value
+
+    def stream(self) -> "Stream":
+        return Stream(self)
+
+    def close(self):
+        if self._h:
+            self._lib.ffs_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Stream:
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        h = C.c_void_p()
+        ctx._check(self._lib.ffs_stream_create(ctx._h, C.byref(h)))
+        self._h = h
+
+    def host_buffer(self) -> np.ndarray:
+        """The stream's pinned staging area as a (max_batch, H, W) array."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self.ctx._check(self._lib.ffs_stream_host_buffer(self._h, C.byref(p), C.byref(n)))
+        buf = (C.c_uint8 * n.value).from_address(p.value)
+        return np.frombuffer(buf, dtype=self.ctx.dtype).reshape(self.ctx.max_batch, self.ctx.H, self.ctx.W)
+
+    def submit(self, frames: np.ndarray, first_frame_id: int = 0):
+        f = np.ascontiguousarray(frames, dtype=self.ctx.dtype)
+        if f.ndim == 2:
+            f = f[None]
+        assert f.shape[1:] == (self.ctx.H, self.ctx.W), f.shape
+        self._keep = f
+        self.ctx._check(self._lib.ffs_submit(self._h, f.ctypes.data_as(C.c_void_p), f.shape[0], first_frame_id))
+
+    def submit_device(self, dev_ptr: int, pitch_bytes: int, frame_stride_bytes: int, n_frames: int,
+                      first_frame_id: int = 0):
+        self.ctx._check(self._lib.ffs_submit_device(self._h, C.c_void_p(dev_ptr), pitch_bytes,
+                                                    frame_stride_bytes, n_frames, first_frame_id))
+
+    def wait(self) -> list[FrameResult]:
+        res = C.POINTER(_FrameResult)()
+        n = C.c_uint32()
+        self.ctx._check(self._lib.ffs_wait(self._h, C.byref(res), C.byref(n)))
+        out = []
+        W, H = self.ctx.W, self.ctx.H
+        for i in range(n.value):
+            r = res[i]
+            ns = r.num_strong_pixels
+            fr = FrameResult(
+                frame_id=r.frame_id, num_strong_pixels=ns,
+                num_strong_pixels_filtered=r.num_strong_pixels_filtered,
+                n_components=r.n_components,
+                boxes=_copy_array(r.boxes, r.n_boxes, _Box, BOX_DT),
+                reflections=_copy_array(r.reflections, r.n_reflections, _Refl, REFL_DT) if r.reflections or self.ctx.params.want_reflections else None,
+                n_filtered_size=r.n_filtered_size, n_filtered_sep=r.n_filtered_sep)
+            if r.strong_k:
+                fr.strong_k = np.ctypeslib.as_array(r.strong_k, (max(ns, 1),))[:ns].copy()
+                fr.strong_intensity = np.ctypeslib.as_array(r.strong_intensity, (max(ns, 1),))[:ns].copy()
+            elif self.ctx.params.want_strong_list:
+                fr.strong_k = np.zeros(0, np.uint32)
+                fr.strong_intensity = np.zeros(0, np.uint32)
+            if r.strong_mask:
+                fr.strong_mask = np.ctypeslib.as_array(r.strong_mask, (H, W)).copy()
+            out.append(fr)
+        return out
+
+    def process(self, frames: np.ndarray, first_frame_id: int = 0) -> list[FrameResult]:
+        self.submit(frames, first_frame_id)
+        return self.wait()
+
+    def timings(self):
+        t = (C.c_float * 5)()
+        self.ctx._check(self._lib.ffs_stream_timings(self._h, t))
+        return dict(zip(("h2d", "threshold", "ccl", "d2h", "total"), list(t)))
+
+    def bench_threshold(self, dev_ptr: int, pitch_bytes: int, frame_stride_bytes: int, n_frames: int,
+                        iters: int):
+        a, b = C.c_float(), C.c_float()
+        self.ctx._check(self._lib.ffs_bench_threshold(self._h, C.c_void_p(dev_ptr), pitch_bytes,
+                                                      frame_stride_bytes, n_frames, iters,
+                                                      C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if self._h:
+            self._lib.ffs_stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Stack3D:
+    """Rotation-sweep accumulator -> 3D connected components (ffs_stack3d_*)."""
+
+    def __init__(self, ctx: Context, max_total_strong: int = 0):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        h = C.c_void_p()
+        ctx._check(self._lib.ffs_stack3d_create(ctx._h, max_total_strong, C.byref(h)))
+        self._h = h
+
+    def add_batch(self, stream: Stream):
+        self.ctx._check(self._lib.ffs_stack3d_add_batch(self._h, stream._h))
+
+    def add_slice(self, frame_id: int, k: np.ndarray, intensity: np.ndarray):
+        k = np.ascontiguousarray(k, dtype=np.uint32)
+        it = np.ascontiguousarray(intensity, dtype=np.uint32)
+        assert k.shape == it.shape
+        self.ctx._check(self._lib.ffs_stack3d_add_slice(self._h, frame_id, k.ctypes.data_as(C.c_void_p),
+                                                        it.ctypes.data_as(C.c_void_p), len(k)))
+
+    def finish(self):
+        """-> (reflections REFL_DT, n_calculated, n_filtered_size, n_filtered_sep)"""
+        r = C.POINTER(_Refl)()
+        n, nc, fs, fp = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self.ctx._check(self._lib.ffs_stack3d_finish(self._h, C.byref(r), C.byref(n), C.byref(nc),
+                                                     C.byref(fs), C.byref(fp)))
+        return _copy_array(r, n.value, _Refl, REFL_DT), nc.value, fs.value, fp.value
+
+    def close(self):
+        if self._h:
+            self._lib.ffs_stack3d_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,195 @@
+/*
+ * ffs_hip.h -- C ABI of libffs_hip.so: the MI355X (gfx950) spot-finder hot path.
+ *
+ * This is the drop-in boundary for the reference's per-frame device work and the
+ * host connected-components stage that follows it.  Each entry point names the
+ * reference interface it replaces (paths relative to the reference checkout).
+ * Plain C: opaque handles, plain pointers and sizes, int status returns
+ * (0 = FFS_OK, negative = error; ffs_last_error() gives the text).  No
+ * exceptions cross this boundary and no torch / HIP types appear in it.
+ *
+ * Data flow of one batch:
+ *   frames (u16/u32, dense host rows or pitched device rows)
+ *     -> dispersion candidate kernel      (replaces kernels/thresholding.cu:145-234)
+ *     -> exact fp64 predicate kernel      (semantics of baseline/spotfinder/standalone.cc:113-174)
+ *     -> strong-pixel compaction
+ *     -> union-find connected components  (replaces connected_components.cc:17-139, 238-266)
+ *     -> per-frame result records (D2H)
+ */
+#ifndef FFS_HIP_H
+#define FFS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFS_OK 0
+#define FFS_ERR_INVALID (-1)   /* bad argument / state */
+#define FFS_ERR_DEVICE (-2)    /* HIP runtime error */
+#define FFS_ERR_NOMEM (-3)     /* host or device allocation failed */
+#define FFS_ERR_OVERFLOW (-4)  /* a frame produced more strong pixels / spots than the context was sized for */
+#define FFS_ERR_NODEVICE (-5)  /* no usable GPU */
+
+typedef struct ffs_ctx ffs_ctx;
+typedef struct ffs_stream ffs_stream;
+typedef struct ffs_stack3d ffs_stack3d;
+
+/* Algorithm parameters.  Defaults (ffs_default_params) are the oracle's,
+ * baseline/spotfinder/standalone.cc:16-20: 7x7 window, min_count 2, nsig_b 6,
+ * nsig_s 3, threshold 0; the GPU reference's launch wrapper defaults
+ * (spotfinder/spotfinder.cuh:18-20) differ only in min_count = 3. */
+typedef struct {
+    int32_t min_count;        /* window needs >= this many valid pixels */
+    double nsig_b;            /* background (dispersion) significance */
+    double nsig_s;            /* signal significance */
+    double threshold;         /* centre pixel must be > threshold */
+    int64_t max_valid;        /* centre pixel must be <= max_valid (thresholding.cu:208-215);
+                                 < 0 = no test (oracle behaviour) */
+    uint32_t min_spot_size;   /* --min-spot-size, spotfinder.cc:318-322 (default 3) */
+    uint32_t min_spot_size_3d;/* --min-spot-size-3d, :324-328 (default 3) */
+    float max_peak_centroid_separation; /* :330-336 (default 2.0) */
+    int32_t want_reflections; /* compute find_2d_components output per frame (spotfinder.cc:919-933) */
+    int32_t want_strong_list; /* return the sparse strong-pixel list (k, intensity) per frame */
+    int32_t want_strong_mask; /* return the dense W*H byte mask per frame (reference D2H, :887-897) */
+} ffs_params;
+
+void ffs_default_params(ffs_params *p);
+
+/* struct Reflection, spotfinder/connected_components/connected_components.hpp:27-30 */
+typedef struct {
+    uint32_t l, t, r, b;
+    int32_t num_pixels;
+} ffs_box;
+
+#define FFS_REFL_FILTERED_SIZE 1u /* removed by min_spot_size (connected_components.cc:213-222) */
+#define FFS_REFL_FILTERED_SEP 2u  /* removed by peak-centroid distance (:224-233) */
+
+/* class Reflection3D, connected_components.hpp:32-260 (what its getters and
+ * center_of_mass() / peak_centroid_distance() return). */
+typedef struct {
+    uint32_t x_min, x_max, y_min, y_max;
+    int32_t z_min, z_max;
+    int32_t num_pixels;
+    float com_x, com_y, com_z;
+    uint32_t peak_x, peak_y;
+    int32_t peak_z;
+    uint32_t peak_intensity;
+    float peak_centroid_distance;
+    uint32_t flags;
+    uint64_t sum_intensity;
+} ffs_reflection;
+
+/* What the reference's worker has in hand after ConnectedComponents(...)
+ * (spotfinder.cc:901-933) for one frame.  Pointers stay valid until the next
+ * ffs_wait() on the same stream. */
+typedef struct {
+    int64_t frame_id;
+    uint32_t num_strong_pixels;          /* get_num_strong_pixels() */
+    uint32_t num_strong_pixels_filtered; /* get_num_strong_pixels_filtered() */
+    uint32_t n_components;               /* "Extracted {} spots", connected_components.cc:119 */
+    uint32_t n_boxes;                    /* boxes.size() after the min-size filter = JSON n_spots_total */
+    const ffs_box *boxes;                /* label order */
+    uint32_t n_reflections;              /* find_2d_components(): after both filters, label order */
+    const ffs_reflection *reflections;   /* NULL unless want_reflections */
+    uint32_t n_filtered_size, n_filtered_sep;
+    const uint32_t *strong_k;            /* ascending linear index y*W+x; NULL unless want_strong_list */
+    const uint32_t *strong_intensity;
+    const uint8_t *strong_mask;          /* dense W*H, NULL unless want_strong_mask */
+} ffs_frame_result;
+
+/* ---- devices (replaces CUDAArgumentParser --list-devices / -d, src/ffs/cuda_arg_parser.cc:30-61) */
+int ffs_device_count(void);
+int ffs_device_name(int device, char *buf, size_t buflen);
+int ffs_device_total_mem(int device, uint64_t *bytes);
+
+/* ---- context: one per (GPU, detector geometry) --------------------------------------------- */
+/* pixel_bytes: 2 (uint16) or 4 (uint32) -- replaces the compile-time pixel_t switch
+ * (h5read/include/h5read.h:16-20, spotfinder/CMakeLists.txt:45-73).
+ * max_batch: frames per submit.  max_strong_per_frame: 0 = default (min(W*H, 1<<20)). */
+int ffs_ctx_create(int device, uint32_t width, uint32_t height, int pixel_bytes,
+                   uint32_t max_batch, uint32_t max_strong_per_frame, ffs_ctx **out);
+void ffs_ctx_destroy(ffs_ctx *ctx);
+const char *ffs_last_error(const ffs_ctx *ctx); /* ctx may be NULL: last error of ffs_ctx_create */
+
+/* upload_mask(), spotfinder/spotfinder.cc:61-108: host_mask = W*H bytes, nonzero = valid,
+ * or NULL for "all valid" (the reference's cudaMemset(1) branch). */
+int ffs_ctx_set_mask(ffs_ctx *ctx, const uint8_t *host_mask);
+
+/* call_apply_resolution_mask(), spotfinder/kernels/masking.cuh:82-97 + masking.cu:37-147:
+ * clears mask bits whose d-spacing is outside [dmin, dmax] (<= 0 = unbounded). */
+int ffs_ctx_apply_resolution_mask(ffs_ctx *ctx, float wavelength, float distance_m,
+                                  float beam_center_x_px, float beam_center_y_px,
+                                  float pixel_size_x_m, float pixel_size_y_m, float dmin,
+                                  float dmax);
+/* Read the current mask back (W*H bytes, 0/1) -- what --writeout copies for mask_calculated.png */
+int ffs_ctx_get_mask(ffs_ctx *ctx, uint8_t *host_mask);
+
+int ffs_ctx_set_params(ffs_ctx *ctx, const ffs_params *p);
+
+/* ---- streams: one in-flight batch each (replaces one worker thread's CudaStream +
+ *      pinned/device buffers, spotfinder.cc:729-742) -------------------------------------------- */
+int ffs_stream_create(ffs_ctx *ctx, ffs_stream **out);
+void ffs_stream_destroy(ffs_stream *s);
+
+/* The stream's pinned staging area (max_batch dense frames): decode straight into it, as the
+ * reference's workers decompress into their pinned host_image (spotfinder.cc:731, :828-842),
+ * then pass the same pointer to ffs_submit(). */
+int ffs_stream_host_buffer(ffs_stream *s, void **ptr, size_t *bytes);
+
+/* cudaMemcpy2DAsync H2D + call_do_spotfinding_dispersion + D2H + ConnectedComponents
+ * (spotfinder.cc:846-905), for n_frames dense host frames (each W*H pixels, consecutive).
+ * Asynchronous; results are collected with ffs_wait(). */
+int ffs_submit(ffs_stream *s, const void *host_pixels, uint32_t n_frames,
+               int64_t first_frame_id);
+/* Same, frames already in device memory (rows pitch_bytes apart, frames frame_stride_bytes
+ * apart; pitch_bytes a multiple of 16).  For producers that decode on the GPU, and for bench.py's
+ * resident-in-HBM measurement. */
+int ffs_submit_device(ffs_stream *s, const void *device_pixels, size_t pitch_bytes,
+                      size_t frame_stride_bytes, uint32_t n_frames, int64_t first_frame_id);
+/* Device layout this context prefers for ffs_submit_device (and uses internally). */
+int ffs_ctx_device_layout(const ffs_ctx *ctx, size_t *pitch_bytes, size_t *frame_stride_bytes);
+
+/* Blocks until the stream's batch is done; results[i] describes frame i of the batch. */
+int ffs_wait(ffs_stream *s, const ffs_frame_result **results, uint32_t *n_results);
+
+/* Timings of the last completed batch on this stream, milliseconds (HIP events on the
+ * stream): [0] H2D, [1] threshold kernels, [2] compaction + connected components,
+ * [3] D2H, [4] total.  (The reference prints Copy/Kernel/Post Copy/Post, spotfinder.cc:1056-1076.) */
+int ffs_stream_timings(ffs_stream *s, float ms[5]);
+
+/* ---- kernel-only entry points (bench.py roofline leg, kernel parity tests) ------------------ */
+/* Runs only the two threshold kernels on device-resident frames, `iters` times back to back
+ * on the stream, and returns the average duration of ONE launch of the dominant
+ * (candidate) kernel and of the exact kernel, from HIP events on that stream. */
+int ffs_bench_threshold(ffs_stream *s, const void *device_pixels, size_t pitch_bytes,
+                        size_t frame_stride_bytes, uint32_t n_frames, uint32_t iters,
+                        float *ms_candidate, float *ms_exact);
+/* Device pointers of the last batch's dense planes (strong byte mask rows are
+ * mask_pitch apart) -- for parity tests that want the raw kernel output. */
+int ffs_stream_debug_planes(ffs_stream *s, const uint8_t **device_strong_bytes,
+                            size_t *mask_pitch, size_t *mask_frame_stride);
+
+/* ---- rotation sweeps: 3D connected components (replaces
+ *      ConnectedComponents::find_3d_components, connected_components.cc:270-470) -------------- */
+int ffs_stack3d_create(ffs_ctx *ctx, uint64_t max_total_strong, ffs_stack3d **out);
+void ffs_stack3d_destroy(ffs_stack3d *st);
+/* Adds the strong pixels of every frame of the stream's last completed batch, keyed by frame_id
+ * (the reference keys its rotation_slices map by image number, spotfinder.cc:913-918). */
+int ffs_stack3d_add_batch(ffs_stack3d *st, ffs_stream *s);
+/* Adds one slice from host memory (k ascending) -- what a gather from other GPUs delivers. */
+int ffs_stack3d_add_slice(ffs_stack3d *st, int64_t frame_id, const uint32_t *k,
+                          const uint32_t *intensity, uint32_t n);
+/* Orders slices by frame_id (std::map order, spotfinder.cc:1105-1108), z = rank, runs the 3D
+ * union-find on the device, filters with min_spot_size_3d / max_peak_centroid_separation.
+ * reflections are in label order; n_calculated = "Calculated {} spots". */
+int ffs_stack3d_finish(ffs_stack3d *st, const ffs_reflection **reflections,
+                       uint32_t *n_reflections, uint32_t *n_calculated,
+                       uint32_t *n_filtered_size, uint32_t *n_filtered_sep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

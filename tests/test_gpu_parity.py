@@ -1,0 +1,180 @@
+"""GPU parity: libffs_hip.so (through its C ABI) against the oracle on the same inputs.
+Integer results (masks, lists, boxes, counts) bit-exact; float32 centroids bit-exact
+(BASELINE.json asks for 1e-6)."""
+import numpy as np
+import pytest
+
+from util import assert_frame_matches_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _spotty(rng, H, W, lam, nspots, dtype=np.uint16, peak=400):
+    img = rng.poisson(lam, (H, W)).astype(np.int64)
+    for _ in range(nspots):
+        cy, cx = rng.integers(0, H), rng.integers(0, W)
+        s = rng.uniform(0.7, 1.8)
+        pk = rng.uniform(10, peak)
+        y0, y1 = max(cy - 6, 0), min(cy + 7, H)
+        x0, x1 = max(cx - 6, 0), min(cx + 7, W)
+        yy, xx = np.mgrid[y0:y1, x0:x1]
+        img[y0:y1, x0:x1] += rng.poisson(pk * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s)))
+    return np.minimum(img, np.iinfo(dtype).max).astype(dtype)
+
+
+def _mask(rng, H, W, dead=40):
+    m = np.ones((H, W), np.uint8)
+    if W > 40:
+        m[:, W // 2 - 3:W // 2 + 2] = 0
+    if H > 40:
+        m[H // 3:H // 3 + 5, :] = 0
+    ys, xs = rng.integers(0, H, dead), rng.integers(0, W, dead)
+    m[ys, xs] = 0
+    return m
+
+
+@pytest.mark.parametrize("H,W", [(13, 20), (48, 64), (100, 497), (389, 517), (200, 1000), (64, 2100)])
+def test_small_frames_match_oracle(ffs, H, W):
+    rng = np.random.default_rng(H * 10007 + W)
+    ctx = ffs.Context(W, H, np.uint16, max_batch=3)
+    mask = _mask(rng, H, W)
+    ctx.set_mask(mask)
+    ctx.set_params(want_strong_mask=1, want_strong_list=1, want_reflections=1)
+    st = ctx.stream()
+    frames = np.stack([_spotty(rng, H, W, lam, max(3, H * W // 3000)) for lam in (0.3, 2.0, 30.0)])
+    res = st.process(frames, first_frame_id=7)
+    assert [r.frame_id for r in res] == [7, 8, 9]
+    total = 0
+    for fr, img in zip(res, frames):
+        _, cc, _ = assert_frame_matches_oracle(fr, img, mask)
+        total += cc.num_strong_pixels
+    assert total > 0
+
+
+def test_no_mask_and_all_masked(ffs):
+    rng = np.random.default_rng(5)
+    H, W = 70, 130
+    ctx = ffs.Context(W, H, np.uint16, max_batch=1)
+    ctx.set_params(want_strong_mask=1, want_strong_list=1)
+    st = ctx.stream()
+    img = _spotty(rng, H, W, 1.0, 20)
+    ones = np.ones((H, W), np.uint8)
+    assert_frame_matches_oracle(st.process(img)[0], img, ones)      # NULL mask = all valid
+    ctx.set_mask(np.zeros((H, W), np.uint8))
+    fr = st.process(img)[0]
+    assert fr.num_strong_pixels == 0 and len(fr.boxes) == 0 and fr.strong_mask.sum() == 0
+    ctx.set_mask(ones)
+    zero = np.zeros((H, W), np.uint16)
+    fr = st.process(zero)[0]                                            # empty frame
+    assert fr.num_strong_pixels == 0 and fr.n_components == 0
+
+
+def test_saturated_and_edge_pixels(ffs):
+    """Bright pixels at the corners/edges (clipped windows) and 65535 values."""
+    H, W = 40, 72
+    rng = np.random.default_rng(11)
+    img = rng.poisson(1.0, (H, W)).astype(np.uint16)
+    for (y, x) in [(0, 0), (0, W - 1), (H - 1, 0), (H - 1, W - 1), (0, 30), (H - 1, 31), (17, 0), (18, W - 1)]:
+        img[y, x] = 65535
+    img[20:23, 40:43] = 60000
+    mask = np.ones((H, W), np.uint8)
+    mask[10, 10] = 0
+    ctx = ffs.Context(W, H, np.uint16)
+    ctx.set_mask(mask)
+    ctx.set_params(want_strong_mask=1, want_strong_list=1)
+    fr = ctx.stream().process(img)[0]
+    assert_frame_matches_oracle(fr, img, mask)
+    assert fr.num_strong_pixels >= 8
+
+
+def test_row_wrap_quirk(ffs):
+    """(W-1, y) and (0, y+1) are joined because the reference links k to k+1 with no row-end
+    check (connected_components.cc:62-70)."""
+    H, W = 32, 64
+    img = np.ones((H, W), np.uint16)
+    img[10, W - 1] = 500
+    img[10, W - 2] = 500
+    img[11, 0] = 500
+    img[11, 1] = 500
+    ctx = ffs.Context(W, H, np.uint16)
+    ctx.set_params(want_strong_mask=1, want_strong_list=1, min_spot_size=1)
+    fr = ctx.stream().process(img)[0]
+    mask = np.ones((H, W), np.uint8)
+    assert_frame_matches_oracle(fr, img, mask, min_spot_size=1)
+    assert fr.num_strong_pixels == 4 and fr.n_components == 1
+    assert fr.boxes[0]["l"] == 0 and fr.boxes[0]["r"] == W - 1
+
+
+def test_config1_plumbing_frames(ffs):
+    """BASELINE.json configs[0]: 10 x 1024^2 u16 synthetic frames with Poisson spots."""
+    from ffs_amd import synth
+    p = synth.config1_params()
+    mask = synth.config1_mask()
+    frames = synth.frames(p, range(10))
+    ctx = ffs.Context(1024, 1024, np.uint16, max_batch=10)
+    ctx.set_mask(mask)
+    ctx.set_params(want_strong_mask=1, want_strong_list=1)
+    res = ctx.stream().process(frames)
+    for fr, img in zip(res, frames):
+        _, cc, _ = assert_frame_matches_oracle(fr, img, mask)
+        assert cc.num_strong_pixels > 500
+
+
+def test_params_min_count_and_max_valid(ffs):
+    """GPU-reference flavoured parameters: min_count 3 (spotfinder.cuh:18) and a trusted
+    maximum on the centre pixel (thresholding.cu:208-215)."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(21)
+    H, W = 60, 90
+    img = _spotty(rng, H, W, 0.5, 25, peak=3000)
+    mask = _mask(rng, H, W, dead=900)
+    ctx = ffs.Context(W, H, np.uint16)
+    ctx.set_mask(mask)
+    ctx.set_params(want_strong_mask=1, min_count=3, max_valid=1000)
+    fr = ctx.stream().process(img)[0]
+    p = O.DispParams(3, 3, 3, 0.0, 6.0, 3.0)
+    want = O.dispersion(img, mask, p)
+    want[img > 1000] = 0
+    np.testing.assert_array_equal(fr.strong_mask, want)
+    assert want.sum() > 0
+
+
+@pytest.mark.parametrize("H,W", [(50, 70), (301, 517)])
+def test_uint32_frames_match_oracle(ffs, H, W):
+    rng = np.random.default_rng(H + W)
+    ctx = ffs.Context(W, H, np.uint32, max_batch=2)
+    mask = _mask(rng, H, W)
+    ctx.set_mask(mask)
+    ctx.set_params(want_strong_mask=1, want_strong_list=1)
+    a = _spotty(rng, H, W, 5.0, 30, np.uint32, peak=200000)
+    b = _spotty(rng, H, W, 300.0, 30, np.uint32, peak=3000000)
+    b[5, 5] = (1 << 24) + 5          # >= 2^24: excluded from sums, still a legal centre
+    b[H - 2, W - 3] = 0xFFFFFFFF
+    frames = np.stack([a, b])
+    res = ctx.stream().process(frames)
+    for fr, img in zip(res, frames):
+        assert_frame_matches_oracle(fr, img, mask)
+
+
+def test_stack3d_matches_oracle(ffs):
+    from oracle import oracle as O
+    from ffs_amd import synth
+    W, H, NZ = 300, 200, 12
+    p = synth.sweep_params(seed=77, n_frames=NZ, n_spots=60, width=W, height=H)
+    frames = synth.frames(p, range(NZ))
+    mask = np.ones((H, W), np.uint8)
+    ctx = ffs.Context(W, H, np.uint16, max_batch=5)
+    ctx.set_params(want_strong_list=1, min_spot_size_3d=4)
+    st = ctx.stream()
+    stack = ffs.Stack3D(ctx)
+    slices = []
+    for z0 in range(0, NZ, 5):
+        res = st.process(frames[z0:z0 + 5], first_frame_id=100 + z0)
+        stack.add_batch(st)
+        slices += [(r.strong_k, r.strong_intensity) for r in res]
+    refl, n_calc, fs, fp = stack.finish()
+    want = O.cc3d(slices, W, H, 4, 2.0)
+    assert n_calc == want.n_calculated and fs == want.n_filtered_size and fp == want.n_filtered_sep
+    from util import assert_reflections_equal
+    assert_reflections_equal(refl, want.reflections)
+    assert len(refl) > 5 and (refl["z_max"] > refl["z_min"]).any()
