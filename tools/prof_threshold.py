@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Profiling harness: only the two threshold kernels on resident synthetic frames
+(ffs_bench_threshold), for `rocprofv3 --kernel-trace --stats` and `--pmc` passes.
+
+  rocprofv3 --kernel-trace --stats -d out -- python3 tools/prof_threshold.py --iters 20
+  rocprofv3 --pmc FETCH_SIZE -d out --output-format csv -- python3 tools/prof_threshold.py --iters 5
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fast-feedback-service_amd", "python"))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--unique", type=int, default=4, help="unique synthetic frames (cycled)")
+    ap.add_argument("--workload", default="eiger16m")
+    args = ap.parse_args()
+    import torch
+    import ffs_amd
+    from bench import WORKLOADS, make_inputs
+    W, H, dt, bpp = WORKLOADS[args.workload]
+    frames, mask = make_inputs(args.workload, args.unique, 0)
+    B = args.batch
+    ctx = ffs_amd.Context(W, H, dt, max_batch=B)
+    ctx.set_mask(mask)
+    pitch, fstride = ctx.device_layout()
+    host = np.zeros((B, H, pitch // np.dtype(dt).itemsize), dt)
+    for i in range(B):
+        host[i, :, :W] = frames[i % len(frames)]
+    d = torch.from_numpy(host.view(np.uint8).reshape(-1)).cuda()
+    st = ctx.stream()
+    a, b = st.bench_threshold(d.data_ptr(), pitch, fstride, B, args.iters)
+    alg = float(W) * H * bpp * B
+    print(f"k_candidates {a*1e3:.1f} us/launch ({alg/a/1e6:.0f} GB/s algorithmic), k_exact {b*1e3:.1f} us/launch, "
+          f"batch {B}")
+
+
+if __name__ == "__main__":
+    main()
