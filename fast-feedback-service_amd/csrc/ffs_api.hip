@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -51,7 +52,7 @@ struct ffs_stream {
     uint8_t* d_img = nullptr;
     uint8_t* d_bits = nullptr;
     uint8_t* d_sbytes = nullptr;
-    uint32_t *d_tile_counts = nullptr, *d_tile_offsets = nullptr, *d_num_strong = nullptr;
+    uint32_t *d_tile_counts = nullptr, *d_tile_offsets = nullptr, *d_num_strong = nullptr, *d_row_off = nullptr;
     uint32_t *d_list_k = nullptr, *d_list_i = nullptr, *d_parent = nullptr, *d_comp_id = nullptr;
     uint32_t *d_n_comp = nullptr, *d_overflow = nullptr, *d_summary = nullptr;
     CompAcc* d_acc = nullptr;
@@ -160,7 +161,7 @@ extern "C" int ffs_ctx_create(int device, uint32_t width, uint32_t height, int p
     Layout& L = c->L;
     L.W = (int)width;
     L.H = (int)height;
-    L.pitch_px = round_up((int)width, 64);
+    L.pitch_px = round_up((int)width, 128);  // byte-mask rows start on 128-byte lines
     L.pitch = (uint32_t)L.pitch_px * (uint32_t)pixel_bytes;
     L.mpitch = (uint32_t)L.pitch_px / 8;
     L.bpitch = (uint32_t)L.pitch_px;
@@ -305,7 +306,7 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     if (s->st) (void)hipStreamSynchronize(s->st);
-    void* dev[] = {s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_tile_offsets, s->d_num_strong,
+    void* dev[] = {s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_tile_offsets, s->d_num_strong,
                    s->d_list_k, s->d_list_i, s->d_parent, s->d_comp_id, s->d_n_comp, s->d_overflow,
                    s->d_summary, s->d_acc, s->d_recs};
     for (void* p : dev)
@@ -345,6 +346,7 @@ extern "C" int ffs_stream_create(ffs_ctx* c, ffs_stream** out) {
     STREAM_TRY(dmalloc(&s->d_tile_counts, B * c->n_tiles * 4));
     STREAM_TRY(dmalloc(&s->d_tile_offsets, B * c->n_tiles * 4));
     STREAM_TRY(dmalloc(&s->d_num_strong, B * 4));
+    STREAM_TRY(dmalloc(&s->d_row_off, B * (size_t)(L.H + 1) * 4));
     STREAM_TRY(dmalloc(&s->d_list_k, B * (size_t)c->cap * 4));
     STREAM_TRY(dmalloc(&s->d_list_i, B * (size_t)c->cap * 4));
     STREAM_TRY(dmalloc(&s->d_parent, B * (size_t)c->cap * 4));
@@ -407,13 +409,22 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
     a.nsig_s = p.nsig_s;
     a.threshold = p.threshold;
     a.max_valid = p.max_valid;
+    {   // FFS_K1_VARIANT=0 selects the unscreened candidate kernel (A/B testing)
+        const char* v = std::getenv("FFS_K1_VARIANT");
+        a.variant = v ? std::atoi(v) : 1;
+    }
     return a;
 }
 
 static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
-    dim3 grid((unsigned)(a.n_strips * a.n_bands), n_frames), block(64);
-    if (s->ctx->pixel_bytes == 2)
-        hipLaunchKernelGGL(k_candidates_u16, grid, block, 0, s->st, a);
+    const int bands8 = (a.n_bands + 7) / 8 * 8;  // XCD-aware mapping wants a multiple of 8 bands
+    dim3 grid((unsigned)(a.n_strips * bands8), n_frames), block(64);
+    if (s->ctx->pixel_bytes == 2) {
+        if (a.variant == 0)
+            hipLaunchKernelGGL(k_candidates_u16<false>, grid, block, 0, s->st, a);
+        else
+            hipLaunchKernelGGL(k_candidates_u16<true>, grid, block, 0, s->st, a);
+    }
     else
         hipLaunchKernelGGL(k_candidates_u32, grid, block, 0, s->st, a);
 }
@@ -434,7 +445,7 @@ static int check_layout(ffs_stream* s, size_t pitch, size_t fstride, uint32_t n_
     }
     if (pitch % 16 || pitch < (size_t)c->L.pitch_px * c->pixel_bytes || pitch >= (1ull << 32)
         || fstride < pitch * c->L.H || (pitch * c->L.H) >= (1ull << 32)) {
-        c->err = "device layout: pitch must be a multiple of 16 bytes and >= round_up(width,64)*pixel_bytes; "
+        c->err = "device layout: pitch must be a multiple of 16 bytes and >= round_up(width,128)*pixel_bytes; "
                  "frame_stride >= pitch*height";
         return FFS_ERR_INVALID;
     }
@@ -463,6 +474,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     ca.tile_counts = s->d_tile_counts;
     ca.tile_offsets = s->d_tile_offsets;
     ca.num_strong = s->d_num_strong;
+    ca.row_off = s->d_row_off;
     ca.list_k = s->d_list_k;
     ca.list_i = s->d_list_i;
     ca.parent = s->d_parent;
@@ -496,6 +508,8 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     sa.max_comp = c->max_comp;
     sa.overflow = s->d_overflow;
     sa.W = (uint32_t)L.W;
+    sa.H = (uint32_t)L.H;
+    sa.row_off = s->d_row_off;
     sa.slice_begin = nullptr;
     sa.n_slices = 1;
     sa.min_spot_size = p.min_spot_size;
@@ -670,6 +684,16 @@ extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_
     }
     if (results) *results = s->results.data();
     if (n_results) *n_results = n;
+    return FFS_OK;
+}
+
+extern "C" int ffs_stream_batch_arrays(ffs_stream* s, const ffs_box** boxes, uint32_t* n_boxes,
+                                       const ffs_reflection** refls, uint32_t* n_refls) {
+    if (!s) return FFS_ERR_INVALID;
+    if (boxes) *boxes = s->boxes.data();
+    if (n_boxes) *n_boxes = (uint32_t)s->boxes.size();
+    if (refls) *refls = s->refls.data();
+    if (n_refls) *n_refls = (uint32_t)s->refls.size();
     return FFS_OK;
 }
 
@@ -852,6 +876,8 @@ extern "C" int ffs_stack3d_finish(ffs_stack3d* st, const ffs_reflection** reflec
         sa.max_comp = N;
         sa.overflow = d_ovf;
         sa.W = (uint32_t)c->L.W;
+        sa.H = (uint32_t)c->L.H;
+        sa.row_off = nullptr;
         sa.slice_begin = d_begin;
         sa.n_slices = nz;
         sa.min_spot_size = c->params.min_spot_size_3d;

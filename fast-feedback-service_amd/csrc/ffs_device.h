@@ -34,7 +34,7 @@ constexpr int kStripStartOffset = -kLanePx;  // strip 0 starts at x = -8 (lane 0
 
 // Exact-stage tiles: one 256-thread workgroup per 8 rows.
 constexpr int kTileRows = 8;
-constexpr int kExactListCap = 8192;  // candidate entries staged in LDS per flush
+constexpr int kExactListCap = 2048;  // candidate entries staged in LDS per flush
 
 struct ThresholdArgs {
     const void* image;         // device pixels
@@ -53,6 +53,7 @@ struct ThresholdArgs {
     int min_count;
     double nsig_b, nsig_s, threshold;
     long long max_valid;       // < 0: no test
+    int variant;               // candidate kernel variant: 0 = per-pixel test, 1 = group screen + LDS queue
 };
 
 // ---- strong-pixel lists and connected components -------------------------------------------------
@@ -64,6 +65,7 @@ struct CclArgs {
     const uint32_t* tile_counts;
     uint32_t* tile_offsets;    // [n][n_tiles]
     uint32_t* num_strong;      // [n]
+    uint32_t* row_off;         // [n][H+1] list offset of the first strong pixel of each image row
     uint32_t* list_k;          // [n][cap] ascending linear index y*W + x
     uint32_t* list_i;          // [n][cap] intensity
     uint32_t* parent;          // [n][cap]
@@ -106,7 +108,8 @@ struct SegArgs {
     CompAcc* acc;             // [n_seg][max_comp]
     uint32_t max_comp;
     uint32_t* overflow;
-    uint32_t W;
+    uint32_t W, H;
+    const uint32_t* row_off;  // 2D only: [n_seg][H+1] per-row list offsets (may be null)
     // 3D only
     const uint32_t* slice_begin;  // [n_slices + 1] entry offsets of each slice inside the segment
     int n_slices;

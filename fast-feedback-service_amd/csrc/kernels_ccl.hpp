@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const CclArgs a) {
     }
     if (threadIdx.x == 0) {
         a.num_strong[frame] = running;
+        a.row_off[(uint64_t)frame * (a.H + 1) + a.H] = min(running, a.cap);
         if (running > a.cap) atomicOr(a.overflow, 1u);
     }
 }
@@ -70,9 +71,14 @@ __global__ __launch_bounds__(256) void k_emit_list(const CclArgs a) {
     __shared__ uint32_t s_wave[4];
     const int tile = blockIdx.x, frame = blockIdx.y;
     const uint32_t count = a.tile_counts[(uint64_t)frame * a.n_tiles + tile];
-    if (count == 0) return;  // block-uniform
     const int y0 = tile * kTileRows;
     const int rows = min(kTileRows, a.H - y0);
+    uint32_t* row_off = a.row_off + (uint64_t)frame * (a.H + 1);
+    if (count == 0) {  // block-uniform: empty rows all start where the tile starts
+        if ((int)threadIdx.x < rows)
+            row_off[y0 + threadIdx.x] = min(a.tile_offsets[(uint64_t)frame * a.n_tiles + tile], a.cap);
+        return;
+    }
     const int dpr = a.mpitch >> 2;
     const int ndw = rows * dpr;
     const uint32_t* words = reinterpret_cast<const uint32_t*>(
@@ -88,6 +94,7 @@ __global__ __launch_bounds__(256) void k_emit_list(const CclArgs a) {
         uint32_t total;
         uint32_t at = running + block_exclusive_scan<256>(__popc(w), s_wave, total);
         running += total;
+        if (g < ndw && g % dpr == 0) row_off[y0 + g / dpr] = min(at, a.cap);  // first word of a row
         if (w) {
             const int row = g / dpr;
             const int xb = (g - row * dpr) * 32;
@@ -162,9 +169,15 @@ __global__ __launch_bounds__(256) void k_union(const SegArgs a) {
         const uint32_t ki = k[i];
         // right neighbour: k + 1, with NO row-end check (connected_components.cc:62-70)
         if (i + 1 < s_end && k[i + 1] == ki + 1) uf_union(parent, i, i + 1);
-        // neighbour below: k + width (:63, :73-78)
+        // neighbour below: k + width (:63, :73-78); it lives in the next image row, whose
+        // list range is known from the compaction (row_off), so the search is a few steps
         {
             uint32_t lo = i + 1, hi = min(s_end, i + 1 + a.W);
+            if (!IS3D && a.row_off) {
+                const uint32_t* ro = a.row_off + (uint64_t)seg * (a.H + 1);
+                const uint32_t y = ki / a.W;
+                if (y + 1 < a.H) { lo = max(lo, ro[y + 1]); hi = min(hi, ro[y + 2]); } else hi = lo;
+            }
             const uint32_t key = ki + a.W;
             while (lo < hi) {
                 const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -233,8 +246,24 @@ __global__ __launch_bounds__(1024) void k_label(const SegArgs a) {
     }
 }
 
+// Per-component sums.  Entries of one component sit close together in the sorted list, so each
+// block first reduces a chunk of 512 consecutive entries into LDS accumulators (components whose
+// root lies inside the chunk have consecutive numbers) and then issues ONE set of global atomics
+// per component instead of one per pixel; entries whose root lies before the chunk go straight
+// to global atomics.  All sums are integers: the result does not depend on arrival order.
+constexpr int kReduceChunk = 512;
+
+struct LdsAcc {
+    unsigned long long sum_i, sum_xi, sum_yi, sum_zi, peak;
+    uint32_t x_min, x_max, y_min, y_max;
+    int32_t z_min, z_max;
+    uint32_t num_pixels, pad;
+};
+
 template <bool IS3D>
 __global__ __launch_bounds__(256) void k_reduce(const SegArgs a) {
+    __shared__ LdsAcc s_acc[kReduceChunk];
+    __shared__ uint32_t s_cmin, s_cmax;
     const int seg = blockIdx.y;
     const uint32_t n = min(a.seg_n[seg], (uint32_t)a.seg_stride);
     const uint32_t* k = a.list_k + (uint64_t)seg * a.seg_stride;
@@ -242,33 +271,104 @@ __global__ __launch_bounds__(256) void k_reduce(const SegArgs a) {
     const uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
     const uint32_t* comp_id = a.comp_id + (uint64_t)seg * a.seg_stride;
     CompAcc* acc = a.acc + (uint64_t)seg * a.max_comp;
-    uint32_t z = 0;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        if (IS3D) {
-            while (a.slice_begin[z + 1] <= i) ++z;
+    const int tid = threadIdx.x;
+
+    for (uint32_t base = blockIdx.x * kReduceChunk; base < n; base += gridDim.x * kReduceChunk) {
+        if (tid == 0) { s_cmin = 0xFFFFFFFFu; s_cmax = 0u; }
+        __syncthreads();
+        uint32_t ci[2], ri[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t i = base + tid + 256 * q;
+            ci[q] = 0xFFFFFFFFu;
+            ri[q] = 0;
+            if (i < n) {
+                ri[q] = parent[i];
+                ci[q] = comp_id[ri[q]];
+                if (ri[q] >= base && ci[q] < a.max_comp) {  // root inside this chunk
+                    atomicMin(&s_cmin, ci[q]);
+                    atomicMax(&s_cmax, ci[q]);
+                }
+            }
         }
-        const uint32_t c = comp_id[parent[i]];
-        if (c >= a.max_comp) continue;
-        CompAcc* r = acc + c;
-        const uint32_t ki = k[i];
-        const uint32_t y = ki / a.W, x = ki - y * a.W;
-        const unsigned long long I = inten[i];
-        atomicMin(&r->x_min, x);
-        atomicMax(&r->x_max, x);
-        atomicMin(&r->y_min, y);
-        atomicMax(&r->y_max, y);
-        if (IS3D) {
-            atomicMin(&r->z_min, (int32_t)z);
-            atomicMax(&r->z_max, (int32_t)z);
-            atomicAdd(&r->sum_zi, (2ull * z + 1ull) * I);
+        __syncthreads();
+        const uint32_t cmin = s_cmin, cmax = s_cmax;
+        const uint32_t nslots = cmin <= cmax ? cmax - cmin + 1 : 0;  // <= kReduceChunk
+        for (uint32_t sl = tid; sl < nslots; sl += 256) {
+            LdsAcc z;
+            z.sum_i = z.sum_xi = z.sum_yi = z.sum_zi = z.peak = 0ull;
+            z.x_min = 0xFFFFFFFFu; z.x_max = 0u; z.y_min = 0xFFFFFFFFu; z.y_max = 0u;
+            z.z_min = 0x7FFFFFFF; z.z_max = (int32_t)0x80000000;
+            z.num_pixels = 0; z.pad = 0;
+            s_acc[sl] = z;
         }
-        atomicAdd(&r->num_pixels, 1u);
-        atomicAdd(&r->sum_i, I);
-        atomicAdd(&r->sum_xi, (2ull * x + 1ull) * I);
-        atomicAdd(&r->sum_yi, (2ull * y + 1ull) * I);
-        // highest intensity, ties -> smallest (z, y, x) = smallest list index
-        // (connected_components.hpp:125-170, connected_components.cc:143-157)
-        atomicMax(&r->peak, (I << 32) | (unsigned long long)(0xFFFFFFFFu - i));
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t i = base + tid + 256 * q;
+            const uint32_t c = ci[q];
+            if (i >= n || c >= a.max_comp) continue;
+            const uint32_t ki = k[i];
+            const uint32_t y = ki / a.W, x = ki - y * a.W;
+            const unsigned long long I = inten[i];
+            uint32_t z = 0;
+            if (IS3D) {
+                int lo = 0, hi = a.n_slices;  // slice containing entry i
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (a.slice_begin[mid] <= i) lo = mid; else hi = mid;
+                }
+                z = (uint32_t)lo;
+            }
+            // highest intensity, ties -> smallest (z, y, x) = smallest list index
+            // (connected_components.hpp:125-170, connected_components.cc:143-157)
+            const unsigned long long pk = (I << 32) | (unsigned long long)(0xFFFFFFFFu - i);
+            if (ri[q] >= base) {
+                LdsAcc* r = &s_acc[c - cmin];
+                atomicMin(&r->x_min, x); atomicMax(&r->x_max, x);
+                atomicMin(&r->y_min, y); atomicMax(&r->y_max, y);
+                if (IS3D) {
+                    atomicMin(&r->z_min, (int32_t)z); atomicMax(&r->z_max, (int32_t)z);
+                    atomicAdd(&r->sum_zi, (2ull * z + 1ull) * I);
+                }
+                atomicAdd(&r->num_pixels, 1u);
+                atomicAdd(&r->sum_i, I);
+                atomicAdd(&r->sum_xi, (2ull * x + 1ull) * I);
+                atomicAdd(&r->sum_yi, (2ull * y + 1ull) * I);
+                atomicMax(&r->peak, pk);
+            } else {
+                CompAcc* r = acc + c;
+                atomicMin(&r->x_min, x); atomicMax(&r->x_max, x);
+                atomicMin(&r->y_min, y); atomicMax(&r->y_max, y);
+                if (IS3D) {
+                    atomicMin(&r->z_min, (int32_t)z); atomicMax(&r->z_max, (int32_t)z);
+                    atomicAdd(&r->sum_zi, (2ull * z + 1ull) * I);
+                }
+                atomicAdd(&r->num_pixels, 1u);
+                atomicAdd(&r->sum_i, I);
+                atomicAdd(&r->sum_xi, (2ull * x + 1ull) * I);
+                atomicAdd(&r->sum_yi, (2ull * y + 1ull) * I);
+                atomicMax(&r->peak, pk);
+            }
+        }
+        __syncthreads();
+        for (uint32_t sl = tid; sl < nslots; sl += 256) {
+            const LdsAcc v = s_acc[sl];
+            if (v.num_pixels == 0) continue;
+            CompAcc* r = acc + cmin + sl;
+            atomicMin(&r->x_min, v.x_min); atomicMax(&r->x_max, v.x_max);
+            atomicMin(&r->y_min, v.y_min); atomicMax(&r->y_max, v.y_max);
+            if (IS3D) {
+                atomicMin(&r->z_min, v.z_min); atomicMax(&r->z_max, v.z_max);
+                atomicAdd(&r->sum_zi, v.sum_zi);
+            }
+            atomicAdd(&r->num_pixels, v.num_pixels);
+            atomicAdd(&r->sum_i, v.sum_i);
+            atomicAdd(&r->sum_xi, v.sum_xi);
+            atomicAdd(&r->sum_yi, v.sum_yi);
+            atomicMax(&r->peak, v.peak);
+        }
+        __syncthreads();
     }
 }
 template __global__ void k_reduce<false>(const SegArgs);

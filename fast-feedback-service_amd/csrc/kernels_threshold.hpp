@@ -64,14 +64,58 @@ __device__ __forceinline__ void unpack_u16(const RowRegsU16& r, uint32_t (&A)[8]
     }
 }
 
+// The per-pixel conservative signal test (see k_candidates_u16) on one lane-group of 8 pixels:
+// window words Wn[j] (sum p | count << 22) and centre words Ac[j]; returns the 8 candidate bits.
+//   oracle: b = m p - x > nsig_s sqrt(x m)   (standalone.cc:167,169-170)
+//   here:   b |b| > nsig_s^2 (1 - 2^-16) x m  in float32 (b exact, |b| < 2^22).
+// An invalid centre has A = 0 -> p = 0 -> b <= 0 -> never a candidate; m < 2 gives b = 0 likewise.
+// e = kS x m - b|b| is negative exactly for candidates; its sign bit is shifted into the byte
+// with one v_alignbit per pixel (j = 7 first).
+__device__ __forceinline__ uint32_t signal_test8(const uint32_t (&Wn)[8], const uint32_t (&Ac)[8], float kS) {
+    uint32_t cb = 0;
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+        const uint32_t x = Wn[j] & kXMask;
+        const uint32_t m = Wn[j] >> 22;
+        const uint32_t pv = Ac[j] & kXMask;
+        const int32_t b = (int32_t)(m * pv) - (int32_t)x;  // 24-bit multiplies
+        const uint32_t tq = x * m;
+        const float bf = (float)b;
+        const float tf = (float)tq;
+        const float lhs = bf * __builtin_fabsf(bf);
+        const float e = __builtin_fmaf(kS, tf, -lhs);
+        cb = __builtin_amdgcn_alignbit(cb, __float_as_uint(e), 31);
+    }
+    return cb;
+}
+
+constexpr int kQCap = 128;  // lane-group queue entries per wave (power of two, >= 64 + 62)
+
+// SCREEN = false: every pixel takes the conservative signal test (11 VALU ops / pixel).
+// SCREEN = true : each lane first tests its 8-pixel group as a whole -- the largest centre pixel
+//   against the smallest window sum (windows with equal counts) -- which is still conservative and
+//   costs ~1/3 of eight pixel tests; the few groups that pass (a few %) are queued in LDS with
+//   their 16 words and tested pixel by pixel 64 groups at a time, so that work runs on dense
+//   lanes.  Both variants produce identical candidate planes.
+template <bool SCREEN>
 __global__ __launch_bounds__(64) void k_candidates_u16(const ThresholdArgs a) {
+    __shared__ uint4 s_qW0[SCREEN ? kQCap : 1], s_qW1[SCREEN ? kQCap : 1];
+    __shared__ uint4 s_qA0[SCREEN ? kQCap : 1], s_qA1[SCREEN ? kQCap : 1];
+    __shared__ uint32_t s_qtag[SCREEN ? kQCap : 1];
+
     const int lane = threadIdx.x;
-    const int strip = blockIdx.x % a.n_strips;
-    const int band = blockIdx.x / a.n_strips;
+    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group), and
+    // neighbouring strips of one band share the cache lines at their common edge: give all strips
+    // of a band the same label so those lines are served by one L2.  Speed only, never correctness.
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int strip = q % a.n_strips;
+    const int band = xcd + 8 * (q / a.n_strips);
+    if (band >= a.n_bands) return;  // grid is padded to a multiple of 8 bands
     const int frame = blockIdx.y;
     const int yb0 = band * a.band_rows;
     const int yb1 = min(yb0 + a.band_rows, a.H);
-    const int lx0 = strip * kStripOwnedPx + kStripStartOffset + lane * kLanePx;
+    const int sx0 = strip * kStripOwnedPx + kStripStartOffset;  // multiple of 8
+    const int lx0 = sx0 + lane * kLanePx;
     const bool active = lx0 >= 0 && lx0 + kLanePx <= a.pitch_px;
     const bool owned = active && lane >= 1 && lane <= 62;
     const int cx = active ? lx0 : 0;  // inactive lanes read column 0 and get their valid bits zeroed
@@ -85,7 +129,18 @@ __global__ __launch_bounds__(64) void k_candidates_u16(const ThresholdArgs a) {
                                   (uint32_t)a.H * a.bpitch);
     const rsrc_t r_cb = make_rsrc(a.bits + (uint64_t)frame * a.plane_frame_stride,
                                   (uint32_t)a.H * a.mpitch);
-    const uint32_t off_px = (uint32_t)cx * 2u, off_bit = (uint32_t)cx >> 3, off_byte = (uint32_t)cx;
+    // Offsets with bit 31 set are out of range for every resource: such loads return 0 and such
+    // stores are dropped.  Used instead of branches (inactive / not-owned lanes, rows outside the
+    // image) so that the loop body is straight-line code and the compiler can keep several rows of
+    // loads in flight with exact s_waitcnt vmcnt(N) counts.
+    constexpr uint32_t kOob = 0x80000000u;
+    const uint32_t off_px = (uint32_t)cx * 2u;
+    const uint32_t off_bit = active ? ((uint32_t)cx >> 3) : kOob;          // mask-bit loads
+    // the byte mask is zero-filled in aligned 512-byte runs (full cache lines), independent of
+    // which lanes own which pixels: wave (strip s) clears columns [512 s, 512 s + 512)
+    const uint32_t zcol = (uint32_t)strip * 512u + (uint32_t)lane * 8u;
+    const uint32_t off_byte_st = zcol < (uint32_t)a.bpitch ? zcol : kOob;  // byte-mask stores
+    const uint32_t off_bit_st = owned ? ((uint32_t)cx >> 3) : kOob;        // candidate stores
 
     const int total = (yb1 - yb0) + 6;  // incoming rows yb0-3 .. yb1+2
     const float kS = a.kS;
@@ -101,18 +156,15 @@ __global__ __launch_bounds__(64) void k_candidates_u16(const ThresholdArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) col[j] = 0;
 
-    // issue the loads of incoming row number i (image row yb0 - 3 + i) into slot `s`
+    // issue the loads of incoming row number i (image row yb0 - 3 + i)
     auto fetch = [&](RowRegsU16& dst, int i) {
         const int yin = yb0 - 3 + i;
-        if (i < total && yin >= 0 && yin < a.H) {  // wave-uniform
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_img, off_px, (uint32_t)yin * a.pitch, 0);
-            dst.raw = make_uint4(v[0], v[1], v[2], v[3]);
-            const uint32_t mb = __builtin_amdgcn_raw_buffer_load_b8(r_mask, off_bit, (uint32_t)yin * a.mpitch, 0);
-            dst.mb = active ? mb : 0u;
-        } else {
-            dst.raw = make_uint4(0, 0, 0, 0);
-            dst.mb = 0u;
-        }
+        const bool ok = (i < total) & (yin >= 0) & (yin < a.H);  // wave-uniform (scalar ALU)
+        const uint32_t kill = ok ? 0u : kOob;
+        const uint32_t row = ok ? (uint32_t)yin : 0u;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_img, off_px | kill, row * a.pitch, 0);
+        dst.raw = make_uint4(v[0], v[1], v[2], v[3]);
+        dst.mb = __builtin_amdgcn_raw_buffer_load_b8(r_mask, off_bit | kill, row * a.mpitch, 0);
     };
 
     // vertical running sum: add incoming row, retire the row that left the 7-row window
@@ -124,28 +176,47 @@ __global__ __launch_bounds__(64) void k_candidates_u16(const ThresholdArgs a) {
         }
     };
 
+    // ---- lane-group queue (SCREEN only); head/count are wave-uniform ---------------------------
+    int qhead = 0, qn = 0;
+    // test `cnt` (<= 64) queued groups, one per lane, and store their candidate bytes
+    auto drain = [&](int cnt) {
+        if (lane < cnt) {
+            const int e = (qhead + lane) & (kQCap - 1);
+            const uint4 w0 = s_qW0[e], w1 = s_qW1[e], a0 = s_qA0[e], a1 = s_qA1[e];
+            const uint32_t tag = s_qtag[e];
+            const uint32_t Wq[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            const uint32_t Aq[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const uint32_t cb = signal_test8(Wq, Aq, kS);
+            const uint32_t row = tag >> 6, ln = tag & 63u;
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)cb, r_cb, row * a.mpitch + (uint32_t)(sx0 >> 3) + ln, 0, 0);
+        }
+        qhead = (qhead + cnt) & (kQCap - 1);
+        qn -= cnt;
+    };
+
 #pragma unroll
-    for (int s = 0; s < 7; ++s) fetch(pre[s], s);
+    for (int s = 0; s < 4; ++s) fetch(pre[s], s);
 
     // warm-up: rows 0..5 of the band's input only fill the window
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
         uint32_t A[8];
         unpack_u16(pre[s], A);
-        fetch(pre[s], s + 7);
+        fetch(pre[(s + 4) % 7], s + 4);
         push(s, A);
     }
 
-    for (int base = 6; base < total; base += 7) {
+    for (int base = 6;; base += 7) {
 #pragma unroll
         for (int t = 0; t < 7; ++t) {
             const int s = (6 + t) % 7;   // slot of incoming row i (i % 7 == s)
             const int sc = (s + 4) % 7;  // slot of the centre row i - 3
             const int i = base + t;
-            if (i < total) {
+            if (i >= total) goto rows_done;
+            {
                 uint32_t A[8];
                 unpack_u16(pre[s], A);
-                fetch(pre[s], i + 7);
+                fetch(pre[(s + 4) % 7], i + 4);  // 4 rows of loads in flight per wave
                 push(s, A);
 
                 // horizontal 7-tap over column sums c[-3..10] = L5 L6 L7 c0..c7 R0 R1 R2
@@ -161,37 +232,57 @@ __global__ __launch_bounds__(64) void k_candidates_u16(const ThresholdArgs a) {
                 Wn[6] = Wn[5] - col[2] + R1;
                 Wn[7] = Wn[6] - col[3] + R2;
 
-                // conservative signal test on the centre row:
-                //   oracle: b = m p - x > nsig_s sqrt(x m)   (standalone.cc:167,169-170)
-                //   here:   b |b| > nsig_s^2 (1 - 2^-16) x m  in float32 (b exact, |b| < 2^22).
-                // An invalid centre has A = 0 -> p = 0 -> b <= 0 -> never a candidate; m < 2
-                // gives b = 0 likewise.
-                // e = kS x m - b|b| is negative exactly for candidates; its sign bit is shifted
-                // into the lane's candidate byte with one v_alignbit per pixel (j = 7 first).
-                uint32_t cb = 0;
-#pragma unroll
-                for (int j = 7; j >= 0; --j) {
-                    const uint32_t x = Wn[j] & kXMask;
-                    const uint32_t m = Wn[j] >> 22;
-                    const uint32_t pv = ring[sc][j] & kXMask;
-                    const int32_t b = (int32_t)(m * pv) - (int32_t)x;  // 24-bit multiplies
-                    const uint32_t tq = x * m;
-                    const float bf = (float)b;
-                    const float tf = (float)tq;
-                    const float lhs = bf * __builtin_fabsf(bf);
-                    const float e = __builtin_fmaf(kS, tf, -lhs);
-                    cb = __builtin_amdgcn_alignbit(cb, __float_as_uint(e), 31);
-                }
-
                 const int yout = yb0 + (i - 6);
-                if (owned) {
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte, (uint32_t)yout * a.bpitch, 0);
-                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)cb, r_cb, off_bit, (uint32_t)yout * a.mpitch, 0);
+                if (!SCREEN) {
+                    const uint32_t cb = signal_test8(Wn, ring[sc], kS);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, (uint32_t)yout * a.bpitch, 0);
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)cb, r_cb, off_bit_st, (uint32_t)yout * a.mpitch, 0);
+                } else {
+                    // group screen: every pixel j of the group has p_j <= pmax and, when all eight
+                    // windows hold the same count m, x_j >= xmin; b_j <= m pmax - xmin and
+                    // sqrt(x_j m) >= sqrt(xmin m), so a group whose (pmax, xmin) fails the test has
+                    // no candidate.  Groups with unequal counts (next to masked pixels) always pass.
+                    const uint32_t wmin = min(min(min(Wn[0], Wn[1]), min(Wn[2], Wn[3])),
+                                              min(min(Wn[4], Wn[5]), min(Wn[6], Wn[7])));
+                    const uint32_t wmax = max(max(max(Wn[0], Wn[1]), max(Wn[2], Wn[3])),
+                                              max(max(Wn[4], Wn[5]), max(Wn[6], Wn[7])));
+                    const uint32_t amax = max(max(max(ring[sc][0], ring[sc][1]), max(ring[sc][2], ring[sc][3])),
+                                              max(max(ring[sc][4], ring[sc][5]), max(ring[sc][6], ring[sc][7])));
+                    const uint32_t x = wmin & kXMask, m = wmin >> 22, pv = amax & kXMask;
+                    const int32_t b = (int32_t)(m * pv) - (int32_t)x;
+                    const float bf = (float)b, tf = (float)(x * m);
+                    const bool pass = (bf * __builtin_fabsf(bf) > kS * tf) || ((wmin ^ wmax) >> 22) != 0;
+                    const bool flag = owned && pass;
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, (uint32_t)yout * a.bpitch, 0);
+                    // queued groups get their byte from drain(); everybody else stores 0 now
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)0, r_cb, flag ? kOob : off_bit_st,
+                                                         (uint32_t)yout * a.mpitch, 0);
+                    const unsigned long long fm = __ballot(flag);
+                    if (fm) {  // wave-uniform
+                        if (flag) {
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32),
+                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                            const int e = (qhead + qn + (int)rank) & (kQCap - 1);
+                            s_qW0[e] = make_uint4(Wn[0], Wn[1], Wn[2], Wn[3]);
+                            s_qW1[e] = make_uint4(Wn[4], Wn[5], Wn[6], Wn[7]);
+                            s_qA0[e] = make_uint4(ring[sc][0], ring[sc][1], ring[sc][2], ring[sc][3]);
+                            s_qA1[e] = make_uint4(ring[sc][4], ring[sc][5], ring[sc][6], ring[sc][7]);
+                            s_qtag[e] = ((uint32_t)yout << 6) | (uint32_t)lane;
+                        }
+                        qn += __popcll(fm);
+                        if (qn >= 64) drain(64);
+                    }
                 }
             }
         }
     }
+rows_done:
+    if (SCREEN) {
+        if (qn > 0) drain(qn);  // qn < 64 here
+    }
 }
+template __global__ void k_candidates_u16<false>(const ThresholdArgs);
+template __global__ void k_candidates_u16<true>(const ThresholdArgs);
 
 // ================================================================================================
 // K1: candidates, uint32 pixels (the reference's PIXEL_DATA_32BIT build, h5read.h:16-20)
@@ -211,8 +302,10 @@ struct RowRegsU32 {
 
 __global__ __launch_bounds__(64) void k_candidates_u32(const ThresholdArgs a) {
     const int lane = threadIdx.x;
-    const int strip = blockIdx.x % a.n_strips;
-    const int band = blockIdx.x / a.n_strips;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;  // XCD-aware mapping, see k_candidates_u16
+    const int strip = q % a.n_strips;
+    const int band = xcd + 8 * (q / a.n_strips);
+    if (band >= a.n_bands) return;
     const int frame = blockIdx.y;
     const int yb0 = band * a.band_rows;
     const int yb1 = min(yb0 + a.band_rows, a.H);
@@ -228,7 +321,12 @@ __global__ __launch_bounds__(64) void k_candidates_u32(const ThresholdArgs a) {
                                   (uint32_t)a.H * a.bpitch);
     const rsrc_t r_cb = make_rsrc(a.bits + (uint64_t)frame * a.plane_frame_stride,
                                   (uint32_t)a.H * a.mpitch);
-    const uint32_t off_px = (uint32_t)cx * 4u, off_bit = (uint32_t)cx >> 3, off_byte = (uint32_t)cx;
+    constexpr uint32_t kOob = 0x80000000u;  // out-of-range offset: loads give 0, stores are dropped
+    const uint32_t off_px = (uint32_t)cx * 4u;
+    const uint32_t off_bit = active ? ((uint32_t)cx >> 3) : kOob;
+    const uint32_t zcol = (uint32_t)strip * 256u + (uint32_t)lane * 4u;  // aligned 256-byte zero runs
+    const uint32_t off_byte_st = zcol < (uint32_t)a.bpitch ? zcol : kOob;
+    const uint32_t off_bit_st = (owned && !(lane & 1)) ? ((uint32_t)cx >> 3) : kOob;
     const uint32_t nib = (uint32_t)cx & 4u;
 
     const int total = (yb1 - yb0) + 6;
@@ -248,15 +346,13 @@ __global__ __launch_bounds__(64) void k_candidates_u32(const ThresholdArgs a) {
 
     auto fetch = [&](RowRegsU32& dst, int i) {
         const int yin = yb0 - 3 + i;
-        if (i < total && yin >= 0 && yin < a.H) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_img, off_px, (uint32_t)yin * a.pitch, 0);
-            dst.raw = make_uint4(v[0], v[1], v[2], v[3]);
-            const uint32_t mb = __builtin_amdgcn_raw_buffer_load_b8(r_mask, off_bit, (uint32_t)yin * a.mpitch, 0);
-            dst.mb = active ? ((mb >> nib) & 0xFu) : 0u;
-        } else {
-            dst.raw = make_uint4(0, 0, 0, 0);
-            dst.mb = 0u;
-        }
+        const bool ok = (i < total) & (yin >= 0) & (yin < a.H);  // wave-uniform
+        const uint32_t kill = ok ? 0u : kOob;
+        const uint32_t row = ok ? (uint32_t)yin : 0u;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_img, off_px | kill, row * a.pitch, 0);
+        dst.raw = make_uint4(v[0], v[1], v[2], v[3]);
+        const uint32_t mb = __builtin_amdgcn_raw_buffer_load_b8(r_mask, off_bit | kill, row * a.mpitch, 0);
+        dst.mb = (mb >> nib) & 0xFu;
     };
 
     auto push = [&](int s, const RowRegsU32& r) {
@@ -277,23 +373,24 @@ __global__ __launch_bounds__(64) void k_candidates_u32(const ThresholdArgs a) {
     };
 
 #pragma unroll
-    for (int s = 0; s < 7; ++s) fetch(pre[s], s);
+    for (int s = 0; s < 4; ++s) fetch(pre[s], s);
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
         const RowRegsU32 r = pre[s];
-        fetch(pre[s], s + 7);
+        fetch(pre[(s + 4) % 7], s + 4);
         push(s, r);
     }
 
-    for (int base = 6; base < total; base += 7) {
+    for (int base = 6;; base += 7) {
 #pragma unroll
         for (int t = 0; t < 7; ++t) {
             const int s = (6 + t) % 7;
             const int sc = (s + 4) % 7;
             const int i = base + t;
-            if (i < total) {
+            if (i >= total) return;
+            {
                 const RowRegsU32 r = pre[s];
-                fetch(pre[s], i + 7);
+                fetch(pre[(s + 4) % 7], i + 4);
                 push(s, r);
 
                 // c[-3..6] = L1 L2 L3 c0..c3 R0 R1 R2 for both words
@@ -338,12 +435,9 @@ __global__ __launch_bounds__(64) void k_candidates_u32(const ThresholdArgs a) {
                 // an (even, odd) lane pair shares one byte of the candidate plane
                 const uint32_t hi = from_right(cb);
                 const int yout = yb0 + (i - 6);
-                if (owned) {
-                    __builtin_amdgcn_raw_buffer_store_b32(0u, r_sb, off_byte, (uint32_t)yout * a.bpitch, 0);
-                    if (!(lane & 1))
-                        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(cb | (hi << 4)), r_cb, off_bit,
-                                                             (uint32_t)yout * a.mpitch, 0);
-                }
+                __builtin_amdgcn_raw_buffer_store_b32(0u, r_sb, off_byte_st, (uint32_t)yout * a.bpitch, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(cb | (hi << 4)), r_cb, off_bit_st,
+                                                     (uint32_t)yout * a.mpitch, 0);
             }
         }
     }
@@ -415,9 +509,11 @@ __device__ bool exact_strong(const ThresholdArgs& a, const uint8_t* img, int x, 
 
 template <typename PixelT>
 __global__ __launch_bounds__(256) void k_exact(const ThresholdArgs a) {
+    // 18 KB of LDS per workgroup -> 8 workgroups (32 waves) per CU: the stage is latency-bound
+    // (sparse gathers), so residency is what hides it.
     __shared__ uint32_t s_words[kTileRows * 320];  // tile bit-plane words (pitch_px <= 10240)
     __shared__ uint32_t s_list[kExactListCap];
-    __shared__ uint32_t s_cnt, s_chunk, s_strong;
+    __shared__ uint32_t s_cnt, s_total, s_strong;
 
     const int tid = threadIdx.x;
     const int tile = blockIdx.x, frame = blockIdx.y;
@@ -430,10 +526,29 @@ __global__ __launch_bounds__(256) void k_exact(const ThresholdArgs a) {
                                                    + (uint64_t)y0 * a.mpitch);
     uint8_t* sbytes = a.strong_bytes + (uint64_t)frame * a.bytes_frame_stride;
 
-    if (tid == 0) { s_cnt = 0; s_strong = 0; }
-    for (int g = tid; g < ndw; g += 256) s_words[g] = gwords[g];
+    if (tid == 0) { s_cnt = 0; s_total = 0; s_strong = 0; }
+    uint32_t mine = 0;
+    for (int g = tid; g < ndw; g += 256) {
+        const uint32_t w = gwords[g];
+        s_words[g] = w;
+        mine += __popc(w);
+    }
     __syncthreads();
+    if (mine) atomicAdd(&s_total, mine);
+    __syncthreads();
+    const uint32_t total = s_total;  // block-uniform
+    if (total == 0) {
+        if (tid == 0) a.tile_counts[(uint64_t)frame * a.n_tiles + tile] = 0;
+        return;
+    }
 
+    auto append = [&](int g, uint32_t w, uint32_t at) {
+        while (w) {
+            const uint32_t bit = __ffs(w) - 1;
+            w &= w - 1;
+            s_list[at++] = ((uint32_t)g << 5) | bit;
+        }
+    };
     auto flush = [&]() {
         const uint32_t n = s_cnt;
         for (uint32_t e = tid; e < n; e += 256) {
@@ -450,32 +565,31 @@ __global__ __launch_bounds__(256) void k_exact(const ThresholdArgs a) {
         }
     };
 
-    for (int pos = 0; pos < ndw; pos += 256) {
-        const int g = pos + tid;
-        const uint32_t w = g < ndw ? s_words[g] : 0u;
-        const uint32_t n = __popc(w);
-        if (tid == 0) s_chunk = 0;
+    if (total <= (uint32_t)kExactListCap) {
+        // the usual case: every candidate of the tile in one dense pass
+        if (mine) {
+            uint32_t at = atomicAdd(&s_cnt, mine);
+            for (int g = tid; g < ndw; g += 256) {
+                const uint32_t w = s_words[g];
+                append(g, w, at);
+                at += __popc(w);
+            }
+        }
         __syncthreads();
-        if (n) atomicAdd(&s_chunk, n);
-        __syncthreads();
-        if (s_cnt + s_chunk > (uint32_t)kExactListCap) {  // block-uniform
+        flush();
+    } else {
+        // dense tile: 64 words (<= 2048 candidates) at a time
+        for (int pos = 0; pos < ndw; pos += kExactListCap / 32) {
+            const int g = pos + tid;
+            const uint32_t w = (tid < kExactListCap / 32 && g < ndw) ? s_words[g] : 0u;
+            if (w) append(g, w, atomicAdd(&s_cnt, (uint32_t)__popc(w)));
+            __syncthreads();
             flush();
             __syncthreads();
             if (tid == 0) s_cnt = 0;
             __syncthreads();
         }
-        if (n) {
-            uint32_t at = atomicAdd(&s_cnt, n);
-            uint32_t ww = w;
-            while (ww) {
-                const uint32_t bit = __ffs(ww) - 1;
-                ww &= ww - 1;
-                s_list[at++] = ((uint32_t)g << 5) | bit;
-            }
-        }
-        __syncthreads();
     }
-    flush();
     __syncthreads();
 
     uint32_t cnt = 0;

@@ -69,7 +69,7 @@ EXPORTS = [
     "ffs_ctx_create", "ffs_ctx_destroy", "ffs_last_error", "ffs_ctx_set_mask",
     "ffs_ctx_apply_resolution_mask", "ffs_ctx_get_mask", "ffs_ctx_set_params",
     "ffs_stream_create", "ffs_stream_destroy", "ffs_stream_host_buffer", "ffs_submit",
-    "ffs_submit_device", "ffs_ctx_device_layout", "ffs_wait", "ffs_stream_timings",
+    "ffs_submit_device", "ffs_ctx_device_layout", "ffs_wait", "ffs_stream_batch_arrays", "ffs_stream_timings",
     "ffs_bench_threshold", "ffs_stream_debug_planes", "ffs_stack3d_create",
     "ffs_stack3d_destroy", "ffs_stack3d_add_batch", "ffs_stack3d_add_slice", "ffs_stack3d_finish",
 ]
@@ -103,6 +103,8 @@ def load_library():
         L.ffs_submit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_int64]
         L.ffs_wait.argtypes = [C.c_void_p, C.POINTER(C.POINTER(_FrameResult)), C.POINTER(C.c_uint32)]
         L.ffs_stream_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.ffs_stream_batch_arrays.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
+                                              C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
         L.ffs_bench_threshold.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32,
                                           C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.ffs_stream_debug_planes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
@@ -263,8 +265,20 @@ class Stream:
         res = C.POINTER(_FrameResult)()
         n = C.c_uint32()
         self.ctx._check(self._lib.ffs_wait(self._h, C.byref(res), C.byref(n)))
+        # two copies for the whole batch, then per-frame views
+        bp, rp = C.c_void_p(), C.c_void_p()
+        nb, nr = C.c_uint32(), C.c_uint32()
+        self.ctx._check(self._lib.ffs_stream_batch_arrays(self._h, C.byref(bp), C.byref(nb),
+                                                          C.byref(rp), C.byref(nr)))
+        boxes = (np.frombuffer(C.string_at(bp, nb.value * BOX_DT.itemsize), BOX_DT)
+                 if nb.value else np.zeros(0, BOX_DT))
+        refls = (np.frombuffer(C.string_at(rp, nr.value * REFL_DT.itemsize), REFL_DT)
+                 if nr.value else np.zeros(0, REFL_DT))
+        want_refl = bool(self.ctx.params.want_reflections)
+        want_list = bool(self.ctx.params.want_strong_list)
         out = []
         W, H = self.ctx.W, self.ctx.H
+        b0 = r0 = 0
         for i in range(n.value):
             r = res[i]
             ns = r.num_strong_pixels
@@ -272,15 +286,18 @@ class Stream:
                 frame_id=r.frame_id, num_strong_pixels=ns,
                 num_strong_pixels_filtered=r.num_strong_pixels_filtered,
                 n_components=r.n_components,
-                boxes=_copy_array(r.boxes, r.n_boxes, _Box, BOX_DT),
-                reflections=_copy_array(r.reflections, r.n_reflections, _Refl, REFL_DT) if r.reflections or self.ctx.params.want_reflections else None,
+                boxes=boxes[b0:b0 + r.n_boxes],
+                reflections=refls[r0:r0 + r.n_reflections] if want_refl else None,
                 n_filtered_size=r.n_filtered_size, n_filtered_sep=r.n_filtered_sep)
-            if r.strong_k:
-                fr.strong_k = np.ctypeslib.as_array(r.strong_k, (max(ns, 1),))[:ns].copy()
-                fr.strong_intensity = np.ctypeslib.as_array(r.strong_intensity, (max(ns, 1),))[:ns].copy()
-            elif self.ctx.params.want_strong_list:
-                fr.strong_k = np.zeros(0, np.uint32)
-                fr.strong_intensity = np.zeros(0, np.uint32)
+            b0 += r.n_boxes
+            r0 += r.n_reflections
+            if want_list:
+                if ns and r.strong_k:
+                    fr.strong_k = np.ctypeslib.as_array(r.strong_k, (ns,)).copy()
+                    fr.strong_intensity = np.ctypeslib.as_array(r.strong_intensity, (ns,)).copy()
+                else:
+                    fr.strong_k = np.zeros(0, np.uint32)
+                    fr.strong_intensity = np.zeros(0, np.uint32)
             if r.strong_mask:
                 fr.strong_mask = np.ctypeslib.as_array(r.strong_mask, (H, W)).copy()
             out.append(fr)

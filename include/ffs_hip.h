@@ -155,6 +155,12 @@ int ffs_ctx_device_layout(const ffs_ctx *ctx, size_t *pitch_bytes, size_t *frame
 /* Blocks until the stream's batch is done; results[i] describes frame i of the batch. */
 int ffs_wait(ffs_stream *s, const ffs_frame_result **results, uint32_t *n_results);
 
+/* The whole batch's boxes and reflections as two contiguous arrays (frame i's slice starts
+ * where frame i-1's ends; lengths are results[i].n_boxes / .n_reflections) -- lets a binding
+ * wrap a batch without touching every frame. */
+int ffs_stream_batch_arrays(ffs_stream *s, const ffs_box **boxes, uint32_t *n_boxes,
+                            const ffs_reflection **reflections, uint32_t *n_reflections);
+
 /* Timings of the last completed batch on this stream, milliseconds (HIP events on the
  * stream): [0] H2D, [1] threshold kernels, [2] compaction + connected components,
  * [3] D2H, [4] total.  (The reference prints Copy/Kernel/Post Copy/Post, spotfinder.cc:1056-1076.) */

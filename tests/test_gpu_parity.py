@@ -120,6 +120,22 @@ def test_config1_plumbing_frames(ffs):
         assert cc.num_strong_pixels > 500
 
 
+@pytest.mark.parametrize("variant", ["0", "1"])
+def test_candidate_kernel_variants(ffs, variant, monkeypatch):
+    """Both candidate-kernel variants (per-pixel test / group screen + LDS queue) must give the
+    oracle's result; frames chosen so the lane-group queue wraps many times per wave."""
+    monkeypatch.setenv("FFS_K1_VARIANT", variant)
+    rng = np.random.default_rng(99)
+    H, W = 700, 1100
+    mask = _mask(rng, H, W, dead=300)
+    ctx = ffs.Context(W, H, np.uint16, max_batch=2)
+    ctx.set_mask(mask)
+    ctx.set_params(want_strong_mask=1, want_strong_list=1)
+    frames = np.stack([_spotty(rng, H, W, 0.05, 400, peak=2000), _spotty(rng, H, W, 8.0, 3000, peak=800)])
+    for fr, img in zip(ctx.stream().process(frames), frames):
+        assert_frame_matches_oracle(fr, img, mask)
+
+
 def test_params_min_count_and_max_valid(ffs):
     """GPU-reference flavoured parameters: min_count 3 (spotfinder.cuh:18) and a trusted
     maximum on the centre pixel (thresholding.cu:208-215)."""

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--unique", type=int, default=4, help="unique synthetic frames (cycled)")
     ap.add_argument("--workload", default="eiger16m")
+    ap.add_argument("--variants", default="1", help="comma list of FFS_K1_VARIANT values to A/B")
+    ap.add_argument("--rounds", type=int, default=1)
     args = ap.parse_args()
     import torch
     import ffs_amd
@@ -36,10 +38,14 @@ def main():
         host[i, :, :W] = frames[i % len(frames)]
     d = torch.from_numpy(host.view(np.uint8).reshape(-1)).cuda()
     st = ctx.stream()
-    a, b = st.bench_threshold(d.data_ptr(), pitch, fstride, B, args.iters)
     alg = float(W) * H * bpp * B
-    print(f"k_candidates {a*1e3:.1f} us/launch ({alg/a/1e6:.0f} GB/s algorithmic), k_exact {b*1e3:.1f} us/launch, "
-          f"batch {B}")
+    variants = [int(v) for v in args.variants.split(",")]
+    for rnd in range(args.rounds):          # interleaved A/B rounds in one process
+        for v in variants:
+            os.environ["FFS_K1_VARIANT"] = str(v)
+            a, b = st.bench_threshold(d.data_ptr(), pitch, fstride, B, args.iters)
+            print(f"round {rnd} variant {v}: k_candidates {a*1e3:.1f} us/launch ({alg/a/1e6:.0f} GB/s algorithmic, "
+                  f"{alg/a/1e6/8000:.3f} of 8 TB/s), k_exact {b*1e3:.1f} us/launch, batch {B}", flush=True)
 
 
 if __name__ == "__main__":
