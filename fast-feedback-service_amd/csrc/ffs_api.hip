@@ -518,7 +518,6 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     sa.summary = s->d_summary;
     const dim3 gseg(32, n), b256(256);
     hipLaunchKernelGGL(k_union<false>, gseg, b256, 0, s->st, sa);
-    hipLaunchKernelGGL(k_flatten, gseg, b256, 0, s->st, sa);
     hipLaunchKernelGGL(k_label, dim3(n), dim3(1024), 0, s->st, sa);
     hipLaunchKernelGGL(k_reduce<false>, gseg, b256, 0, s->st, sa);
     hipLaunchKernelGGL(k_finalize<false>, dim3(8, n), b256, 0, s->st, sa);
@@ -886,7 +885,6 @@ extern "C" int ffs_stack3d_finish(ffs_stack3d* st, const ffs_reflection** reflec
         sa.summary = d_sum;
         const unsigned nb = (unsigned)std::min<uint64_t>(2048, ((uint64_t)N + 255) / 256);
         hipLaunchKernelGGL(k_union<true>, dim3(nb, 1), dim3(256), 0, 0, sa);
-        hipLaunchKernelGGL(k_flatten, dim3(nb, 1), dim3(256), 0, 0, sa);
         hipLaunchKernelGGL(k_label, dim3(1), dim3(1024), 0, 0, sa);
         hipLaunchKernelGGL(k_reduce<true>, dim3(nb, 1), dim3(256), 0, 0, sa);
         hipLaunchKernelGGL(k_finalize<true>, dim3(nb, 1), dim3(256), 0, 0, sa);

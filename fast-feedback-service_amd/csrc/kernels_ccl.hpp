@@ -87,30 +87,31 @@ __global__ __launch_bounds__(256) void k_emit_list(const CclArgs a) {
     uint32_t* lk = a.list_k + (uint64_t)frame * a.cap;
     uint32_t* li = a.list_i + (uint64_t)frame * a.cap;
     uint32_t* par = a.parent + (uint64_t)frame * a.cap;
-    uint32_t running = a.tile_offsets[(uint64_t)frame * a.n_tiles + tile];
-    for (int pos = 0; pos < ndw; pos += 256) {
-        const int g = pos + threadIdx.x;
-        uint32_t w = g < ndw ? words[g] : 0u;
-        uint32_t total;
-        uint32_t at = running + block_exclusive_scan<256>(__popc(w), s_wave, total);
-        running += total;
-        if (g < ndw && g % dpr == 0) row_off[y0 + g / dpr] = min(at, a.cap);  // first word of a row
-        if (w) {
-            const int row = g / dpr;
-            const int xb = (g - row * dpr) * 32;
-            const int y = y0 + row;
-            while (w) {
-                const int bit = __ffs(w) - 1;
-                w &= w - 1;
-                const int x = xb + bit;
-                if (at < a.cap) {
-                    lk[at] = (uint32_t)y * (uint32_t)a.W + (uint32_t)x;
-                    li[at] = *reinterpret_cast<const PixelT*>(img + (uint64_t)y * a.pitch
-                                                               + (uint64_t)x * sizeof(PixelT));
-                    par[at] = at;
-                }
-                ++at;
+    // each thread owns a contiguous run of words, so ONE block scan gives raster order
+    const uint32_t tile_base = a.tile_offsets[(uint64_t)frame * a.n_tiles + tile];
+    const int per = (ndw + 255) / 256;
+    const int g0 = min((int)threadIdx.x * per, ndw), g1 = min(g0 + per, ndw);
+    uint32_t mine = 0;
+    for (int g = g0; g < g1; ++g) mine += __popc(words[g]);
+    uint32_t total;
+    uint32_t at = tile_base + block_exclusive_scan<256>(mine, s_wave, total);
+    for (int g = g0; g < g1; ++g) {
+        uint32_t w = words[g];
+        const int row = g / dpr;
+        if (g - row * dpr == 0) row_off[y0 + row] = min(at, a.cap);  // first word of an image row
+        const int xb = (g - row * dpr) * 32;
+        const int y = y0 + row;
+        while (w) {
+            const int bit = __ffs(w) - 1;
+            w &= w - 1;
+            const int x = xb + bit;
+            if (at < a.cap) {
+                lk[at] = (uint32_t)y * (uint32_t)a.W + (uint32_t)x;
+                li[at] = *reinterpret_cast<const PixelT*>(img + (uint64_t)y * a.pitch
+                                                           + (uint64_t)x * sizeof(PixelT));
+                par[at] = at;
             }
+            ++at;
         }
     }
 }
@@ -216,27 +217,27 @@ __global__ __launch_bounds__(1024) void k_label(const SegArgs a) {
     const uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
     uint32_t* comp_id = a.comp_id + (uint64_t)seg * a.seg_stride;
     CompAcc* acc = a.acc + (uint64_t)seg * a.max_comp;
-    uint32_t running = 0;
-    for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
-        const uint32_t i = i0 + threadIdx.x;
-        const bool root = i < n && parent[i] == i;
-        uint32_t total;
-        const uint32_t c = running + block_exclusive_scan<1024>(root ? 1u : 0u, s_wave, total);
-        running += total;
-        if (root) {
-            comp_id[i] = c;
-            if (c < a.max_comp) {
-                CompAcc z;
-                z.sum_i = z.sum_xi = z.sum_yi = z.sum_zi = 0ull;
-                z.peak = 0ull;
-                z.x_min = 0xFFFFFFFFu; z.x_max = 0u;
-                z.y_min = 0xFFFFFFFFu; z.y_max = 0u;
-                z.z_min = 0x7FFFFFFF; z.z_max = (int32_t)0x80000000;
-                z.num_pixels = 0u;
-                z.root = i;
-                acc[c] = z;
-            }
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t b0 = min(threadIdx.x * per, n), b1 = min(b0 + per, n);
+    uint32_t mine = 0;
+    for (uint32_t i = b0; i < b1; ++i) mine += parent[i] == i ? 1u : 0u;
+    uint32_t running;
+    uint32_t c = block_exclusive_scan<1024>(mine, s_wave, running);
+    for (uint32_t i = b0; i < b1; ++i) {
+        if (parent[i] != i) continue;
+        comp_id[i] = c;
+        if (c < a.max_comp) {
+            CompAcc z;
+            z.sum_i = z.sum_xi = z.sum_yi = z.sum_zi = 0ull;
+            z.peak = 0ull;
+            z.x_min = 0xFFFFFFFFu; z.x_max = 0u;
+            z.y_min = 0xFFFFFFFFu; z.y_max = 0u;
+            z.z_min = 0x7FFFFFFF; z.z_max = (int32_t)0x80000000;
+            z.num_pixels = 0u;
+            z.root = i;
+            acc[c] = z;
         }
+        ++c;
     }
     if (threadIdx.x == 0) {
         a.n_comp[seg] = running;
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256) void k_reduce(const SegArgs a) {
     const uint32_t n = min(a.seg_n[seg], (uint32_t)a.seg_stride);
     const uint32_t* k = a.list_k + (uint64_t)seg * a.seg_stride;
     const uint32_t* inten = a.list_i + (uint64_t)seg * a.seg_stride;
-    const uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
+    uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
     const uint32_t* comp_id = a.comp_id + (uint64_t)seg * a.seg_stride;
     CompAcc* acc = a.acc + (uint64_t)seg * a.max_comp;
     const int tid = threadIdx.x;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void k_reduce(const SegArgs a) {
             ci[q] = 0xFFFFFFFFu;
             ri[q] = 0;
             if (i < n) {
-                ri[q] = parent[i];
+                ri[q] = uf_find(parent, i);  // no separate flatten pass: chase to the root here
                 ci[q] = comp_id[ri[q]];
                 if (ri[q] >= base && ci[q] < a.max_comp) {  // root inside this chunk
                     atomicMin(&s_cmin, ci[q]);

@@ -448,52 +448,69 @@ __global__ __launch_bounds__(64) void k_candidates_u32(const ThresholdArgs a) {
 // ================================================================================================
 
 // Exact integer window sums + the oracle predicate, standalone.cc:113-174 operation for operation.
+// All seven window rows (pixels and mask bits) are requested before any is used, so a candidate
+// costs one memory round trip, not seven.
 template <typename PixelT>
 __device__ bool exact_strong(const ThresholdArgs& a, const uint8_t* img, int x, int y) {
     const int W = a.W, H = a.H;
-    const uint8_t* mrow = a.maskbits + (uint64_t)y * a.mpitch;
-    if (!((mrow[x >> 3] >> (x & 7)) & 1)) return false;  // mask[k], :165
-    const PixelT pc = *reinterpret_cast<const PixelT*>(img + (uint64_t)y * a.pitch + (uint64_t)x * sizeof(PixelT));
-
     const int xs = max(x - 3, 0), xe = min(x + 3, W - 1);  // window clipped to the image, :126-130
-    const int ys = max(y - 3, 0), ye = min(y + 3, H - 1);
-    uint32_t m = 0;
-    unsigned long long sx = 0, sy = 0;
     // 8 pixels starting at an even column cover the (<= 7 wide) window row
     const int bx = min(xs & ~1, a.pitch_px - 8);
     const uint32_t rm = ((1u << (xe - bx + 1)) - 1u) & ~((1u << (xs - bx)) - 1u);
-    for (int yy = ys; yy <= ye; ++yy) {
-        const uint8_t* mp = a.maskbits + (uint64_t)yy * a.mpitch + (bx >> 3);
-        uint32_t mb = mp[0];
-        if (bx & 7) mb |= (uint32_t)mp[1] << 8;
-        mb = (mb >> (bx & 7)) & rm;
-        const uint8_t* rp = img + (uint64_t)yy * a.pitch + (uint64_t)bx * sizeof(PixelT);
+    const int sh = bx & 7;
+
+    uint4 r0[7], r1[7];
+    uint32_t mb[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const int yy = y - 3 + r;
+        const bool ok = yy >= 0 && yy < H;  // rows outside the image contribute nothing
+        const int yc = ok ? yy : y;
+        const uint8_t* mp = a.maskbits + (uint64_t)yc * a.mpitch + (bx >> 3);
+        uint32_t b = mp[0];
+        if (sh) b |= (uint32_t)mp[1] << 8;
+        mb[r] = ok ? b : 0u;
+        const uint8_t* rp = img + (uint64_t)yc * a.pitch + (uint64_t)bx * sizeof(PixelT);
+        r0[r] = *reinterpret_cast<const uint4*>(rp);  // 4-byte aligned
+        if constexpr (sizeof(PixelT) == 4) r1[r] = *reinterpret_cast<const uint4*>(rp + 16);
+    }
+
+    uint32_t m = 0;
+    unsigned long long sx = 0, sy = 0;
+    uint32_t pc = 0;
+    bool centre_valid = false;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
         uint32_t p[8];
         if constexpr (sizeof(PixelT) == 2) {
-            const uint4 r = *reinterpret_cast<const uint4*>(rp);  // 4-byte aligned
-            p[0] = r.x & 0xFFFFu; p[1] = r.x >> 16; p[2] = r.y & 0xFFFFu; p[3] = r.y >> 16;
-            p[4] = r.z & 0xFFFFu; p[5] = r.z >> 16; p[6] = r.w & 0xFFFFu; p[7] = r.w >> 16;
+            p[0] = r0[r].x & 0xFFFFu; p[1] = r0[r].x >> 16; p[2] = r0[r].y & 0xFFFFu; p[3] = r0[r].y >> 16;
+            p[4] = r0[r].z & 0xFFFFu; p[5] = r0[r].z >> 16; p[6] = r0[r].w & 0xFFFFu; p[7] = r0[r].w >> 16;
         } else {
-            const uint4 r0 = *reinterpret_cast<const uint4*>(rp);
-            const uint4 r1 = *reinterpret_cast<const uint4*>(rp + 16);
-            p[0] = r0.x; p[1] = r0.y; p[2] = r0.z; p[3] = r0.w;
-            p[4] = r1.x; p[5] = r1.y; p[6] = r1.z; p[7] = r1.w;
+            p[0] = r0[r].x; p[1] = r0[r].y; p[2] = r0[r].z; p[3] = r0[r].w;
+            p[4] = r1[r].x; p[5] = r1[r].y; p[6] = r1[r].z; p[7] = r1[r].w;
+        }
+        const uint32_t bits = (mb[r] >> sh) & rm;
+        if (r == 3) {  // the candidate itself
+            const int q = x - bx;
+            centre_valid = (mb[r] >> (sh + q)) & 1u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j == q) pc = p[j];
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             // mm = mask && src < 2^24, standalone.cc:78,90
-            const bool inc = ((mb >> q) & 1u) && (sizeof(PixelT) == 2 || p[q] < (1u << 24));
-            if (inc) {
-                m += 1;
-                sx += p[q];
-                sy += (unsigned long long)p[q] * p[q];
-            }
+            const bool inc = ((bits >> q) & 1u) && (sizeof(PixelT) == 2 || p[q] < (1u << 24));
+            const uint32_t pv = inc ? p[q] : 0u;
+            m += inc ? 1u : 0u;
+            sx += pv;
+            sy += (unsigned long long)pv * pv;
         }
     }
 
     // :165  mask[k] && m >= min_count && x >= 0 && src[k] > threshold
     const double src = (double)pc;
-    if (!((int)m >= a.min_count && src > a.threshold)) return false;
+    if (!(centre_valid && (int)m >= a.min_count && src > a.threshold)) return false;
     if (a.max_valid >= 0 && (long long)pc > a.max_valid) return false;  // GPU reference only, thresholding.cu:208-215
     const double md = (double)m, xd = (double)sx, yd = (double)sy;
     // :166-170, each operation rounded separately (contraction is off for this library)
