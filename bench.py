@@ -51,6 +51,25 @@ def make_inputs(workload, n_unique, rank):
     return frames, mask
 
 
+def pmc_traffic(workload, batch):
+    """HBM bytes per launch of the candidate kernel from the newest committed rocprofv3 PMC summary
+    for this workload and batch (profiles/*pmc_threshold_<workload>_b<batch>.json, produced by
+    tools/summarize_pmc.py from separate FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2
+    correction on FETCH_SIZE).  None if no such profile exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_threshold_{workload}_b{batch}.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        for k, v in d.items():
+            if "k_candidates" in k and "hbm_bytes_per_launch" in v:
+                return int(v["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        pass
+    return None, None
+
+
 def cpu_baseline(frames, mask, budget_s=20.0):
     """Reference CPU path timed on this box's host cores: dispersion threshold by the
     reference's own standalone.cc when oracle/_ref is present (else our restatement), then the
@@ -77,7 +96,7 @@ def cpu_baseline(frames, mask, budget_s=20.0):
                 break
         return done
 
-    per = max(1, int(np.ceil(2 * len(frames) / cores / 2)))
+    per = 4  # frames per thread: ~16 x 4 x 0.35 s = 20-25 core-seconds
     jobs = [[(c * per + j) % len(frames) for j in range(per)] for c in range(cores)]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
@@ -134,27 +153,19 @@ def main():
     ptr = d_frames.data_ptr()
     streams = [ctx.stream() for _ in range(max(1, args.streams))]
 
+    from ffs_amd import dist as D
     gather_buf = None
+    spot_cap = 4096 * B
 
     def gather(results):
-        """one RCCL collective per batch: padded all_gather of (frame_id, x, y, z) per spot"""
+        """one RCCL collective per batch: padded all_gather of (frame_id, x, y, z) per spot
+        (ffs_amd/dist.py; the same code runs over gloo in tests/test_distributed_gloo.py)"""
         nonlocal gather_buf
         if dist is None:
             return
-        cap = 4096 * B
-        recs = np.zeros((cap, 4), np.float32)
-        n = 0
-        for r in results:
-            m = min(len(r.reflections), cap - n)
-            recs[n:n + m, 0] = r.frame_id
-            recs[n:n + m, 1] = r.reflections["com_x"][:m]
-            recs[n:n + m, 2] = r.reflections["com_y"][:m]
-            recs[n:n + m, 3] = r.reflections["com_z"][:m]
-            n += m
-        recs[-1, 0] = n
-        mine = torch.from_numpy(recs).to(dev, non_blocking=True)
+        mine = torch.from_numpy(D.pack_spots(results, spot_cap)).to(dev, non_blocking=True)
         if gather_buf is None:
-            gather_buf = torch.empty((world * cap, 4), dtype=torch.float32, device=dev)
+            gather_buf = torch.empty((world * (spot_cap + 1), 4), dtype=torch.float32, device=dev)
         dist.all_gather_into_tensor(gather_buf, mine)
 
     def run_steps(k):
@@ -202,6 +213,7 @@ def main():
     alg_bytes = float(W) * H * bytes_per_px * B
     achieved = alg_bytes / (ms_cand * 1e-3) / 1e9
     tm = streams[0].timings()
+    traffic, traffic_src = pmc_traffic(args.workload, B)
 
     out = None
     if rank == 0:
@@ -225,7 +237,8 @@ def main():
                        "frames_per_step_per_gpu": B, "streams": len(streams),
                        "spots_per_frame": round(spots / max(1, args.steps * B), 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": "k_candidates", "ms_per_launch": round(ms_cand, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "exact_kernel_ms_per_launch": round(ms_exact, 4)},

@@ -409,9 +409,9 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
     a.nsig_s = p.nsig_s;
     a.threshold = p.threshold;
     a.max_valid = p.max_valid;
-    {   // FFS_K1_VARIANT=0 selects the unscreened candidate kernel (A/B testing)
+    {   // FFS_K1_VARIANT=1 selects the group-screen candidate kernel (A/B testing)
         const char* v = std::getenv("FFS_K1_VARIANT");
-        a.variant = v ? std::atoi(v) : 1;
+        a.variant = v ? std::atoi(v) : 0;
     }
     return a;
 }
@@ -742,6 +742,28 @@ extern "C" int ffs_bench_threshold(ffs_stream* s, const void* device_pixels, siz
     HIP_TRY(c, hipEventElapsedTime(&t2, s->ev[1], s->ev[2]));
     if (ms_candidate) *ms_candidate = t1 / iters;
     if (ms_exact) *ms_exact = std::max(0.0f, (t2 - t1) / iters);
+    return FFS_OK;
+}
+
+__global__ void k_selftest_sqrt(unsigned long long begin, unsigned long long end, unsigned long long* out) {
+    unsigned long long acc = 0;
+    for (unsigned long long n = begin + blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; n < end;
+         n += (unsigned long long)gridDim.x * blockDim.x)
+        acc += (unsigned long long)__double_as_longlong(__builtin_sqrt((double)n));
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+extern "C" int ffs_selftest_sqrt(ffs_ctx* c, uint64_t begin, uint64_t end, uint64_t* sum_of_bits) {
+    if (!c || !sum_of_bits || end < begin) return FFS_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned long long* d = nullptr;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d), 8));
+    HIP_TRY(c, hipMemset(d, 0, 8));
+    hipLaunchKernelGGL(k_selftest_sqrt, dim3(2048), dim3(256), 0, 0, begin, end, d);
+    hipError_t e = hipMemcpy(sum_of_bits, d, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    HIP_TRY(c, e);
     return FFS_OK;
 }
 

@@ -70,7 +70,7 @@ EXPORTS = [
     "ffs_ctx_apply_resolution_mask", "ffs_ctx_get_mask", "ffs_ctx_set_params",
     "ffs_stream_create", "ffs_stream_destroy", "ffs_stream_host_buffer", "ffs_submit",
     "ffs_submit_device", "ffs_ctx_device_layout", "ffs_wait", "ffs_stream_batch_arrays", "ffs_stream_timings",
-    "ffs_bench_threshold", "ffs_stream_debug_planes", "ffs_stack3d_create",
+    "ffs_bench_threshold", "ffs_stream_debug_planes", "ffs_selftest_sqrt", "ffs_stack3d_create",
     "ffs_stack3d_destroy", "ffs_stack3d_add_batch", "ffs_stack3d_add_slice", "ffs_stack3d_finish",
 ]
 
@@ -109,6 +109,7 @@ def load_library():
                                           C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.ffs_stream_debug_planes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                               C.POINTER(C.c_size_t)]
+        L.ffs_selftest_sqrt.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
         L.ffs_device_name.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         L.ffs_device_total_mem.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
         L.ffs_stack3d_create.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
@@ -212,6 +213,11 @@ class Context:
                 raise AttributeError(k)
             setattr(self.params, k, v)
         self._check(self._lib.ffs_ctx_set_params(self._h, C.byref(self.params)))
+
+    def selftest_sqrt(self, begin: int, end: int) -> int:
+        out = C.c_uint64()
+        self._check(self._lib.ffs_selftest_sqrt(self._h, begin, end, C.byref(out)))
+        return out.value
 
     def device_layout(self):
         pitch, stride = C.c_size_t(), C.c_size_t()

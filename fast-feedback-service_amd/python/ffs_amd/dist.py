@@ -1,0 +1,102 @@
+"""Multi-GPU plumbing: one process per GPU, frames sharded over ranks, spot lists gathered.
+
+The reference has no distributed layer (one process, one GPU: src/ffs/cuda_arg_parser.cc:56-61);
+frames are independent units (spotfinder/spotfinder.cc:752), so the data path needs no collective.
+The only exchange is the gather of per-frame results:
+  * stills: (frame_id, x, y, z) per spot -> every rank (one collective per batch);
+  * rotation sweeps: each frame's strong-pixel list (k, intensity) -> the rank that owns the 3D
+    stack (ffs_stack3d_add_slice).
+Works on any torch.distributed backend: "nccl" (= RCCL over xGMI) with device tensors in bench.py,
+"gloo" with CPU tensors in the tests.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def frame_shard(n_frames: int, rank: int, world: int) -> list[int]:
+    """Frame i belongs to rank i mod world (static, deterministic partition of the frame queue)."""
+    return list(range(rank, n_frames, world))
+
+
+def pack_spots(results, cap: int) -> np.ndarray:
+    """(cap + 1, 4) float32: rows = (frame_id, com_x, com_y, com_z); last row holds the count."""
+    out = np.zeros((cap + 1, 4), np.float32)
+    n = 0
+    for r in results:
+        refl = r.reflections
+        m = min(len(refl), cap - n)
+        out[n:n + m, 0] = r.frame_id
+        out[n:n + m, 1] = refl["com_x"][:m]
+        out[n:n + m, 2] = refl["com_y"][:m]
+        out[n:n + m, 3] = refl["com_z"][:m]
+        n += m
+    out[cap, 0] = n
+    return out
+
+
+def unpack_spots(gathered: np.ndarray, world: int, cap: int):
+    """-> {frame_id: (n,3) float32 centres} merged over ranks, insertion in frame order."""
+    g = gathered.reshape(world, cap + 1, 4)
+    merged = {}
+    for r in range(world):
+        n = int(g[r, cap, 0])
+        rows = g[r, :n]
+        for fid in np.unique(rows[:, 0]):
+            merged[int(fid)] = rows[rows[:, 0] == fid, 1:4].copy()
+    return dict(sorted(merged.items()))
+
+
+def all_gather_fixed(t, group=None):
+    """One collective: every rank contributes a tensor of identical shape; returns the
+    concatenation along dim 0 (rank-major)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    return torch.cat(out, 0)
+
+
+def gather_strong_lists(slices: dict, device=None, group=None) -> dict:
+    """Variable-length gather of {frame_id: (k uint32, intensity uint32)} to every rank:
+    all_gather of counts, then one padded all_gather of the payload."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    ids = sorted(slices)
+    n_entries = sum(len(slices[i][0]) for i in ids)
+    meta = torch.tensor([len(ids), n_entries], dtype=torch.int64, device=device)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    max_ids = max(int(m[0]) for m in metas)
+    max_entries = max(int(m[1]) for m in metas)
+    # header: (frame_id, count) per slice; payload: k, intensity concatenated
+    head = np.zeros((max(max_ids, 1), 2), np.int64)
+    k = np.zeros(max(max_entries, 1), np.int64)
+    it = np.zeros(max(max_entries, 1), np.int64)
+    at = 0
+    for j, i in enumerate(ids):
+        kk, ii = slices[i]
+        head[j] = (i, len(kk))
+        k[at:at + len(kk)] = kk
+        it[at:at + len(kk)] = ii
+        at += len(kk)
+    payload = torch.from_numpy(np.concatenate([head.reshape(-1), k, it]))
+    if device is not None:
+        payload = payload.to(device)
+    outs = [torch.empty_like(payload) for _ in range(world)]
+    dist.all_gather(outs, payload, group=group)
+    merged = {}
+    hl = head.size
+    for r in range(world):
+        o = outs[r].cpu().numpy()
+        h = o[:hl].reshape(-1, 2)
+        kk = o[hl:hl + len(k)]
+        ii = o[hl + len(k):]
+        at = 0
+        for j in range(int(metas[r][0])):
+            fid, cnt = int(h[j, 0]), int(h[j, 1])
+            merged[fid] = (kk[at:at + cnt].astype(np.uint32), ii[at:at + cnt].astype(np.uint32))
+            at += cnt
+    return dict(sorted(merged.items()))

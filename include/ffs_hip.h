@@ -178,6 +178,13 @@ int ffs_bench_threshold(ffs_stream *s, const void *device_pixels, size_t pitch_b
 int ffs_stream_debug_planes(ffs_stream *s, const uint8_t **device_strong_bytes,
                             size_t *mask_pitch, size_t *mask_frame_stride);
 
+/* Known-answer self test of the one non-trivial fp64 operation the exact predicate relies on:
+ * sum (mod 2^64) of the bit patterns of sqrt((double)n) for integers n in [begin, end), computed on
+ * the device with the same code path k_exact uses.  The caller compares it with libm's correctly
+ * rounded sqrt (tests/test_gpu_numerics.py does, exhaustively for every n = x*m a uint16 frame
+ * can produce). */
+int ffs_selftest_sqrt(ffs_ctx *ctx, uint64_t begin, uint64_t end, uint64_t *sum_of_bits);
+
 /* ---- rotation sweeps: 3D connected components (replaces
  *      ConnectedComponents::find_3d_components, connected_components.cc:270-470) -------------- */
 int ffs_stack3d_create(ffs_ctx *ctx, uint64_t max_total_strong, ffs_stack3d **out);

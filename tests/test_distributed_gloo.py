@@ -1,0 +1,101 @@
+"""CPU, world_size 2, gloo: the N>1 path -- frame sharding and the spot-list gathers that
+bench.py runs over RCCL.  Strong pixels here come from the oracle (this is a test)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Fr:
+    def __init__(self, fid, refl):
+        self.frame_id, self.reflections = fid, refl
+
+
+def _sweep():
+    from ffs_amd import synth
+    W, H, NZ = 160, 120, 8
+    p = synth.sweep_params(seed=31, n_frames=NZ, n_spots=25, width=W, height=H)
+    return W, H, NZ, synth.frames(p, range(NZ), threads=2)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ffs_amd import dist as D
+        from oracle import oracle as O
+        W, H, NZ, frames = _sweep()
+        mask = np.ones((H, W), np.uint8)
+        mine = D.frame_shard(NZ, rank, world)
+        assert mine == list(range(rank, NZ, world))
+        results, slices = [], {}
+        for f in mine:
+            strong = O.dispersion(frames[f], mask)
+            cc = O.cc2d(strong, frames[f], 3)
+            refl = O.cc2d_reflections(cc.k, cc.intensity, W, H, 3, 2.0).reflections
+            results.append(_Fr(f, refl))
+            slices[f] = (cc.k.astype(np.uint32), cc.intensity)
+        cap = 256
+        packed = torch.from_numpy(D.pack_spots(results, cap))
+        gathered = D.all_gather_fixed(packed).numpy()
+        spots = D.unpack_spots(gathered, world, cap)
+        merged = D.gather_strong_lists(slices)
+        if rank == 0:
+            q.put((spots, merged))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gather_matches_single_process():
+    from oracle import oracle as O
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    spots, merged = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    W, H, NZ, frames = _sweep()
+    mask = np.ones((H, W), np.uint8)
+    assert list(spots) == [f for f in range(NZ) if f in spots] and list(merged) == list(range(NZ))
+    single = []
+    n_spots = 0
+    for f in range(NZ):
+        strong = O.dispersion(frames[f], mask)
+        cc = O.cc2d(strong, frames[f], 3)
+        np.testing.assert_array_equal(merged[f][0], cc.k.astype(np.uint32))
+        np.testing.assert_array_equal(merged[f][1], cc.intensity)
+        refl = O.cc2d_reflections(cc.k, cc.intensity, W, H, 3, 2.0).reflections
+        if len(refl):
+            want = np.stack([refl["com_x"], refl["com_y"], refl["com_z"]], 1)
+            np.testing.assert_array_equal(spots[f], want)
+            n_spots += len(refl)
+        single.append((cc.k, cc.intensity))
+    assert n_spots > 10
+    # the gathered lists drive the same 3D labelling as a single process would
+    a = O.cc3d([merged[f] for f in range(NZ)], W, H, 3, 2.0)
+    b = O.cc3d(single, W, H, 3, 2.0)
+    assert a.n_calculated == b.n_calculated and len(a.reflections) == len(b.reflections) > 0
+    np.testing.assert_array_equal(a.reflections, b.reflections)
+
+
+def test_frame_shard_partitions():
+    from ffs_amd import dist as D
+    for world in (1, 2, 3, 8):
+        got = sorted(sum((D.frame_shard(37, r, world) for r in range(world)), []))
+        assert got == list(range(37))
