@@ -29,7 +29,11 @@ $(PKG)/libffs_hip.so: $(HIP_SRCS) $(HIP_HDRS)
 
 CLI_SRCS := $(wildcard $(PKG)/host/*.cc)
 CLI_HDRS := $(wildcard $(PKG)/host/*.hpp) $(wildcard include/*.h)
-cli: $(PKG)/bin/spotfinder
+cli: $(PKG)/bin/spotfinder $(PKG)/bin/ffs_hosttool
+$(PKG)/bin/ffs_hosttool: $(PKG)/tools/ffs_hosttool.cc $(PKG)/host/readers.cc $(CLI_HDRS) $(PKG)/libffs_synth.so
+	mkdir -p $(PKG)/bin && $(CXX) -std=c++20 -O2 -Iinclude -I$(PKG)/host -o $@ $(PKG)/tools/ffs_hosttool.cc \
+	    $(PKG)/host/readers.cc -L$(PKG) -lffs_synth -Wl,-rpath,'$$ORIGIN/..'
+
 $(PKG)/bin/spotfinder: $(CLI_SRCS) $(CLI_HDRS) $(PKG)/libffs_hip.so $(PKG)/libffs_synth.so
 	@if [ -n "$(CLI_SRCS)" ]; then mkdir -p $(PKG)/bin && \
 	$(CXX) -std=c++20 -O2 -Iinclude -I$(PKG)/host -o $@ $(CLI_SRCS) \

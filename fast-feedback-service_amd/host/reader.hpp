@@ -1,0 +1,47 @@
+// reader.hpp -- frame-source plugin surface of the spotfinder driver.
+// Same shape as the reference's abstract `class Reader` (h5read/include/h5read.h:173-204) so
+// that its H5Read / SHMRead / CBFRead implementations map one to one; the only addition is
+// ChunkCompression::NONE for sources that hand over raw pixels (the synthetic reader).
+#pragma once
+#include <array>
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <optional>
+#include <span>
+#include <string>
+#include <vector>
+
+namespace ffshost {
+
+enum class PixelDType { UINT16, UINT32 };  // h5read_dtype subset the driver accepts (h5read.h:22-32)
+
+class Reader {
+  public:
+    enum ChunkCompression { BITSHUFFLE_LZ4, BYTE_OFFSET_32, NONE };
+    virtual ~Reader() = default;
+    virtual bool is_image_available(size_t index) = 0;
+    virtual std::span<uint8_t> get_raw_chunk(size_t index, std::span<uint8_t> destination) = 0;
+    virtual ChunkCompression get_raw_chunk_compression() = 0;
+    virtual size_t get_number_of_images() const = 0;
+    size_t get_element_size() const { return get_dtype() == PixelDType::UINT16 ? 2 : 4; }
+    virtual PixelDType get_dtype() const = 0;
+    virtual std::array<int64_t, 2> get_trusted_range() const = 0;
+    virtual std::array<size_t, 2> image_shape() const = 0;  // (slow, fast)
+    virtual std::optional<std::span<const uint8_t>> get_mask() const = 0;  // 1 = valid
+    virtual std::optional<float> get_wavelength() const = 0;
+    virtual std::optional<std::array<float, 2>> get_pixel_size() const = 0;   // (y, x) m
+    virtual std::optional<std::array<float, 2>> get_beam_center() const = 0;  // (y, x) px
+    virtual std::optional<float> get_detector_distance() const = 0;           // m
+    virtual std::array<float, 2> get_oscillation() const = 0;                 // (start, width) deg
+};
+
+// spotfinder <file>: directory -> SHMRead, *.cbf -> CBFRead, "synth:..." -> SynthRead,
+// anything else -> H5Read (spotfinder/spotfinder.cc:443-465)
+std::unique_ptr<Reader> make_synth_reader(const std::string& spec);
+std::unique_ptr<Reader> make_cbf_reader(const std::string& templ, size_t num_images, size_t first_index);
+std::unique_ptr<Reader> make_shm_reader(const std::string& dir);
+bool shm_ready_for_read(const std::string& dir);
+bool cbf_ready_for_read(const std::string& templ);
+
+}  // namespace ffshost

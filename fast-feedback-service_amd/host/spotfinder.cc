@@ -1,0 +1,658 @@
+// spotfinder.cc -- the `spotfinder` driver for libffs_hip.so: same command line, stdout phrases,
+// --pipe_fd JSON lines, output files and exit codes as the reference's spotfinder/spotfinder.cc
+// (flags :291-398, JSON :997-1008, per-image lines :1055-1087, 3D stage :1101-1148, summary
+// :1308-1329), rebuilt around batches: every worker thread owns one ffs_stream, pulls a run of
+// frame numbers from the shared counter (the reference pulls one, :752), decodes them into the
+// stream's pinned buffer and submits the batch.  All device work goes through include/ffs_hip.h.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <csignal>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <unistd.h>
+#include <vector>
+
+#include "codecs.hpp"
+#include "ffs_hip.h"
+#include "minijson.hpp"
+#include "reader.hpp"
+
+using namespace ffshost;
+using namespace std::chrono_literals;
+namespace fs = std::filesystem;
+
+#ifndef FFS_VERSION
+#define FFS_VERSION "ffs-mi355x 0.1 (gfx950)"
+#endif
+
+static std::atomic<bool> g_stop{false};
+extern "C" void stop_processing(int) {  // spotfinder.cc:43-54
+    if (g_stop.load()) std::_Exit(1);
+    static const char msg[] = "Running interrupted by user request\n";
+    (void)!write(STDOUT_FILENO, msg, sizeof msg - 1);
+    g_stop.store(true);
+}
+
+// ---- arguments (spotfinder.cc:291-398, src/ffs/arg_parser.cc, src/ffs/cuda_arg_parser.cc) ---------
+struct Args {
+    std::string file;
+    bool sample = false, validate = false, writeout = false, save_h5 = false, output_for_index = false;
+    bool verbose = false, strict_dtype = false;
+    uint32_t threads = 1, images = 0, min_spot_size = 3, min_spot_size_3d = 3, start_index = 0, batch = 0;
+    bool images_set = false, wavelength_set = false, detector_set = false;
+    float max_sep = 2.0f, timeout = 30.0f, dmin = -1.f, dmax = -1.f, wavelength = 0.f;
+    int pipe_fd = -1, device = 0;
+    std::string algorithm = "dispersion", detector_json;
+};
+
+static void usage() {
+    std::printf(
+      "Usage: spotfinder [-h] [--version] [-v] [-d DEVICE] [--list-devices] [--sample | FILE.nxs]\n"
+      "                  [-n NUM] [--validate] [--images NUM] [--writeout] [--min-spot-size N]\n"
+      "                  [--min-spot-size-3d N] [--max-peak-centroid-separation N] [--start-index N]\n"
+      "                  [-t S] [-fd FD] [-a ALGO] [--dmin MIN D] [--dmax MAX D] [-w \xce\xbb] [--detector JSON]\n"
+      "                  [-h5] [--output-for-index] [--batch N]\n"
+      "FILE: NXmx .nxs/.h5 (needs an HDF5 build), a /dev/shm directory, a ####.cbf template, or\n"
+      "      synth:<eiger16m|jungfrau9m|plumbing1k|sweep16m|tiny|tinysweep>[:n_images[:seed]]\n");
+}
+
+[[noreturn]] static void arg_error(const std::string& m) {  // arg_parser.cc:72-77
+    std::printf("Error: %s\n", m.c_str());
+    usage();
+    std::exit(1);
+}
+
+static void list_devices() {  // cuda_arg_parser.cc:39-53
+    const int n = ffs_device_count();
+    for (int i = 0; i < n; ++i) {
+        char name[256];
+        ffs_device_name(i, name, sizeof name);
+        std::printf("%d: %s\n", i, name);
+    }
+    std::exit(0);
+}
+
+static Args parse_args(int argc, char** argv) {
+    std::vector<std::string> a(argv + 1, argv + argc);
+    if (fs::exists("common.args")) {  // arg_parser.cc:57-71
+        std::ifstream f("common.args");
+        std::string line;
+        while (std::getline(f, line))
+            if (!line.empty() && std::find(a.begin(), a.end(), line) == a.end()) a.push_back(line);
+    }
+    Args r;
+    if (const char* e = std::getenv("SPOTFINDER_TIMEOUT")) {  // spotfinder.cc:293-301
+        try { r.timeout = std::stof(e); } catch (...) { std::printf("Ignoring invalid SPOTFINDER_TIMEOUT value: %s\n", e); }
+    }
+    auto need = [&](size_t& i, const std::string& flag) -> const std::string& {
+        if (i + 1 >= a.size()) arg_error("Too few arguments for '" + flag + "'.");
+        return a[++i];
+    };
+    auto u32 = [&](const std::string& v, const std::string& flag) {
+        try { size_t used; long long x = std::stoll(v, &used); if (used != v.size() || x < 0) throw 1; return (uint32_t)x; }
+        catch (...) { arg_error("pattern not found for '" + flag + "': " + v); }
+    };
+    auto f32 = [&](const std::string& v, const std::string& flag) {
+        try { size_t used; float x = std::stof(v, &used); if (used != v.size()) throw 1; return x; }
+        catch (...) { arg_error("pattern not found for '" + flag + "': " + v); }
+    };
+    for (size_t i = 0; i < a.size(); ++i) {
+        const std::string& s = a[i];
+        if (s == "-h" || s == "--help") { usage(); std::exit(0); }
+        else if (s == "--version") { std::printf("%s\n", FFS_VERSION); std::exit(0); }
+        else if (s == "-v" || s == "--verbose") r.verbose = true;
+        else if (s == "--list-devices") list_devices();
+        else if (s == "-d" || s == "--device") r.device = (int)u32(need(i, s), s);
+        else if (s == "--sample") r.sample = true;
+        else if (s == "-n" || s == "--threads") r.threads = u32(need(i, s), s);
+        else if (s == "--validate") r.validate = true;
+        else if (s == "--images") { r.images = u32(need(i, s), s); r.images_set = true; }
+        else if (s == "--writeout") r.writeout = true;
+        else if (s == "--min-spot-size") r.min_spot_size = u32(need(i, s), s);
+        else if (s == "--min-spot-size-3d") r.min_spot_size_3d = u32(need(i, s), s);
+        else if (s == "--max-peak-centroid-separation") r.max_sep = f32(need(i, s), s);
+        else if (s == "--start-index") r.start_index = u32(need(i, s), s);
+        else if (s == "-t" || s == "--timeout") r.timeout = f32(need(i, s), s);
+        else if (s == "-fd" || s == "--pipe_fd") r.pipe_fd = std::stoi(need(i, s));
+        else if (s == "-a" || s == "--algorithm") r.algorithm = need(i, s);
+        else if (s == "--dmin") r.dmin = f32(need(i, s), s);
+        else if (s == "--dmax") r.dmax = f32(need(i, s), s);
+        else if (s == "-w" || s == "--wavelength" || s == "-\xce\xbb") { r.wavelength = f32(need(i, s), s); r.wavelength_set = true; }
+        else if (s == "--detector") { r.detector_json = need(i, s); r.detector_set = true; }
+        else if (s == "-h5" || s == "--save-h5") r.save_h5 = true;
+        else if (s == "--output-for-index") r.output_for_index = true;
+        else if (s == "--batch") r.batch = u32(need(i, s), s);
+        else if (s == "--strict-dtype") r.strict_dtype = true;
+        else if (!s.empty() && s[0] == '-' && s.size() > 1) arg_error("Unknown argument: " + s);
+        else if (r.file.empty()) r.file = s;
+        else arg_error("Maximum number of positional arguments exceeded");
+    }
+    const bool implicit_sample = std::getenv("H5READ_IMPLICIT_SAMPLE") != nullptr;  // spotfinder.cc:268-283
+    if (r.sample && !r.file.empty()) arg_error("Argument 'FILE.nxs' not allowed with '--sample'");
+    if (!r.sample && r.file.empty() && !implicit_sample) arg_error("One of the arguments '--sample' or 'FILE.nxs' is required");
+    if (r.file.empty()) r.sample = true;
+    return r;
+}
+
+struct DetectorGeometry {  // spotfinder/kernels/masking.cuh:16-80
+    float pixel_size_x = 0, pixel_size_y = 0, beam_center_x = 0, beam_center_y = 0, distance = 0;
+};
+
+static DetectorGeometry detector_from_json(const std::string& text) {
+    const JsonValue j = JsonParser(text).parse();
+    for (const char* k : {"pixel_size_x", "pixel_size_y", "beam_center_x", "beam_center_y", "distance"})
+        (void)j.at(k);  // throws "Key ... is missing from the input JSON"
+    DetectorGeometry d;
+    d.pixel_size_x = (float)j.at("pixel_size_x").number() / 1000.0f;  // mm -> m
+    d.pixel_size_y = (float)j.at("pixel_size_y").number() / 1000.0f;
+    d.beam_center_x = (float)j.at("beam_center_x").number() / (d.pixel_size_x * 1000);  // mm -> px
+    d.beam_center_y = (float)j.at("beam_center_y").number() / (d.pixel_size_y * 1000);
+    d.distance = (float)j.at("distance").number() / 1000.0f;
+    return d;
+}
+
+// thread-safe writer of JSON lines to the inherited pipe (PipeHandler, spotfinder.cc:208-255)
+class PipeHandler {
+    int fd_;
+    std::mutex m_;
+  public:
+    explicit PipeHandler(int fd) : fd_(fd) { std::printf("PipeHandler initialized with pipe_fd: %d\n", fd); }
+    ~PipeHandler() { close(fd_); }
+    void send(const std::string& line) {
+        std::lock_guard<std::mutex> lock(m_);
+        const std::string s = line + "\n";
+        if (write(fd_, s.c_str(), s.size()) == -1) std::cerr << "Error writing to pipe: " << std::strerror(errno) << std::endl;
+    }
+};
+
+// minimal PNG (stored deflate blocks) for --writeout, in place of lodepng
+static void write_png_rgb(const std::string& path, const uint8_t* rgb, uint32_t w, uint32_t h) {
+    auto crc32 = [](const uint8_t* d, size_t n, uint32_t c) {
+        static uint32_t table[256];
+        static bool init = false;
+        if (!init) {
+            for (uint32_t i = 0; i < 256; ++i) {
+                uint32_t k = i;
+                for (int j = 0; j < 8; ++j) k = (k & 1) ? 0xEDB88320u ^ (k >> 1) : k >> 1;
+                table[i] = k;
+            }
+            init = true;
+        }
+        c = ~c;
+        for (size_t i = 0; i < n; ++i) c = table[(c ^ d[i]) & 255] ^ (c >> 8);
+        return ~c;
+    };
+    std::ofstream f(path, std::ios::binary);
+    auto be32 = [](uint32_t v, uint8_t* o) { o[0] = v >> 24; o[1] = v >> 16; o[2] = v >> 8; o[3] = v; };
+    auto chunk = [&](const char* type, const std::vector<uint8_t>& data) {
+        uint8_t len[4];
+        be32((uint32_t)data.size(), len);
+        f.write((const char*)len, 4);
+        std::vector<uint8_t> td(type, type + 4);
+        td.insert(td.end(), data.begin(), data.end());
+        f.write((const char*)td.data(), (std::streamsize)td.size());
+        uint8_t c[4];
+        be32(crc32(td.data(), td.size(), 0), c);
+        f.write((const char*)c, 4);
+    };
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    f.write((const char*)sig, 8);
+    std::vector<uint8_t> ihdr(13);
+    be32(w, &ihdr[0]);
+    be32(h, &ihdr[4]);
+    ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+    chunk("IHDR", ihdr);
+    std::vector<uint8_t> raw;
+    raw.reserve((size_t)h * (3 * w + 1));
+    for (uint32_t y = 0; y < h; ++y) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgb + (size_t)y * w * 3, rgb + (size_t)(y + 1) * w * 3);
+    }
+    std::vector<uint8_t> z = {0x78, 0x01};
+    uint32_t a = 1, b = 0;
+    for (size_t off = 0; off < raw.size();) {
+        const size_t n = std::min<size_t>(65535, raw.size() - off);
+        z.push_back(off + n == raw.size() ? 1 : 0);
+        z.push_back(n & 255); z.push_back(n >> 8); z.push_back(~n & 255); z.push_back((~n >> 8) & 255);
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+        for (size_t i = 0; i < n; ++i) { a = (a + raw[off + i]) % 65521; b = (b + a) % 65521; }
+        off += n;
+    }
+    uint8_t ad[4];
+    be32((b << 16) | a, ad);
+    z.insert(z.end(), ad, ad + 4);
+    chunk("IDAT", z);
+    chunk("IEND", {});
+}
+
+static void write_mask_png(const std::string& path, const uint8_t* mask, uint32_t w, uint32_t h) {
+    std::vector<uint8_t> img((size_t)w * h * 3, 255);  // spotfinder.cc:627-645
+    for (size_t k = 0; k < (size_t)w * h; ++k)
+        if (!mask[k]) { img[3 * k + 1] = 0; img[3 * k + 2] = 0; }
+    write_png_rgb(path, img.data(), w, h);
+}
+
+template <typename T>
+static std::string fmt_num(T v) { std::ostringstream o; o << v; return o.str(); }  // iostream default, :1138-1147
+
+#define FFS_CHECK(ctx, expr)                                                       \
+    do {                                                                           \
+        if ((expr) != FFS_OK) {                                                    \
+            std::printf("Error: %s\n", ffs_last_error(ctx));                       \
+            std::exit(1);                                                          \
+        }                                                                          \
+    } while (0)
+
+int main(int argc, char** argv) {
+    std::printf("Spotfinder version: %s\n", FFS_VERSION);
+    Args args = parse_args(argc, argv);
+    const std::string file = args.file;
+
+    {  // DispersionAlgorithm, spotfinder.cc:180-203
+        std::string lower = args.algorithm;
+        std::transform(lower.begin(), lower.end(), lower.begin(), ::tolower);
+        if (lower == "dispersion") std::printf("Algorithm: Dispersion\n");
+        else if (lower == "dispersion_extended") {
+            std::printf("Algorithm: Dispersion Extended\n");
+            std::printf("Error: the extended dispersion algorithm is not part of this build\n");
+            return 1;
+        } else {
+            std::printf("Error: Invalid algorithm specified\n");
+            return 1;
+        }
+    }
+    if (args.threads < 1) {
+        std::printf("Error: Thread count must be >= 1\n");
+        return 1;
+    }
+    if (ffs_device_count() < 1) {  // cuda_arg_parser.cc:56-61
+        std::printf("\033[1;31mError: Could not select GPU device\033[0m\n");
+        return 1;
+    }
+    {
+        char name[256];
+        if (ffs_device_name(args.device, name, sizeof name) != FFS_OK) {
+            std::printf("\033[1;31mError: Could not select GPU device\033[0m\n");
+            return 1;
+        }
+        std::printf("Using %s\n", name);
+    }
+
+    // ---- choose the reader (spotfinder.cc:438-466) ------------------------------------------------
+    std::unique_ptr<Reader> reader_ptr;
+    auto wait_ready = [&](const std::string& path, auto checker) {  // wait_for_ready_for_read, :137-175
+        const auto t0 = std::chrono::steady_clock::now();
+        bool waited = false;
+        while (!checker(path)) {
+            const double w = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::printf("\rWaiting for \033[1;35m%s\033[0m to be ready for read [%4.1f s] ", path.c_str(), w);
+            std::fflush(stdout);
+            waited = true;
+            if (w > args.timeout) {
+                std::printf("\nError: Waited too long for read availability\n");
+                std::exit(1);
+            }
+            std::this_thread::sleep_for(80ms);
+        }
+        if (waited) std::printf("\n");
+    };
+    try {
+        if (args.sample || file.rfind("synth:", 0) == 0) {
+            reader_ptr = make_synth_reader(args.sample ? "synth:eiger16m:6" : file);
+        } else {
+            if (!fs::exists(file) && file.find('#') == std::string::npos)
+                wait_ready(file, [](const std::string& s) { return fs::exists(s); });
+            if (fs::is_directory(file)) {
+                wait_ready(file, shm_ready_for_read);
+                reader_ptr = make_shm_reader(file);
+            } else if (file.size() > 4 && file.compare(file.size() - 4, 4, ".cbf") == 0) {
+                if (!args.images_set) {
+                    std::printf("Error: CBF reading must specify --images\n");
+                    return 1;
+                }
+                reader_ptr = make_cbf_reader(file, args.images, args.start_index);
+            } else {
+                std::printf("Error: HDF5/NeXus input needs an HDF5-enabled build; this build reads /dev/shm "
+                            "directories, ####.cbf templates and synth: sources\n");
+                return 1;
+            }
+        }
+    } catch (const std::exception& e) {
+        std::printf("Error: %s\n", e.what());
+        return 1;
+    }
+    Reader& reader = *reader_ptr;
+    std::mutex reader_mutex;
+
+    const size_t bytes_per_pixel = reader.get_element_size();
+    {
+        // The reference builds one binary per pixel width and exits with the data's bit depth on a
+        // mismatch (spotfinder.cc:468-476) so that the service relaunches spotfinder32
+        // (service.py:503-507).  This binary handles both widths; --strict-dtype (or being invoked
+        // as spotfinder / spotfinder32 with FFS_STRICT_DTYPE set) restores the exit-code protocol.
+        const std::string self = fs::path(argv[0]).filename().string();
+        const size_t expect = self == "spotfinder32" ? 4 : 2;
+        if ((args.strict_dtype || std::getenv("FFS_STRICT_DTYPE")) && bytes_per_pixel != expect) {
+            std::printf("Error: Data type mismatch; This executable only accepts %zu bit != %zu\n", expect * 8,
+                        bytes_per_pixel * 8);
+            return (int)(bytes_per_pixel * 8);
+        }
+    }
+    const uint32_t num_images = args.images_set ? args.images : (uint32_t)reader.get_number_of_images();
+    const uint32_t height = (uint32_t)reader.image_shape()[0], width = (uint32_t)reader.image_shape()[1];
+    const int64_t trusted_px_max = reader.get_trusted_range()[1];
+    (void)trusted_px_max;
+
+    // ---- detector geometry / wavelength (spotfinder.cc:484-587) -----------------------------------
+    DetectorGeometry detector;
+    if (args.detector_set) {
+        try {
+            detector = detector_from_json(args.detector_json);
+        } catch (const std::exception& e) {
+            std::printf("Error: %s\n", e.what());
+            return 1;
+        }
+    } else {
+        const auto bc = reader.get_beam_center();
+        const auto ps = reader.get_pixel_size();
+        const auto dd = reader.get_detector_distance();
+        if (!bc) { std::printf("Error: No beam center available from file. Please pass detector metadata with --distance.\n"); return 1; }
+        if (!ps) { std::printf("Error: No pixel size available from file. Please pass detector metadata with --distance.\n"); return 1; }
+        if (!dd) { std::printf("Error: No detector distance available from file. Please pass metadata with --distance.\n"); return 1; }
+        detector.distance = *dd;
+        detector.beam_center_x = (*bc)[1];
+        detector.beam_center_y = (*bc)[0];
+        detector.pixel_size_x = (*ps)[1];
+        detector.pixel_size_y = (*ps)[0];
+    }
+    float wavelength;
+    if (args.wavelength_set) {
+        wavelength = args.wavelength;
+    } else {
+        const auto w = reader.get_wavelength();
+        if (!w) {
+            std::printf("Error: No wavelength provided. Please pass wavelength using: --wavelength\n");
+            return 1;
+        }
+        wavelength = *w;
+        std::printf("Got wavelength from file: %f \xc3\x85\n", wavelength);
+    }
+    std::printf("Detector geometry:\n    Distance:    %.1f mm\n    Beam Center: %.1f px %.1f px\nBeam Wavelength: %.2f \xc3\x85\n",
+                detector.distance * 1000, detector.beam_center_x, detector.beam_center_y, wavelength);
+    const auto [oscillation_start, oscillation_width] = reader.get_oscillation();
+    if (oscillation_width > 0)
+        std::printf("Oscillation:  Start: %.2f\xc2\xb0  Width: %.2f\xc2\xb0\n", oscillation_start, oscillation_width);
+
+    std::signal(SIGINT, stop_processing);
+
+    // ---- device context -------------------------------------------------------------------------------
+    const uint32_t batch = args.batch ? args.batch : std::max<uint32_t>(1, std::min<uint32_t>(8, num_images / std::max(1u, args.threads)));
+    std::printf("Image:       %4u x %4u = %u px\n", width, height, width * height);
+    std::printf("GPU batches: %u frames per submit, one stream per CPU thread\n", batch);
+    std::printf("Running with %u CPU threads\n", args.threads);
+
+    ffs_ctx* ctx = nullptr;
+    if (ffs_ctx_create(args.device, width, height, (int)bytes_per_pixel, batch, 0, &ctx) != FFS_OK) {
+        std::printf("Error: %s\n", ffs_last_error(nullptr));
+        return 1;
+    }
+    {  // upload_mask, spotfinder.cc:61-108
+        size_t valid = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (reader.get_mask()) {
+            for (uint8_t v : *reader.get_mask()) valid += v != 0;
+            FFS_CHECK(ctx, ffs_ctx_set_mask(ctx, reader.get_mask()->data()));
+        } else {
+            valid = (size_t)width * height;
+            FFS_CHECK(ctx, ffs_ctx_set_mask(ctx, nullptr));
+        }
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("Uploaded mask (%.2f Mpx) in %.2f ms (%.1f GBps)\n", valid / 1e6, ms,
+                    (double)width * height / (ms * 1e-3) / 1e9);
+    }
+    if (args.writeout && reader.get_mask()) write_mask_png("mask_source.png", reader.get_mask()->data(), width, height);
+    if (args.dmin > 0 || args.dmax > 0) {  // spotfinder.cc:648-683
+        FFS_CHECK(ctx, ffs_ctx_apply_resolution_mask(ctx, wavelength, detector.distance, detector.beam_center_x,
+                                                     detector.beam_center_y, detector.pixel_size_x,
+                                                     detector.pixel_size_y, args.dmin, args.dmax));
+        if (args.writeout) {
+            std::vector<uint8_t> m((size_t)width * height);
+            FFS_CHECK(ctx, ffs_ctx_get_mask(ctx, m.data()));
+            write_mask_png("mask_calculated.png", m.data(), width, height);
+        }
+    }
+    const bool rotation = oscillation_width > 0;
+    ffs_params prm;
+    ffs_default_params(&prm);
+    prm.min_spot_size = args.min_spot_size;
+    prm.min_spot_size_3d = args.min_spot_size_3d;
+    prm.max_peak_centroid_separation = args.max_sep;
+    prm.want_reflections = (!rotation && (args.save_h5 || args.output_for_index)) ? 1 : 0;
+    prm.want_strong_mask = args.writeout ? 1 : 0;
+    FFS_CHECK(ctx, ffs_ctx_set_params(ctx, &prm));
+    if (args.validate)
+        std::printf("Note: --validate is not linked into this build (the CPU baseline is test infrastructure: "
+                    "run `pytest -m gpu`, which compares every stage with it)\n");
+    if (args.save_h5)
+        std::printf("Note: results_ffs.h5 output needs the dx2/HDF5 reflection-table writer, which is not part "
+                    "of this build\n");
+
+    std::printf("Dataset type: %s\n", rotation ? "Rotation set" : "Still set");
+    ffs_stack3d* stack = nullptr;
+    std::mutex stack_mutex, print_mutex;
+    if (rotation) FFS_CHECK(ctx, ffs_stack3d_create(ctx, 0, &stack));
+
+    std::unique_ptr<PipeHandler> pipe;
+    if (args.pipe_fd != -1) pipe = std::make_unique<PipeHandler>(args.pipe_fd);
+
+    const auto all_start = std::chrono::steady_clock::now();
+    std::atomic<uint32_t> next_image{0};
+    std::atomic<uint32_t> completed{0};
+    double time_waiting = 0.0;
+    std::atomic<int> failed{0};
+
+    auto worker = [&](int thread_id) {
+        ffs_stream* s = nullptr;
+        if (ffs_stream_create(ctx, &s) != FFS_OK) {
+            std::printf("Error: %s\n", ffs_last_error(ctx));
+            failed = 1;
+            return;
+        }
+        void* host_v = nullptr;
+        size_t host_bytes = 0;
+        ffs_stream_host_buffer(s, &host_v, &host_bytes);
+        uint8_t* host = static_cast<uint8_t*>(host_v);
+        const size_t frame_bytes = (size_t)width * height * bytes_per_pixel;
+        std::vector<uint8_t> raw(frame_bytes * (bytes_per_pixel == 2 ? 2 : 1) + 4096);
+        auto last_received = std::chrono::steady_clock::now();
+        while (!g_stop.load() && !failed.load()) {
+            const uint32_t first = next_image.fetch_add(batch);  // a run of frames instead of one (:752)
+            if (first >= num_images) break;
+            const uint32_t n = std::min(batch, num_images - first);
+            uint32_t got = 0;
+            for (; got < n && !g_stop.load(); ++got) {
+                const uint32_t image_num = first + got;
+                const uint32_t offset_image_num = image_num + args.start_index;  // :756
+                std::span<uint8_t> chunk;
+                {
+                    std::scoped_lock lock(reader_mutex);  // readers are not thread-safe (:763-765)
+                    const auto w0 = std::chrono::steady_clock::now();
+                    while (!reader.is_image_available(offset_image_num) && !g_stop.load()) {
+                        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - last_received).count();
+                        if (waited > args.timeout) {  // :776-787
+                            std::printf("Timeout waiting for image %u\n", offset_image_num);
+                            g_stop.store(true);
+                            break;
+                        }
+                        std::this_thread::sleep_for(100ms);
+                    }
+                    if (g_stop.load()) break;
+                    last_received = std::chrono::steady_clock::now();
+                    time_waiting += std::chrono::duration<double>(last_received - w0).count();
+                    for (;;) {  // zero-length reads on /dev/shm: retry (:805-821)
+                        chunk = reader.get_raw_chunk(offset_image_num, raw);
+                        if (chunk.size() != 0) break;
+                        std::printf("\033[1mRace Condition?!?? Got buffer size 0 for image %u. Sleeping.\033[0m\n", image_num);
+                        std::this_thread::sleep_for(100ms);
+                    }
+                }
+                uint8_t* dst = host + (size_t)got * frame_bytes;  // decode outside the lock (:823-842)
+                switch (reader.get_raw_chunk_compression()) {
+                case Reader::BITSHUFFLE_LZ4:
+                    if (chunk.size() < 12 || bshuf_decompress_lz4(chunk.data() + 12, chunk.size() - 12, dst, (size_t)width * height, bytes_per_pixel) < 0) {
+                        std::printf("Error: corrupt bitshuffle-LZ4 chunk for image %u\n", image_num);
+                        failed = 1;
+                    }
+                    break;
+                case Reader::BYTE_OFFSET_32:
+                    if (bytes_per_pixel == 2) byte_offset_decompress(chunk.data(), chunk.size(), reinterpret_cast<uint16_t*>(dst), (size_t)width * height);
+                    else byte_offset_decompress(chunk.data(), chunk.size(), reinterpret_cast<uint32_t*>(dst), (size_t)width * height);
+                    break;
+                case Reader::NONE:
+                    std::memcpy(dst, chunk.data(), std::min(chunk.size(), frame_bytes));
+                    break;
+                }
+            }
+            if (got == 0 || failed.load()) break;
+            const ffs_frame_result* res = nullptr;
+            uint32_t nres = 0;
+            if (ffs_submit(s, host, got, first) != FFS_OK || ffs_wait(s, &res, &nres) != FFS_OK) {
+                std::printf("Error: %s\n", ffs_last_error(ctx));
+                failed = 1;
+                break;
+            }
+            float tm[5] = {0};
+            ffs_stream_timings(s, tm);
+            if (rotation) {
+                // key = image number read (rotation_slices[offset_image_num], :913-918)
+                std::lock_guard<std::mutex> lock(stack_mutex);
+                if (ffs_stack3d_add_batch(stack, s) != FFS_OK) { std::printf("Error: %s\n", ffs_last_error(ctx)); failed = 1; break; }
+            }
+            for (uint32_t i = 0; i < nres; ++i) {
+                const ffs_frame_result& r = res[i];
+                const uint32_t image_num = (uint32_t)r.frame_id;
+                if (args.writeout && r.strong_mask) {  // :937-994
+                    const uint8_t* px = host + (size_t)i * frame_bytes;
+                    std::vector<uint8_t> img((size_t)width * height * 3);
+                    for (size_t k = 0; k < (size_t)width * height; ++k) {
+                        const float v = bytes_per_pixel == 2 ? (float)reinterpret_cast<const uint16_t*>(px)[k]
+                                                             : (float)reinterpret_cast<const uint32_t*>(px)[k];
+                        const uint8_t g = (uint8_t)std::max(0.0f, 255.99f - v * 10);
+                        img[3 * k] = img[3 * k + 1] = img[3 * k + 2] = g;
+                    }
+                    auto put = [&](long x, long y) {
+                        if (x >= 0 && y >= 0 && x < (long)width && y < (long)height) {
+                            const size_t k = (size_t)y * width + x;
+                            img[3 * k] = 0; img[3 * k + 1] = 0; img[3 * k + 2] = 255;
+                        }
+                    };
+                    for (uint32_t bi = 0; bi < r.n_boxes; ++bi) {
+                        const ffs_box& b = r.boxes[bi];
+                        for (int e = 5; e <= 7; ++e) {
+                            for (long x = (long)b.l - e; x <= (long)b.r + e; ++x) { put(x, (long)b.t - e); put(x, (long)b.b + e); }
+                            for (long y = (long)b.t - e; y <= (long)b.b + e; ++y) { put((long)b.l - e, y); put((long)b.r + e, y); }
+                        }
+                    }
+                    char name[64];
+                    std::snprintf(name, sizeof name, "pixels_%05u.txt", image_num);
+                    std::ofstream out(name);
+                    for (uint32_t y = 0, k = 0; y < height; ++y)
+                        for (uint32_t x = 0; x < width; ++x, ++k)
+                            if (r.strong_mask[k]) {
+                                img[3 * k] = 255; img[3 * k + 1] = 0; img[3 * k + 2] = 0;
+                                char line[32];
+                                std::snprintf(line, sizeof line, "%4u, %4u\n", x, y);
+                                out << line;
+                            }
+                    std::snprintf(name, sizeof name, "image_%05u.png", image_num);
+                    write_png_rgb(name, img.data(), width, height);
+                }
+                if (pipe) {  // keys in alphabetical order, as nlohmann dumps them (:997-1008)
+                    std::string j = "{\"file\":" + json_escape(file) + ",\"file-number\":" + std::to_string(image_num)
+                                    + ",\"n_spots_total\":" + std::to_string(r.n_boxes)
+                                    + ",\"num_strong_pixels\":" + std::to_string(r.num_strong_pixels);
+                    if (args.output_for_index) {
+                        j += ",\"spot_centers\":[";
+                        for (uint32_t q = 0; q < r.n_reflections; ++q) {
+                            if (q) j += ",";
+                            j += json_number(r.reflections[q].com_x) + "," + json_number(r.reflections[q].com_y) + ","
+                                 + json_number(r.reflections[q].com_z);
+                        }
+                        j += "]";
+                    }
+                    pipe->send(j + "}");
+                }
+                std::lock_guard<std::mutex> lock(print_mutex);
+                std::printf("Extracted %u spots\n", r.n_components);  // connected_components.cc:119
+                if (prm.min_spot_size > 0)
+                    std::printf("Removed %u spots with size < %u pixels\n", r.n_components - r.n_boxes, prm.min_spot_size);
+                if (prm.want_reflections && r.n_filtered_sep > 0)
+                    std::printf("Filtered %u spots with peak-centroid distance > %s\n", r.n_filtered_sep, fmt_num(prm.max_peak_centroid_separation).c_str());
+                if (args.threads == 1) {  // :1056-1076 (timings are per batch here)
+                    std::printf("Thread %2d finished image %4u\n       Copy: %5.1f ms\n     Kernel: %5.1f ms\n  Post Copy: %5.1f ms\n"
+                                "       Post: %5.1f ms\n             \xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\n"
+                                "     Total:  %5.1f ms (%.1f GBps)\n    %u strong pixels\n    %u filtered reflections (%u pixels)\n",
+                                thread_id, image_num, tm[0] / nres, tm[1] / nres, tm[3] / nres, tm[2] / nres, tm[4] / nres,
+                                (double)frame_bytes * nres / (tm[4] * 1e-3) / 1e9, r.num_strong_pixels, r.n_boxes,
+                                r.num_strong_pixels_filtered);
+                } else {  // :1078-1085
+                    std::printf("Thread %2d finished image %4u with %5u strong pixels, %4u filtered reflections (%u pixels)\n",
+                                thread_id, image_num, r.num_strong_pixels, r.n_boxes, r.num_strong_pixels_filtered);
+                }
+                completed += 1;
+            }
+        }
+        ffs_stream_destroy(s);
+    };
+    {
+        std::vector<std::thread> threads;
+        for (uint32_t t = 0; t < args.threads; ++t) threads.emplace_back(worker, (int)t);
+        for (auto& t : threads) t.join();
+    }
+    if (failed.load()) return 1;
+
+    // ---- 3D connected components (spotfinder.cc:1099-1148) ------------------------------------------
+    if (rotation) {
+        std::printf("Processing 3D spots\n");
+        const ffs_reflection* refl = nullptr;
+        uint32_t n = 0, n_calc = 0, f_size = 0, f_sep = 0;
+        FFS_CHECK(ctx, ffs_stack3d_finish(stack, &refl, &n, &n_calc, &f_size, &f_sep));
+        std::printf("Calculated %u spots\n", n_calc);  // connected_components.cc:453-454
+        if (f_size > 0) std::printf("Filtered %u spots with size < %u pixels\n", f_size, prm.min_spot_size_3d);
+        if (f_sep > 0) std::printf("Filtered %u spots with peak-centroid distance > %s\n", f_sep, fmt_num(prm.max_peak_centroid_separation).c_str());
+        std::printf("Found %u spots\n", n);
+        if (args.writeout) {
+            std::ofstream out("3d_reflections.txt");
+            for (uint32_t i = 0; i < n; ++i) {
+                const ffs_reflection& r = refl[i];
+                out << "X: [" << r.x_min << ", " << r.x_max << "] "
+                    << "Y: [" << r.y_min << ", " << r.y_max << "] "
+                    << "Z: [" << r.z_min << ", " << r.z_max << "] "
+                    << "COM: (" << r.com_x << ", " << r.com_y << ", " << r.com_z << ")\n";
+            }
+        }
+        std::printf("3D spot analysis complete\n");
+        ffs_stack3d_destroy(stack);
+    }
+
+    const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - all_start).count();
+    const uint32_t done = completed.load();
+    std::printf("\n%d images in %.2f s (\033[1;34m%.2f GBps\033[0m) (\033[1;34m%.1f fps\033[0m)\n", (int)done, total,
+                (double)width * height * bytes_per_pixel * done / total / 1e9, done / total);
+    if (time_waiting < 10) std::printf("Total time waiting for images to appear: %.0f ms\n", time_waiting * 1000);
+    else std::printf("Total time waiting for images to appear: %.2f s\n", time_waiting);
+    pipe.reset();
+    ffs_ctx_destroy(ctx);
+    return 0;
+}

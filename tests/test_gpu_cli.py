@@ -1,0 +1,161 @@
+"""GPU: the spotfinder driver end to end -- stdout phrases, --pipe_fd JSON lines, files and exit
+codes of the reference's CLI contract (spotfinder/spotfinder.cc, tests/test_spotfinder.py:26-29,
+tests/3d_connected_components.sh:48-62), with expected values from the oracle."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "fast-feedback-service_amd", "bin")
+SPOTFINDER = os.path.join(BIN, "spotfinder")
+TOOL = os.path.join(BIN, "ffs_hosttool")
+
+pixels_match_regex = r"image\s+(\d+).*?(\d+)\s+strong pixels"            # reference tests/test_spotfinder.py:26
+spots_match_regex = r"Calculated\s+(\d+)\s+spots"
+min_spot_size_regex = r"Filtered\s+(\d+)\s+spots with size < (\d+) pixels"
+max_separation_regex = r"Filtered\s+(\d+)\s+spots with peak-centroid distance > 2"
+
+
+def strip_ansi(t):
+    return re.sub(r"\x1b\[[0-9;]*m", "", t)
+
+
+def tiny_frames(n, sweep=False, seed=7):
+    from ffs_amd import synth
+    p = synth.params(300, 200, np.uint16, seed=seed, background=2.0, n_spots=40, sigma=(0.8, 1.6),
+                     peak=(30.0, 5000.0), max_value=65535,
+                     n_frames=n if sweep else 0, sigma_z=(0.5, 2.0) if sweep else (0.0, 0.0))
+    return synth.frames(p, range(n), threads=2)
+
+
+def run_with_pipe(argv, cwd):
+    r, w = os.pipe()
+    proc = subprocess.Popen([SPOTFINDER, *argv, "--pipe_fd", str(w)], pass_fds=[w], cwd=cwd,
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    os.close(w)
+    out, err = proc.communicate(timeout=300)
+    with os.fdopen(r) as f:
+        lines = [l for l in f.read().split("\n") if l]
+    return proc.returncode, out, err, lines
+
+
+def expected(frames, mask, min_spot_size=3):
+    from oracle import oracle as O
+    exp = []
+    for img in frames:
+        strong = O.dispersion(img, mask)
+        cc = O.cc2d(strong, img, min_spot_size)
+        refl = O.cc2d_reflections(cc.k, cc.intensity, img.shape[1], img.shape[0], min_spot_size, 2.0)
+        exp.append((cc, refl))
+    return exp
+
+
+@pytest.mark.parametrize("threads,batch", [(1, 1), (3, 2), (2, 4)])
+def test_stills_json_lines_and_stdout(tmp_path, threads, batch):
+    N = 7
+    rc, out, err, lines = run_with_pipe(["synth:tiny:%d" % N, "--threads", str(threads), "--batch", str(batch),
+                                         "--output-for-index"], tmp_path)
+    assert rc == 0 and not err, err
+    frames = tiny_frames(N)
+    exp = expected(frames, np.ones((200, 300), np.uint8))
+    got = {}
+    for l in lines:
+        # nlohmann dump(): alphabetical keys, no spaces
+        assert list(json.loads(l).keys()) == sorted(json.loads(l).keys()) and ", " not in l
+        j = json.loads(l)
+        got[j["file-number"]] = j
+    assert sorted(got) == list(range(N))
+    found = dict((int(a), int(b)) for a, b in re.findall(pixels_match_regex, strip_ansi(out)))
+    for i, (cc, refl) in enumerate(exp):
+        j = got[i]
+        assert j["file"] == "synth:tiny:%d" % N
+        assert j["num_strong_pixels"] == cc.num_strong_pixels == found[i]
+        assert j["n_spots_total"] == len(cc.boxes)
+        want = np.stack([refl.reflections["com_x"], refl.reflections["com_y"], refl.reflections["com_z"]], 1).reshape(-1)
+        np.testing.assert_allclose(np.array(j["spot_centers"], np.float32), want, rtol=0, atol=1e-6)
+    assert f"{N} images in" in out
+
+
+def test_rotation_3d_output(tmp_path):
+    N = 8
+    rc, out, err, lines = run_with_pipe(["synth:tinysweep:%d" % N, "--threads", "2", "--batch", "3", "--writeout",
+                                         "--min-spot-size-3d", "4"], tmp_path)
+    assert rc == 0 and not err, err
+    from oracle import oracle as O
+    frames = tiny_frames(N, sweep=True)
+    mask = np.ones((200, 300), np.uint8)
+    exp = expected(frames, mask)
+    want = O.cc3d([(cc.k, cc.intensity) for cc, _ in exp], 300, 200, 4, 2.0)
+    txt = strip_ansi(out)
+    assert "Dataset type: Rotation set" in txt
+    assert int(re.search(spots_match_regex, txt).group(1)) == want.n_calculated
+    m = re.search(min_spot_size_regex, txt)
+    assert (int(m.group(1)), int(m.group(2))) == (want.n_filtered_size, 4)
+    if want.n_filtered_sep:
+        assert int(re.search(max_separation_regex, txt).group(1)) == want.n_filtered_sep
+    assert f"Found {len(want.reflections)} spots" in txt
+    got = open(tmp_path / "3d_reflections.txt").read().strip().split("\n")
+    assert len(got) == len(want.reflections) > 3
+    for line, r in zip(got, want.reflections):
+        m = re.match(r"X: \[(\d+), (\d+)\] Y: \[(\d+), (\d+)\] Z: \[(\d+), (\d+)\] COM: \(([^,]+), ([^,]+), ([^)]+)\)", line)
+        assert m, line
+        assert [int(m.group(i)) for i in range(1, 7)] == [r["x_min"], r["x_max"], r["y_min"], r["y_max"], r["z_min"], r["z_max"]]
+        # iostream default formatting = 6 significant digits (spotfinder.cc:1138-1147)
+        for g, w in zip(m.groups()[6:], (r["com_x"], r["com_y"], r["com_z"])):
+            assert g == "%g" % w
+    # --writeout also lists strong pixels per image ("{:4d}, {:4d}", spotfinder.cc:985-993)
+    px = open(tmp_path / "pixels_00000.txt").read().strip().split("\n")
+    assert len(px) == exp[0][0].num_strong_pixels
+    ys, xs = np.divmod(exp[0][0].k.astype(np.int64), 300)
+    assert px[0] == "%4d, %4d" % (xs[0], ys[0])
+    assert (tmp_path / "image_00000.png").read_bytes()[:8] == b"\x89PNG\r\n\x1a\n"
+
+
+def test_shm_and_cbf_readers(tmp_path):
+    """Frames written as an Eiger-stream directory (bitshuffle-LZ4) and as miniCBF (byte-offset)
+    give the same answers as the raw synthetic source."""
+    N = 4
+    spec = "synth:tiny:%d" % N
+    shm = tmp_path / "shm"
+    assert subprocess.run([TOOL, "mkshm", spec, str(shm)]).returncode == 0
+    assert subprocess.run([TOOL, "mkcbf", spec, str(tmp_path / "img_")]).returncode == 0
+    exp = expected(tiny_frames(N), np.ones((200, 300), np.uint8))
+    det = json.dumps({"pixel_size_x": 0.075, "pixel_size_y": 0.075, "beam_center_x": 11.25, "beam_center_y": 7.5,
+                      "distance": 300.0})
+    for argv in (["%s" % shm, "--threads", "2"],
+                 [str(tmp_path / "img_####.cbf"), "--images", str(N), "--start-index", "1", "--wavelength", "0.976",
+                  "--detector", det]):
+        rc, out, err, lines = run_with_pipe(argv, tmp_path)
+        assert rc == 0 and not err, (out, err)
+        got = {json.loads(l)["file-number"]: json.loads(l) for l in lines}
+        for i, (cc, _) in enumerate(exp):
+            assert got[i]["num_strong_pixels"] == cc.num_strong_pixels
+            assert got[i]["n_spots_total"] == len(cc.boxes)
+            assert got[i]["file"] == argv[0]
+
+
+def test_dtype_exit_code_protocol(tmp_path):
+    """With --strict-dtype the binary follows the reference's protocol: exit code = bit depth of the
+    data when it does not match the executable (spotfinder.cc:468-476; service.py:503-507)."""
+    p = subprocess.run([SPOTFINDER, "synth:jungfrau9m:1", "--strict-dtype"], capture_output=True, text=True, cwd=tmp_path)
+    assert p.returncode == 32 and "only accepts 16 bit" in p.stdout
+    p = subprocess.run([os.path.join(BIN, "spotfinder32"), "synth:tiny:1", "--strict-dtype"], capture_output=True,
+                       text=True, cwd=tmp_path)
+    assert p.returncode == 16
+    p = subprocess.run([SPOTFINDER, "--list-devices"], capture_output=True, text=True)
+    assert p.returncode == 0 and re.match(r"0: .*gfx950", p.stdout.split("\n")[1])
+
+
+def test_resolution_mask_flags(tmp_path):
+    rc, out, err, lines = run_with_pipe(["synth:tiny:2", "--dmin", "2.0"], tmp_path)
+    assert rc == 0 and not err
+    rc2, out2, err2, lines2 = run_with_pipe(["synth:tiny:2"], tmp_path)
+    a = [json.loads(l)["num_strong_pixels"] for l in sorted(lines)]
+    b = [json.loads(l)["num_strong_pixels"] for l in sorted(lines2)]
+    assert all(x <= y for x, y in zip(a, b)) and sum(a) < sum(b)
