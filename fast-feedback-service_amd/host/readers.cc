@@ -135,16 +135,19 @@ class CBFRead : public Reader {
         // the negative (= flagged) pixels as VALID; we use the evident intent, valid = (value >= 0)
         const size_t npx = shape_[0] * shape_[1];
         std::vector<uint8_t> buf(npx * 4);
-        auto chunk = get_raw_chunk(0, buf);
+        auto chunk = get_raw_chunk(first_, buf);
         std::vector<int32_t> img(npx, 0);
         byte_offset_decompress(chunk.data(), chunk.size(), img.data(), npx);
         mask_.resize(npx);
         for (size_t i = 0; i < npx; ++i) mask_[i] = img[i] >= 0;
     }
     PixelDType get_dtype() const override { return PixelDType::UINT16; }
-    bool is_image_available(size_t index) override { return fs::exists(expand_template(templ_, index + first_)); }
+    // `index` is the driver's offset image number (image_num + --start-index, spotfinder.cc:756) and
+    // is used as the file number as it stands.  (The reference adds the start index a second time
+    // inside CBFRead, cbfread.cc:87-96, so with --start-index 1 it opens file 2 for image 0.)
+    bool is_image_available(size_t index) override { return fs::exists(expand_template(templ_, index)); }
     std::span<uint8_t> get_raw_chunk(size_t index, std::span<uint8_t> dst) override {  // cbfread.cc:94-128
-        std::ifstream f(expand_template(templ_, index + first_), std::ios::binary);
+        std::ifstream f(expand_template(templ_, index), std::ios::binary);
         std::string data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
         static const std::string marker = "\x0c\x1a\x04\xd5";
         const size_t at = data.find(marker);

@@ -410,9 +410,9 @@ int main(int argc, char** argv) {
     {  // upload_mask, spotfinder.cc:61-108
         size_t valid = 0;
         const auto t0 = std::chrono::steady_clock::now();
-        if (reader.get_mask()) {
-            for (uint8_t v : *reader.get_mask()) valid += v != 0;
-            FFS_CHECK(ctx, ffs_ctx_set_mask(ctx, reader.get_mask()->data()));
+        if (const auto mask = reader.get_mask()) {
+            for (uint8_t v : *mask) valid += v != 0;
+            FFS_CHECK(ctx, ffs_ctx_set_mask(ctx, mask->data()));
         } else {
             valid = (size_t)width * height;
             FFS_CHECK(ctx, ffs_ctx_set_mask(ctx, nullptr));
@@ -421,7 +421,7 @@ int main(int argc, char** argv) {
         std::printf("Uploaded mask (%.2f Mpx) in %.2f ms (%.1f GBps)\n", valid / 1e6, ms,
                     (double)width * height / (ms * 1e-3) / 1e9);
     }
-    if (args.writeout && reader.get_mask()) write_mask_png("mask_source.png", reader.get_mask()->data(), width, height);
+    if (const auto mask = reader.get_mask(); args.writeout && mask) write_mask_png("mask_source.png", mask->data(), width, height);
     if (args.dmin > 0 || args.dmax > 0) {  // spotfinder.cc:648-683
         FFS_CHECK(ctx, ffs_ctx_apply_resolution_mask(ctx, wavelength, detector.distance, detector.beam_center_x,
                                                      detector.beam_center_y, detector.pixel_size_x,
