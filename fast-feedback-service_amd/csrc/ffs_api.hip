@@ -404,14 +404,16 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
     a.band_rows = (int)rows;
     a.n_bands = (L.H + a.band_rows - 1) / a.band_rows;
     a.kS = (float)(p.nsig_s * p.nsig_s * (1.0 - 1.0 / 65536.0));
+    a.kB = (float)(p.nsig_b * (1.0 - 1.0 / 1048576.0));
     a.min_count = p.min_count;
     a.nsig_b = p.nsig_b;
     a.nsig_s = p.nsig_s;
     a.threshold = p.threshold;
     a.max_valid = p.max_valid;
-    {   // FFS_K1_VARIANT=1 selects the group-screen candidate kernel (A/B testing)
+    {   // FFS_K1_VARIANT=0 selects the signal-test-only candidate kernel (A/B testing); default 1 =
+        // signal + dispersion screen in the candidate kernel
         const char* v = std::getenv("FFS_K1_VARIANT");
-        a.variant = v ? std::atoi(v) : 0;
+        a.variant = v ? std::atoi(v) : 1;
     }
     return a;
 }
@@ -431,7 +433,9 @@ static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_
 
 static void launch_exact(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
     dim3 grid((unsigned)a.n_tiles, n_frames), block(256);
-    if (s->ctx->pixel_bytes == 2)
+    if (s->ctx->pixel_bytes == 2 && a.variant == 1)  // few candidates per tile: one wave per tile
+        hipLaunchKernelGGL(k_exact_w64<uint16_t>, grid, dim3(64), 0, s->st, a);
+    else if (s->ctx->pixel_bytes == 2)
         hipLaunchKernelGGL(k_exact<uint16_t>, grid, block, 0, s->st, a);
     else
         hipLaunchKernelGGL(k_exact<uint32_t>, grid, block, 0, s->st, a);

@@ -50,6 +50,7 @@ struct ThresholdArgs {
     int n_strips, band_rows, n_bands, n_tiles;
     // parameters
     float kS;                  // nsig_s^2 (1 - 2^-16): conservative signal pre-filter
+    float kB;                  // nsig_b (1 - 2^-20): conservative dispersion pre-filter
     int min_count;
     double nsig_b, nsig_s, threshold;
     long long max_valid;       // < 0: no test

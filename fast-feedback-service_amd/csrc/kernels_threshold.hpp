@@ -89,19 +89,58 @@ __device__ __forceinline__ uint32_t signal_test8(const uint32_t (&Wn)[8], const 
     return cb;
 }
 
-constexpr int kQCap = 128;  // lane-group queue entries per wave (power of two, >= 64 + 62)
 
-// SCREEN = false: every pixel takes the conservative signal test (11 VALU ops / pixel).
-// SCREEN = true : each lane first tests its 8-pixel group as a whole -- the largest centre pixel
-//   against the smallest window sum (windows with equal counts) -- which is still conservative and
-//   costs ~1/3 of eight pixel tests; the few groups that pass (a few %) are queued in LDS with
-//   their 16 words and tested pixel by pixel 64 groups at a time, so that work runs on dense
-//   lanes.  Both variants produce identical candidate planes.
+constexpr int kQCap = 64;        // lane-group queue entries per wave (8 KB of LDS)
+
+// Per-pixel tests on one queued lane-group (8 pixels): the conservative signal test above AND a
+// conservative form of the oracle's dispersion test
+//     a = m y - x^2 - x (m-1)  >  c = nsig_b x sqrt(2 (m-1))        (standalone.cc:166,168,170)
+// in float32 with an explicit error allowance (|fl(a) - a| < 2^-21 m y; we grant 2^-20 m y and
+// shave 2^-20 off c).  y = sum p^2 comes from 32-bit running sums that are exact while every
+// pixel of the window is < 8192 (49 * 8191^2 < 2^32); x < 8192 guarantees that, and brighter
+// windows are passed on unconditionally (the exact kernel decides them).
+// The queue lives in LDS word-major, q[w][e]: words 0-7 window words W, 8-15 centre words A,
+// 16-29 the 14 column sums of p^2 (L5 L6 L7 c0..c7 R0 R1 R2), 30 the (row, lane) tag.  Word-major
+// keeps every access conflict-free (consecutive lanes -> consecutive entries) and lets the pushes
+// be ds_write2_b32 from whatever registers hold the values (a b128 layout costs ~30 v_mov per push).
+constexpr int kQWords = 32;
+// Deliberately a rolled loop reading LDS word by word: the drain runs once per ~20 rows, and
+// keeping its live registers to a handful is what lets the streaming loop keep 4 waves per SIMD.
+__device__ __forceinline__ uint32_t group_tests8(const uint32_t (*q)[kQCap], int e, float kS, float kB) {
+    uint32_t wq = 0;  // window j sums cq[j .. j+6]
+#pragma nounroll
+    for (int t = 0; t < 7; ++t) wq += q[16 + t][e];
+    uint32_t cb = 0;
+#pragma nounroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t W = q[j][e], A = q[8 + j][e];
+        const uint32_t x = W & kXMask, m = W >> 22, pv = A & kXMask;
+        const int32_t b = (int32_t)(m * pv) - (int32_t)x;
+        const float bf = (float)b, tf = (float)(x * m);
+        const bool sig = bf * __builtin_fabsf(bf) > kS * tf;
+        const float mf = (float)m, xf = (float)x, yf = (float)wq;
+        const float t0 = mf * yf;
+        const float af = (t0 - xf * xf) - xf * (mf - 1.0f);
+        const float cf = xf * (kB * __builtin_sqrtf(2.0f * (mf - 1.0f)));
+        const bool disp = (af + t0 * 9.5367431640625e-07f >= cf) || x >= 8192u;
+        cb |= (sig && disp) ? (1u << j) : 0u;
+        wq = wq - q[16 + j][e] + q[23 + j][e];  // j = 7 reads the tag word; that sum is not used
+    }
+    return cb;
+}
+
+// SCREEN = false: every pixel takes the conservative signal test (11 VALU ops / pixel); about
+//   0.5-0.7 % of pixels become candidates for the exact kernel.
+// SCREEN = true : the kernel also carries sum p^2 (a second running column sum, updated with
+//   dq = (p_in - p_out)(p_in + p_out)), screens each lane's 8-pixel group as a whole with the signal
+//   test -- largest centre pixel against smallest window sum, still conservative -- and queues the
+//   few groups that pass (a few %) in LDS with their window words; 64 queued groups at a time take
+//   the per-pixel signal AND dispersion tests on dense lanes (group_tests8).  The candidate plane
+//   then holds little more than the true strong pixels, so the exact kernel no longer re-reads the
+//   batch from HBM.  Both variants are supersets of the oracle's strong pixels.
 template <bool SCREEN>
-__global__ __launch_bounds__(64) void k_candidates_u16(const ThresholdArgs a) {
-    __shared__ uint4 s_qW0[SCREEN ? kQCap : 1], s_qW1[SCREEN ? kQCap : 1];
-    __shared__ uint4 s_qA0[SCREEN ? kQCap : 1], s_qA1[SCREEN ? kQCap : 1];
-    __shared__ uint32_t s_qtag[SCREEN ? kQCap : 1];
+__global__ __launch_bounds__(64, 4) void k_candidates_u16(const ThresholdArgs a) {  // <= 128 VGPRs: 4 waves per SIMD
+    __shared__ uint32_t s_q[SCREEN ? kQWords : 1][SCREEN ? kQCap : 1];
 
     const int lane = threadIdx.x;
     // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group), and
@@ -118,7 +157,7 @@ __global__ __launch_bounds__(64) void k_candidates_u16(const ThresholdArgs a) {
     const int lx0 = sx0 + lane * kLanePx;
     const bool active = lx0 >= 0 && lx0 + kLanePx <= a.pitch_px;
     const bool owned = active && lane >= 1 && lane <= 62;
-    const int cx = active ? lx0 : 0;  // inactive lanes read column 0 and get their valid bits zeroed
+    const int cx = active ? lx0 : 0;
 
     // Buffer resources (wave-uniform, SGPRs): per-lane column offset in a VGPR, row offset in an
     // SGPR, so no per-row VALU address arithmetic; out-of-range accesses are dropped by hardware.
@@ -143,10 +182,10 @@ __global__ __launch_bounds__(64) void k_candidates_u16(const ThresholdArgs a) {
     const uint32_t off_bit_st = owned ? ((uint32_t)cx >> 3) : kOob;        // candidate stores
 
     const int total = (yb1 - yb0) + 6;  // incoming rows yb0-3 .. yb1+2
-    const float kS = a.kS;
+    const float kS = a.kS, kB = a.kB;
 
     uint32_t ring[7][8];
-    uint32_t col[8];
+    uint32_t col[8], colq[8];
     RowRegsU16 pre[7];
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
@@ -154,7 +193,7 @@ __global__ __launch_bounds__(64) void k_candidates_u16(const ThresholdArgs a) {
         for (int j = 0; j < 8; ++j) ring[s][j] = 0;
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) col[j] = 0;
+    for (int j = 0; j < 8; ++j) { col[j] = 0; colq[j] = 0; }
 
     // issue the loads of incoming row number i (image row yb0 - 3 + i)
     auto fetch = [&](RowRegsU16& dst, int i) {
@@ -167,42 +206,40 @@ __global__ __launch_bounds__(64) void k_candidates_u16(const ThresholdArgs a) {
         dst.mb = __builtin_amdgcn_raw_buffer_load_b8(r_mask, off_bit | kill, row * a.mpitch, 0);
     };
 
-    // vertical running sum: add incoming row, retire the row that left the 7-row window
+    // vertical running sums: add the incoming row, retire the row that left the 7-row window
     auto push = [&](int s, const uint32_t (&A)[8]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            if (SCREEN) {
+                // p_in^2 - p_out^2 as one 24-bit multiply; an invalid pixel has low half 0
+                const int32_t pn = (int32_t)(A[j] & 0xFFFFu), po = (int32_t)(ring[s][j] & 0xFFFFu);
+                colq[j] += (uint32_t)((pn - po) * (pn + po));
+            }
             col[j] += A[j] - ring[s][j];
             ring[s][j] = A[j];
         }
     };
 
-    // ---- lane-group queue (SCREEN only); head/count are wave-uniform ---------------------------
-    int qhead = 0, qn = 0;
-    // test `cnt` (<= 64) queued groups, one per lane, and store their candidate bytes
-    auto drain = [&](int cnt) {
-        if (lane < cnt) {
-            const int e = (qhead + lane) & (kQCap - 1);
-            const uint4 w0 = s_qW0[e], w1 = s_qW1[e], a0 = s_qA0[e], a1 = s_qA1[e];
-            const uint32_t tag = s_qtag[e];
-            const uint32_t Wq[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-            const uint32_t Aq[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            const uint32_t cb = signal_test8(Wq, Aq, kS);
-            const uint32_t row = tag >> 6, ln = tag & 63u;
+    int qn = 0;  // queued lane-groups (wave-uniform)
+    auto drain = [&]() {
+        if constexpr (SCREEN) if (lane < qn) {
+            const uint32_t cb = group_tests8(s_q, lane, kS, kB);
+            const uint32_t tag = s_q[30][lane], row = tag >> 6, ln = tag & 63u;
             __builtin_amdgcn_raw_buffer_store_b8((uint8_t)cb, r_cb, row * a.mpitch + (uint32_t)(sx0 >> 3) + ln, 0, 0);
         }
-        qhead = (qhead + cnt) & (kQCap - 1);
-        qn -= cnt;
+        qn = 0;
     };
 
+    constexpr int kAhead = SCREEN ? 3 : 4;  // rows of loads in flight per wave  // rows of loads in flight per wave
 #pragma unroll
-    for (int s = 0; s < 4; ++s) fetch(pre[s], s);
+    for (int s = 0; s < kAhead; ++s) fetch(pre[s], s);
 
     // warm-up: rows 0..5 of the band's input only fill the window
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
         uint32_t A[8];
         unpack_u16(pre[s], A);
-        fetch(pre[(s + 4) % 7], s + 4);
+        fetch(pre[(s + kAhead) % 7], s + kAhead);
         push(s, A);
     }
 
@@ -216,27 +253,44 @@ __global__ __launch_bounds__(64) void k_candidates_u16(const ThresholdArgs a) {
             {
                 uint32_t A[8];
                 unpack_u16(pre[s], A);
-                fetch(pre[(s + 4) % 7], i + 4);  // 4 rows of loads in flight per wave
+                fetch(pre[(s + kAhead) % 7], i + kAhead);
                 push(s, A);
 
                 // horizontal 7-tap over column sums c[-3..10] = L5 L6 L7 c0..c7 R0 R1 R2
                 const uint32_t L5 = from_left(col[5]), L6 = from_left(col[6]), L7 = from_left(col[7]);
                 const uint32_t R0 = from_right(col[0]), R1 = from_right(col[1]), R2 = from_right(col[2]);
                 uint32_t Wn[8];
-                Wn[0] = (L5 + L6 + L7) + (col[0] + col[1] + col[2]) + col[3];
-                Wn[1] = Wn[0] - L5 + col[4];
-                Wn[2] = Wn[1] - L6 + col[5];
-                Wn[3] = Wn[2] - L7 + col[6];
-                Wn[4] = Wn[3] - col[0] + col[7];
-                Wn[5] = Wn[4] - col[1] + R0;
-                Wn[6] = Wn[5] - col[2] + R1;
-                Wn[7] = Wn[6] - col[3] + R2;
+                if constexpr (!SCREEN) {
+                    // two independent sliding chains (outwards from pixels 3 and 4) for ILP
+                    const uint32_t mid = (col[1] + col[2] + col[3]) + (col[4] + col[5] + col[6]);  // c1..c6
+                    Wn[3] = mid + col[0];
+                    Wn[4] = mid + col[7];
+                    Wn[2] = Wn[3] - col[6] + L7;
+                    Wn[5] = Wn[4] - col[1] + R0;
+                    Wn[1] = Wn[2] - col[5] + L6;
+                    Wn[6] = Wn[5] - col[2] + R1;
+                    Wn[0] = Wn[1] - col[4] + L5;
+                    Wn[7] = Wn[6] - col[3] + R2;
+                } else {
+                    // one chain: fewer values live at once (this variant is register-bound)
+                    Wn[0] = (L5 + L6 + L7) + (col[0] + col[1] + col[2]) + col[3];
+                    Wn[1] = Wn[0] - L5 + col[4];
+                    Wn[2] = Wn[1] - L6 + col[5];
+                    Wn[3] = Wn[2] - L7 + col[6];
+                    Wn[4] = Wn[3] - col[0] + col[7];
+                    Wn[5] = Wn[4] - col[1] + R0;
+                    Wn[6] = Wn[5] - col[2] + R1;
+                    Wn[7] = Wn[6] - col[3] + R2;
+                }
 
-                const int yout = yb0 + (i - 6);
-                if (!SCREEN) {
+                // readfirstlane: the row offsets are wave-uniform, but the compiler keeps the loop's
+                // induction value in a VGPR and would wrap every store in a waterfall loop
+                const int yout = __builtin_amdgcn_readfirstlane(yb0 + (i - 6));
+                const uint32_t so_bytes = (uint32_t)yout * a.bpitch, so_bits = (uint32_t)yout * a.mpitch;
+                if constexpr (!SCREEN) {
                     const uint32_t cb = signal_test8(Wn, ring[sc], kS);
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, (uint32_t)yout * a.bpitch, 0);
-                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)cb, r_cb, off_bit_st, (uint32_t)yout * a.mpitch, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, so_bytes, 0);
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)cb, r_cb, off_bit_st, so_bits, 0);
                 } else {
                     // group screen: every pixel j of the group has p_j <= pmax and, when all eight
                     // windows hold the same count m, x_j >= xmin; b_j <= m pmax - xmin and
@@ -253,32 +307,45 @@ __global__ __launch_bounds__(64) void k_candidates_u16(const ThresholdArgs a) {
                     const float bf = (float)b, tf = (float)(x * m);
                     const bool pass = (bf * __builtin_fabsf(bf) > kS * tf) || ((wmin ^ wmax) >> 22) != 0;
                     const bool flag = owned && pass;
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, (uint32_t)yout * a.bpitch, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, so_bytes, 0);
                     // queued groups get their byte from drain(); everybody else stores 0 now
-                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)0, r_cb, flag ? kOob : off_bit_st,
-                                                         (uint32_t)yout * a.mpitch, 0);
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)0, r_cb, flag ? kOob : off_bit_st, so_bits, 0);
                     const unsigned long long fm = __ballot(flag);
                     if (fm) {  // wave-uniform
+                        const int nf = __popcll(fm);
+                        if (qn + nf > kQCap) drain();
+                        // the group's 14 column sums of p^2 (own 8 + 3 from each neighbour lane)
+                        const uint32_t QL5 = from_left(colq[5]), QL6 = from_left(colq[6]), QL7 = from_left(colq[7]);
+                        const uint32_t QR0 = from_right(colq[0]), QR1 = from_right(colq[1]), QR2 = from_right(colq[2]);
                         if (flag) {
                             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32),
                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
-                            const int e = (qhead + qn + (int)rank) & (kQCap - 1);
-                            s_qW0[e] = make_uint4(Wn[0], Wn[1], Wn[2], Wn[3]);
-                            s_qW1[e] = make_uint4(Wn[4], Wn[5], Wn[6], Wn[7]);
-                            s_qA0[e] = make_uint4(ring[sc][0], ring[sc][1], ring[sc][2], ring[sc][3]);
-                            s_qA1[e] = make_uint4(ring[sc][4], ring[sc][5], ring[sc][6], ring[sc][7]);
-                            s_qtag[e] = ((uint32_t)yout << 6) | (uint32_t)lane;
+                            const int e = qn + (int)rank;
+                            if (e >= kQCap) {
+                                // queue full (a burst of flagged groups): hand the whole group to
+                                // the exact kernel instead -- still a superset, never a miss
+                                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)0xFF, r_cb, off_bit_st, so_bits, 0);
+                            } else {
+#pragma unroll
+                            for (int w = 0; w < 8; ++w) {
+                                s_q[w][e] = Wn[w];
+                                s_q[8 + w][e] = ring[sc][w];
+                                s_q[19 + w][e] = colq[w];
+                            }
+                            s_q[16][e] = QL5; s_q[17][e] = QL6; s_q[18][e] = QL7;
+                            s_q[27][e] = QR0; s_q[28][e] = QR1; s_q[29][e] = QR2;
+                            s_q[30][e] = ((uint32_t)yout << 6) | (uint32_t)lane;
+                            }
                         }
-                        qn += __popcll(fm);
-                        if (qn >= 64) drain(64);
+                        qn = min(qn + nf, kQCap);
                     }
                 }
             }
         }
     }
 rows_done:
-    if (SCREEN) {
-        if (qn > 0) drain(qn);  // qn < 64 here
+    if constexpr (SCREEN) {
+        if (qn > 0) drain();
     }
 }
 template __global__ void k_candidates_u16<false>(const ThresholdArgs);
@@ -434,7 +501,7 @@ __global__ __launch_bounds__(64) void k_candidates_u32(const ThresholdArgs a) {
 
                 // an (even, odd) lane pair shares one byte of the candidate plane
                 const uint32_t hi = from_right(cb);
-                const int yout = yb0 + (i - 6);
+                const int yout = __builtin_amdgcn_readfirstlane(yb0 + (i - 6));  // see k_candidates_u16
                 __builtin_amdgcn_raw_buffer_store_b32(0u, r_sb, off_byte_st, (uint32_t)yout * a.bpitch, 0);
                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(cb | (hi << 4)), r_cb, off_bit_st,
                                                      (uint32_t)yout * a.mpitch, 0);
@@ -524,12 +591,12 @@ __device__ bool exact_strong(const ThresholdArgs& a, const uint8_t* img, int x, 
     return av > cv && bv > dv;
 }
 
-template <typename PixelT>
-__global__ __launch_bounds__(256) void k_exact(const ThresholdArgs a) {
-    // 18 KB of LDS per workgroup -> 8 workgroups (32 waves) per CU: the stage is latency-bound
-    // (sparse gathers), so residency is what hides it.
+template <typename PixelT, int NT, int LISTCAP>
+__device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
+    // The stage is latency-bound (sparse gathers).  Measured dead ends: a smaller LDS footprint
+    // (more tiles resident) and one-wave workgroups both made it slower.
     __shared__ uint32_t s_words[kTileRows * 320];  // tile bit-plane words (pitch_px <= 10240)
-    __shared__ uint32_t s_list[kExactListCap];
+    __shared__ uint32_t s_list[LISTCAP];
     __shared__ uint32_t s_cnt, s_total, s_strong;
 
     const int tid = threadIdx.x;
@@ -545,7 +612,7 @@ __global__ __launch_bounds__(256) void k_exact(const ThresholdArgs a) {
 
     if (tid == 0) { s_cnt = 0; s_total = 0; s_strong = 0; }
     uint32_t mine = 0;
-    for (int g = tid; g < ndw; g += 256) {
+    for (int g = tid; g < ndw; g += NT) {
         const uint32_t w = gwords[g];
         s_words[g] = w;
         mine += __popc(w);
@@ -568,7 +635,7 @@ __global__ __launch_bounds__(256) void k_exact(const ThresholdArgs a) {
     };
     auto flush = [&]() {
         const uint32_t n = s_cnt;
-        for (uint32_t e = tid; e < n; e += 256) {
+        for (uint32_t e = tid; e < n; e += NT) {
             const uint32_t idx = s_list[e];
             const uint32_t g = idx >> 5, bit = idx & 31u;
             const int row = g / dpr;
@@ -582,11 +649,11 @@ __global__ __launch_bounds__(256) void k_exact(const ThresholdArgs a) {
         }
     };
 
-    if (total <= (uint32_t)kExactListCap) {
+    if (total <= (uint32_t)LISTCAP) {
         // the usual case: every candidate of the tile in one dense pass
         if (mine) {
             uint32_t at = atomicAdd(&s_cnt, mine);
-            for (int g = tid; g < ndw; g += 256) {
+            for (int g = tid; g < ndw; g += NT) {
                 const uint32_t w = s_words[g];
                 append(g, w, at);
                 at += __popc(w);
@@ -596,9 +663,9 @@ __global__ __launch_bounds__(256) void k_exact(const ThresholdArgs a) {
         flush();
     } else {
         // dense tile: 64 words (<= 2048 candidates) at a time
-        for (int pos = 0; pos < ndw; pos += kExactListCap / 32) {
+        for (int pos = 0; pos < ndw; pos += LISTCAP / 32) {
             const int g = pos + tid;
-            const uint32_t w = (tid < kExactListCap / 32 && g < ndw) ? s_words[g] : 0u;
+            const uint32_t w = (tid < LISTCAP / 32 && g < ndw) ? s_words[g] : 0u;
             if (w) append(g, w, atomicAdd(&s_cnt, (uint32_t)__popc(w)));
             __syncthreads();
             flush();
@@ -610,7 +677,7 @@ __global__ __launch_bounds__(256) void k_exact(const ThresholdArgs a) {
     __syncthreads();
 
     uint32_t cnt = 0;
-    for (int g = tid; g < ndw; g += 256) {
+    for (int g = tid; g < ndw; g += NT) {
         const uint32_t w = s_words[g];
         gwords[g] = w;
         cnt += __popc(w);
@@ -620,7 +687,14 @@ __global__ __launch_bounds__(256) void k_exact(const ThresholdArgs a) {
     if (tid == 0) a.tile_counts[(uint64_t)frame * a.n_tiles + tile] = s_strong;
 }
 
+// NB: __launch_bounds__ must be a literal here -- with a template parameter hipcc 7.2 silently
+// dropped it (default 1024-thread bound -> 178 VGPRs + scratch, kernel 2x slower).
+template <typename PixelT>
+__global__ __launch_bounds__(256) void k_exact(const ThresholdArgs a) { exact_tile<PixelT, 256, kExactListCap>(a); }
+// one wave per tile: for the few candidates left after the dispersion screen
+template <typename PixelT>
+__global__ __launch_bounds__(64) void k_exact_w64(const ThresholdArgs a) { exact_tile<PixelT, 64, 256>(a); }
 template __global__ void k_exact<uint16_t>(const ThresholdArgs);
 template __global__ void k_exact<uint32_t>(const ThresholdArgs);
-
+template __global__ void k_exact_w64<uint16_t>(const ThresholdArgs);
 }  // namespace ffsamd

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--unique", type=int, default=4, help="unique synthetic frames (cycled)")
     ap.add_argument("--workload", default="eiger16m")
-    ap.add_argument("--variants", default="0", help="comma list of FFS_K1_VARIANT values to A/B")
+    ap.add_argument("--variants", default="1", help="comma list of FFS_K1_VARIANT values to A/B")
     ap.add_argument("--rounds", type=int, default=1)
     args = ap.parse_args()
     import torch
