@@ -46,7 +46,8 @@ struct ffs_ctx {
 
 struct ffs_stream {
     ffs_ctx* ctx = nullptr;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr;    // threshold kernels (+ H2D)
+    hipStream_t st2 = nullptr;   // compaction + connected components + D2H; == st unless the CUs are split
     hipEvent_t ev[6] = {};
     // device
     uint8_t* d_img = nullptr;
@@ -306,6 +307,7 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     if (s->st) (void)hipStreamSynchronize(s->st);
+    if (s->st2 && s->st2 != s->st) { (void)hipStreamSynchronize(s->st2); (void)hipStreamDestroy(s->st2); }
     void* dev[] = {s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_tile_offsets, s->d_num_strong,
                    s->d_list_k, s->d_list_i, s->d_parent, s->d_comp_id, s->d_n_comp, s->d_overflow,
                    s->d_summary, s->d_acc, s->d_recs};
@@ -338,7 +340,33 @@ extern "C" int ffs_stream_create(ffs_ctx* c, ffs_stream** out) {
             return e_ == hipErrorOutOfMemory ? FFS_ERR_NOMEM : FFS_ERR_DEVICE;  \
         }                                                                       \
     } while (0)
-    STREAM_TRY(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+    // The sparse stages (compaction, union-find, reductions) are latency-bound and keep only a few
+    // CUs busy; the streaming candidate kernel is HBM-bound and does not need all 256.  With
+    // FFS_CCL_CUS = n > 0 the two groups of kernels run on disjoint CU sets (HIP CU masks), so the
+    // connected-components stage of one batch can overlap the threshold stage of the next batch
+    // submitted on another ffs_stream.  Measured on MI355X (bench.py, 2 streams): 0 -> 34.4k fps,
+    // 32 -> 34.9k, 64 -> 33.8k, 16 -> 21.8k: no gain worth the constraint, so it is off by default.
+    {
+        int ncu = 0;
+        if (const char* e = std::getenv("FFS_CCL_CUS")) ncu = std::atoi(e);
+        hipDeviceProp_t prop;
+        STREAM_TRY(hipGetDeviceProperties(&prop, c->device));
+        const int total = prop.multiProcessorCount;
+        if (ncu > 0 && ncu < total && total <= 1024) {
+            const int words = (total + 31) / 32;
+            std::vector<uint32_t> m_ccl(words, 0), m_thr(words, 0);
+            const int step = total / ncu;  // spread the CCL CUs evenly over the XCDs
+            for (int i = 0; i < total; ++i) {
+                const bool ccl = (i % step) == 0 && (i / step) < ncu;
+                (ccl ? m_ccl : m_thr)[i / 32] |= 1u << (i % 32);
+            }
+            STREAM_TRY(hipExtStreamCreateWithCUMask(&s->st, (uint32_t)words, m_thr.data()));
+            STREAM_TRY(hipExtStreamCreateWithCUMask(&s->st2, (uint32_t)words, m_ccl.data()));
+        } else {
+            STREAM_TRY(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+            s->st2 = s->st;
+        }
+    }
     for (auto& e : s->ev) STREAM_TRY(hipEventCreate(&e));
     STREAM_TRY(dmalloc(&s->d_img, B * L.frame_stride));
     STREAM_TRY(dmalloc(&s->d_bits, B * L.plane_frame_stride));
@@ -469,6 +497,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     launch_candidates(s, ta, n);
     launch_exact(s, ta, n);
     HIP_TRY(c, hipEventRecord(s->ev[2], s->st));
+    if (s->st2 != s->st) HIP_TRY(c, hipStreamWaitEvent(s->st2, s->ev[2], 0));
 
     CclArgs ca{};
     ca.image = d_img;
@@ -494,11 +523,11 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     ca.cap = c->cap;
     ca.max_comp = c->max_comp;
     ca.pixel_bytes = c->pixel_bytes;
-    hipLaunchKernelGGL(k_scan_tiles, dim3(n), dim3(256), 0, s->st, ca);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(n), dim3(256), 0, s->st2, ca);
     if (c->pixel_bytes == 2)
-        hipLaunchKernelGGL(k_emit_list<uint16_t>, dim3(c->n_tiles, n), dim3(256), 0, s->st, ca);
+        hipLaunchKernelGGL(k_emit_list<uint16_t>, dim3(c->n_tiles, n), dim3(256), 0, s->st2, ca);
     else
-        hipLaunchKernelGGL(k_emit_list<uint32_t>, dim3(c->n_tiles, n), dim3(256), 0, s->st, ca);
+        hipLaunchKernelGGL(k_emit_list<uint32_t>, dim3(c->n_tiles, n), dim3(256), 0, s->st2, ca);
 
     SegArgs sa{};
     sa.list_k = s->d_list_k;
@@ -521,20 +550,20 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     sa.recs = s->d_recs;
     sa.summary = s->d_summary;
     const dim3 gseg(32, n), b256(256);
-    hipLaunchKernelGGL(k_union<false>, gseg, b256, 0, s->st, sa);
-    hipLaunchKernelGGL(k_label, dim3(n), dim3(1024), 0, s->st, sa);
-    hipLaunchKernelGGL(k_reduce<false>, gseg, b256, 0, s->st, sa);
-    hipLaunchKernelGGL(k_finalize<false>, dim3(8, n), b256, 0, s->st, sa);
+    hipLaunchKernelGGL(k_union<false>, gseg, b256, 0, s->st2, sa);
+    hipLaunchKernelGGL(k_label, dim3(n), dim3(1024), 0, s->st2, sa);
+    hipLaunchKernelGGL(k_reduce<false>, gseg, b256, 0, s->st2, sa);
+    hipLaunchKernelGGL(k_finalize<false>, dim3(8, n), b256, 0, s->st2, sa);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(s->ev[3], s->st));
+    HIP_TRY(c, hipEventRecord(s->ev[3], s->st2));
 
     // small counts first; ffs_wait() sizes the record copy from them
     const size_t B = c->max_batch;
-    HIP_TRY(c, hipMemcpyAsync(s->h_counts, s->d_num_strong, n * 4, hipMemcpyDeviceToHost, s->st));
-    HIP_TRY(c, hipMemcpyAsync(s->h_counts + B, s->d_n_comp, n * 4, hipMemcpyDeviceToHost, s->st));
-    HIP_TRY(c, hipMemcpyAsync(s->h_counts + 2 * B, s->d_summary, n * 8 * 4, hipMemcpyDeviceToHost, s->st));
-    HIP_TRY(c, hipMemcpyAsync(s->h_counts + 10 * B, s->d_overflow, 4, hipMemcpyDeviceToHost, s->st));
-    HIP_TRY(c, hipEventRecord(s->ev[4], s->st));
+    HIP_TRY(c, hipMemcpyAsync(s->h_counts, s->d_num_strong, n * 4, hipMemcpyDeviceToHost, s->st2));
+    HIP_TRY(c, hipMemcpyAsync(s->h_counts + B, s->d_n_comp, n * 4, hipMemcpyDeviceToHost, s->st2));
+    HIP_TRY(c, hipMemcpyAsync(s->h_counts + 2 * B, s->d_summary, n * 8 * 4, hipMemcpyDeviceToHost, s->st2));
+    HIP_TRY(c, hipMemcpyAsync(s->h_counts + 10 * B, s->d_overflow, 4, hipMemcpyDeviceToHost, s->st2));
+    HIP_TRY(c, hipEventRecord(s->ev[4], s->st2));
     s->busy = true;
     s->n_frames = n;
     return FFS_OK;
@@ -609,8 +638,8 @@ extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_
     const uint32_t overflow = s->h_counts[10 * B];
     s->busy = false;
     if (overflow) {
-        (void)hipMemsetAsync(s->d_overflow, 0, 4, s->st);
-        (void)hipStreamSynchronize(s->st);
+        (void)hipMemsetAsync(s->d_overflow, 0, 4, s->st2);
+        (void)hipStreamSynchronize(s->st2);
         c->err = (overflow & 1u) ? "a frame has more strong pixels than max_strong_per_frame"
                                  : "a frame has more connected components than the context holds";
         return FFS_ERR_OVERFLOW;
@@ -622,23 +651,23 @@ extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_
         max_ns = std::max(max_ns, h_ns[f]);
     }
     if (total_recs)
-        HIP_TRY(c, hipMemcpyAsync(s->h_recs, s->d_recs, total_recs * sizeof(ReflOut), hipMemcpyDeviceToHost, s->st));
+        HIP_TRY(c, hipMemcpyAsync(s->h_recs, s->d_recs, total_recs * sizeof(ReflOut), hipMemcpyDeviceToHost, s->st2));
     if (p.want_strong_list && max_ns) {
         int rc = ensure_list_host(s);
         if (rc != FFS_OK) return rc;
         HIP_TRY(c, hipMemcpy2DAsync(s->h_list_k, (size_t)c->cap * 4, s->d_list_k, (size_t)c->cap * 4,
-                                    (size_t)max_ns * 4, n, hipMemcpyDeviceToHost, s->st));
+                                    (size_t)max_ns * 4, n, hipMemcpyDeviceToHost, s->st2));
         HIP_TRY(c, hipMemcpy2DAsync(s->h_list_i, (size_t)c->cap * 4, s->d_list_i, (size_t)c->cap * 4,
-                                    (size_t)max_ns * 4, n, hipMemcpyDeviceToHost, s->st));
+                                    (size_t)max_ns * 4, n, hipMemcpyDeviceToHost, s->st2));
     }
     if (p.want_strong_mask) {
         if (!s->h_mask)
             HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&s->h_mask), B * (size_t)L.W * L.H, hipHostMallocDefault));
         // the reference's full-mask D2H (spotfinder.cc:887-894), all frames of the batch in one 2D copy
         HIP_TRY(c, hipMemcpy2DAsync(s->h_mask, L.W, s->d_sbytes, L.bpitch, L.W, (size_t)L.H * n,
-                                    hipMemcpyDeviceToHost, s->st));
+                                    hipMemcpyDeviceToHost, s->st2));
     }
-    HIP_TRY(c, hipEventRecord(s->ev[5], s->st));
+    HIP_TRY(c, hipEventRecord(s->ev[5], s->st2));
     HIP_TRY(c, hipEventSynchronize(s->ev[5]));
     (void)hipEventElapsedTime(&s->timings[0], s->ev[0], s->ev[1]);
     (void)hipEventElapsedTime(&s->timings[1], s->ev[1], s->ev[2]);
@@ -809,12 +838,12 @@ extern "C" int ffs_stack3d_add_batch(ffs_stack3d* st, ffs_stream* s) {
         sl.inten.resize(n);
         if (n) {
             HIP_TRY(c, hipMemcpyAsync(sl.k.data(), s->d_list_k + (size_t)f * c->cap, (size_t)n * 4,
-                                      hipMemcpyDeviceToHost, s->st));
+                                      hipMemcpyDeviceToHost, s->st2));
             HIP_TRY(c, hipMemcpyAsync(sl.inten.data(), s->d_list_i + (size_t)f * c->cap, (size_t)n * 4,
-                                      hipMemcpyDeviceToHost, s->st));
+                                      hipMemcpyDeviceToHost, s->st2));
         }
     }
-    HIP_TRY(c, hipStreamSynchronize(s->st));
+    HIP_TRY(c, hipStreamSynchronize(s->st2));
     return FFS_OK;
 }
 
