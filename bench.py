@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--workload", default="eiger16m", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=2, help="batches in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streamed", action="store_true",
+                    help="also time the PCIe-inclusive path (pinned host frames -> ffs_submit); reported as "
+                         "streamed_frames_per_s, never as `value`")
     args = ap.parse_args()
 
     import torch
@@ -215,6 +218,30 @@ def main():
     tm = streams[0].timings()
     traffic, traffic_src = pmc_traffic(args.workload, B)
 
+    streamed = None
+    if args.streamed:
+        # host frames in each stream's pinned staging buffer -> H2D + full hot path per batch
+        bufs = []
+        for st in streams:
+            hb = st.host_buffer()
+            hb[:B] = frames[:B]
+            bufs.append(hb)
+        n_st = max(4, args.steps // 2)
+        barrier()
+        ts = time.perf_counter()
+        inflight = []
+        for step in range(n_st + len(streams)):
+            if step < n_st:
+                i = step % len(streams)
+                if len(inflight) == len(streams):
+                    inflight.pop(0).wait()
+                streams[i].submit(bufs[i][:B], first_frame_id=step * B)
+                inflight.append(streams[i])
+            elif inflight:
+                inflight.pop(0).wait()
+        barrier()
+        streamed = n_st * B / (time.perf_counter() - ts)
+
     out = None
     if rank == 0:
         total_frames = world * args.steps * B
@@ -244,6 +271,11 @@ def main():
                          "exact_kernel_ms_per_launch": round(ms_exact, 4)},
             "stage_ms_last_batch": {k: round(v, 4) for k, v in tm.items()},
         }
+        # the whole threshold stage (candidate + exact kernels) against the same algorithmic bytes
+        out["roofline"]["threshold_stage_frac"] = round(
+            alg_bytes / ((ms_cand + ms_exact) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if streamed is not None:
+            out["streamed_frames_per_s"] = round(streamed * world, 1)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, mask)
         print(json.dumps(out), flush=True)
