@@ -549,7 +549,9 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     sa.max_sep = p.max_peak_centroid_separation;
     sa.recs = s->d_recs;
     sa.summary = s->d_summary;
-    const dim3 gseg(32, n), b256(256);
+    int gx = 32;
+    if (const char* e = std::getenv("FFS_CCL_GRID")) gx = std::max(1, std::atoi(e));
+    const dim3 gseg((unsigned)gx, n), b256(256);
     hipLaunchKernelGGL(k_union<false>, gseg, b256, 0, s->st2, sa);
     hipLaunchKernelGGL(k_label, dim3(n), dim3(1024), 0, s->st2, sa);
     hipLaunchKernelGGL(k_reduce<false>, gseg, b256, 0, s->st2, sa);

@@ -53,6 +53,17 @@ struct RowRegsU16 {
 
 __device__ __forceinline__ void unpack_u16(const RowRegsU16& r, uint32_t (&A)[8]) {
     const uint32_t w[4] = {r.raw.x, r.raw.y, r.raw.z, r.raw.w};
+    // Most wave-rows lie inside a detector module: all 512 pixels valid.  Then the word is just
+    // p | 2^22 (one op per pixel: v_and_or / v_alignbit) -- a wave-uniform shortcut, VALU only, so
+    // it does not disturb the counted s_waitcnt of the loads in flight.
+    if (__ballot(r.mb != 0xFFu) == 0ull) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            A[2 * q] = (w[q] & 0xFFFFu) | kFlag;
+            A[2 * q + 1] = __builtin_amdgcn_alignbit(kFlag >> 16, w[q], 16);  // (w >> 16) | 2^22
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t lo = (w[q] & 0xFFFFu) | kFlag;
@@ -111,7 +122,7 @@ __device__ __forceinline__ uint32_t group_tests8(const uint32_t (*q)[kQCap], int
 #pragma nounroll
     for (int t = 0; t < 7; ++t) wq += q[16 + t][e];
     uint32_t cb = 0;
-#pragma nounroll
+#pragma unroll 2
     for (int j = 0; j < 8; ++j) {
         const uint32_t W = q[j][e], A = q[8 + j][e];
         const uint32_t x = W & kXMask, m = W >> 22, pv = A & kXMask;
