@@ -493,6 +493,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     s->cur_pitch = pitch;
     s->cur_fstride = fstride;
 
+    (void)hipGetLastError();  // drop any stale error state: the check below is for OUR launches
     const ThresholdArgs ta = make_threshold_args(s, d_img, pitch, fstride, n);
     launch_candidates(s, ta, n);
     launch_exact(s, ta, n);

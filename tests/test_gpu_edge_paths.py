@@ -1,0 +1,82 @@
+"""GPU: the rarely taken paths -- dense candidates (LDS queue overflow in the candidate kernel, the
+chunked path of the exact kernel), capacity overflow errors, extreme shapes."""
+import numpy as np
+import pytest
+
+from util import assert_frame_matches_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("variant", ["0", "1"])
+@pytest.mark.parametrize("kind", ["single_photons", "uniform_noise", "stripes", "saturated_blocks"])
+def test_dense_candidate_frames(ffs, kind, variant, monkeypatch):
+    monkeypatch.setenv("FFS_K1_VARIANT", variant)
+    rng = np.random.default_rng(hash(kind) % 1000)
+    H, W = 300, 1300
+    if kind == "single_photons":       # every photon passes the signal test: ~3 % candidates
+        img = (rng.random((H, W)) < 0.03).astype(np.uint16)
+    elif kind == "uniform_noise":      # huge dispersion everywhere
+        img = rng.integers(0, 65536, (H, W)).astype(np.uint16)
+    elif kind == "stripes":            # every third column bright: queue bursts in every row
+        img = rng.poisson(1.0, (H, W)).astype(np.uint16)
+        img[:, ::3] += 40
+    else:                              # windows with sum >= 8192 skip the dispersion screen
+        img = rng.poisson(3.0, (H, W)).astype(np.uint16)
+        for _ in range(60):
+            y, x = rng.integers(0, H - 6), rng.integers(0, W - 6)
+            img[y:y + rng.integers(1, 6), x:x + rng.integers(1, 6)] = rng.integers(9000, 65536)
+    mask = (rng.random((H, W)) > 0.01).astype(np.uint8)
+    ctx = ffs.Context(W, H, np.uint16, max_strong_per_frame=W * H)
+    ctx.set_mask(mask)
+    ctx.set_params(want_strong_mask=1, want_strong_list=1)
+    fr = ctx.stream().process(img)[0]
+    assert_frame_matches_oracle(fr, img, mask)
+
+
+def test_capacity_overflow_is_an_error_not_a_crash(ffs):
+    rng = np.random.default_rng(3)
+    H, W = 120, 200
+    img = rng.poisson(1.0, (H, W)).astype(np.uint16)
+    img[::7, ::5] = 900                      # ~700 isolated strong pixels
+    ctx = ffs.Context(W, H, np.uint16, max_strong_per_frame=100)
+    st = ctx.stream()
+    with pytest.raises(ffs.FfsError) as e:
+        st.process(img)
+    assert e.value.code == -4                # FFS_ERR_OVERFLOW
+    # the stream stays usable
+    quiet = rng.poisson(1.0, (H, W)).astype(np.uint16)
+    quiet[50, 60:63] = 300
+    fr = st.process(quiet)[0]
+    assert 1 <= fr.num_strong_pixels <= 100
+
+
+@pytest.mark.parametrize("H,W", [(1, 1), (3, 5), (7, 9), (6, 700), (2000, 8), (40, 4097), (16, 10240)])
+def test_extreme_shapes(ffs, H, W):
+    rng = np.random.default_rng(H * 31 + W)
+    img = rng.poisson(2.0, (H, W)).astype(np.uint16)
+    img[rng.integers(0, H, 5), rng.integers(0, W, 5)] += 500
+    mask = np.ones((H, W), np.uint8)
+    ctx = ffs.Context(W, H, np.uint16)
+    ctx.set_params(want_strong_mask=1, want_strong_list=1, min_spot_size=1)
+    fr = ctx.stream().process(img)[0]
+    assert_frame_matches_oracle(fr, img, mask, min_spot_size=1)
+
+
+def test_bad_arguments_are_rejected(ffs):
+    with pytest.raises(ffs.FfsError):
+        ffs.Context(0, 10)
+    with pytest.raises(ffs.FfsError):
+        ffs.Context(20000, 10)
+    ctx = ffs.Context(64, 64, max_batch=2)
+    st = ctx.stream()
+    with pytest.raises(ffs.FfsError):
+        st.wait()                                            # nothing submitted
+    with pytest.raises(ffs.FfsError):
+        st.submit(np.zeros((3, 64, 64), np.uint16))          # more than max_batch
+    with pytest.raises(ffs.FfsError):
+        ctx.set_params(min_count=1)                          # standalone.cc:60 asserts min_count > 1
+    st.submit(np.zeros((64, 64), np.uint16))
+    with pytest.raises(ffs.FfsError):
+        st.submit(np.zeros((64, 64), np.uint16))             # batch already in flight
+    assert st.wait()[0].num_strong_pixels == 0
