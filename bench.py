@@ -129,7 +129,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("FFS_BENCH_FORCE_DIST"):  # the env var rehearses the RCCL path on one GPU
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -158,18 +158,22 @@ def main():
 
     from ffs_amd import dist as D
     gather_buf = None
-    spot_cap = 4096 * B
+    spot_cap = 2048 * B
+    pack_host = torch.empty((spot_cap + 1, 4), dtype=torch.float32).pin_memory() if (world > 1 or os.environ.get("FFS_BENCH_FORCE_DIST")) else None
+    pack_dev = None
 
-    def gather(results):
+    def gather(results, stream):
         """one RCCL collective per batch: padded all_gather of (frame_id, x, y, z) per spot
-        (ffs_amd/dist.py; the same code runs over gloo in tests/test_distributed_gloo.py)"""
-        nonlocal gather_buf
+        (ffs_amd/dist.py; the same layout runs over gloo in tests/test_distributed_gloo.py)"""
+        nonlocal gather_buf, pack_dev
         if dist is None:
             return
-        mine = torch.from_numpy(D.pack_spots(results, spot_cap)).to(dev, non_blocking=True)
+        D.pack_spots_batch(results, stream.last_batch_reflections, spot_cap, pack_host.numpy())
         if gather_buf is None:
             gather_buf = torch.empty((world * (spot_cap + 1), 4), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(gather_buf, mine)
+            pack_dev = torch.empty((spot_cap + 1, 4), dtype=torch.float32, device=dev)
+        pack_dev.copy_(pack_host, non_blocking=True)
+        dist.all_gather_into_tensor(gather_buf, pack_dev)
 
     def run_steps(k):
         """k steps, `streams` batches in flight"""
@@ -182,7 +186,7 @@ def main():
                 if len(inflight) == len(streams):
                     done = inflight.pop(0)
                     res = done.wait()
-                    gather(res)
+                    gather(res, done)
                     spots += sum(len(r.boxes) for r in res)
                 s.submit_device(ptr, pitch, fstride, B, first_frame_id=(rank * k + step) * B)
                 inflight.append(s)
@@ -190,7 +194,7 @@ def main():
             elif inflight:
                 done = inflight.pop(0)
                 res = done.wait()
-                gather(res)
+                gather(res, done)
                 spots += sum(len(r.boxes) for r in res)
         return spots
 

@@ -280,6 +280,7 @@ class Stream:
                  if nb.value else np.zeros(0, BOX_DT))
         refls = (np.frombuffer(C.string_at(rp, nr.value * REFL_DT.itemsize), REFL_DT)
                  if nr.value else np.zeros(0, REFL_DT))
+        self.last_batch_boxes, self.last_batch_reflections = boxes, refls   # whole-batch arrays
         want_refl = bool(self.ctx.params.want_reflections)
         want_list = bool(self.ctx.params.want_strong_list)
         out = []

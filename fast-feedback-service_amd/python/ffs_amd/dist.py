@@ -35,6 +35,23 @@ def pack_spots(results, cap: int) -> np.ndarray:
     return out
 
 
+def pack_spots_batch(results, refl_all: np.ndarray, cap: int, out: np.ndarray | None = None) -> np.ndarray:
+    """Same layout as pack_spots, built from the batch-wide reflection array a Stream keeps
+    (`stream.last_batch_reflections`: frame i's reflections follow frame i-1's) without a
+    per-frame loop over arrays.  `out` may be a reusable (cap + 1, 4) float32 buffer."""
+    if out is None:
+        out = np.empty((cap + 1, 4), np.float32)
+    counts = np.fromiter((len(r.reflections) for r in results), np.int64, len(results))
+    ids = np.fromiter((r.frame_id for r in results), np.float32, len(results))
+    n = int(min(counts.sum(), cap))
+    out[:n, 0] = np.repeat(ids, counts)[:n]
+    out[:n, 1] = refl_all["com_x"][:n]
+    out[:n, 2] = refl_all["com_y"][:n]
+    out[:n, 3] = refl_all["com_z"][:n]
+    out[cap] = (n, 0, 0, 0)
+    return out
+
+
 def unpack_spots(gathered: np.ndarray, world: int, cap: int):
     """-> {frame_id: (n,3) float32 centres} merged over ranks, insertion in frame order."""
     g = gathered.reshape(world, cap + 1, 4)

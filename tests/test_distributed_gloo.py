@@ -99,3 +99,21 @@ def test_frame_shard_partitions():
     for world in (1, 2, 3, 8):
         got = sorted(sum((D.frame_shard(37, r, world) for r in range(world)), []))
         assert got == list(range(37))
+
+
+def test_pack_spots_batch_equals_pack_spots():
+    from ffs_amd import dist as D
+    from oracle import oracle as O
+    rng = np.random.default_rng(0)
+    results, parts = [], []
+    for fid in (5, 6, 9):
+        n = int(rng.integers(0, 7))
+        refl = np.zeros(n, O.REFL_DT)
+        refl["com_x"], refl["com_y"], refl["com_z"] = rng.random(n), rng.random(n), 0.5
+        results.append(_Fr(fid, refl))
+        parts.append(refl)
+    allr = np.concatenate(parts)
+    a, b = D.pack_spots(results, 32), D.pack_spots_batch(results, allr, 32)
+    n = int(a[32, 0])
+    assert n == len(allr) == int(b[32, 0])
+    np.testing.assert_array_equal(a[:n], b[:n])      # rows beyond the count are don't-care
