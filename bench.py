@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--workload", default="eiger16m", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=2, help="batches in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-every", type=int, default=4,
+                    help="N>1: batches whose spot lists are gathered by one RCCL collective")
     ap.add_argument("--streamed", action="store_true",
                     help="also time the PCIe-inclusive path (pinned host frames -> ffs_submit); reported as "
                          "streamed_frames_per_s, never as `value`")
@@ -157,28 +159,40 @@ def main():
     streams = [ctx.stream() for _ in range(max(1, args.streams))]
 
     from ffs_amd import dist as D
-    gather_buf = None
+    # ---- N>1: gather of the per-frame spot lists -------------------------------------------------
+    # One RCCL collective per `gather_every` batches ("one small collective per batch of
+    # frames, not per frame"): every rank contributes a fixed-size block of (frame_id, x, y, z) rows.
+    use_dist = dist is not None
+    G = max(1, args.gather_every)
     spot_cap = 2048 * B
-    pack_host = torch.empty((spot_cap + 1, 4), dtype=torch.float32).pin_memory() if (world > 1 or os.environ.get("FFS_BENCH_FORCE_DIST")) else None
-    pack_dev = None
+    if use_dist:
+        pack_host = torch.empty((G, spot_cap + 1, 4), dtype=torch.float32).pin_memory()
+        pack_dev = torch.empty((G, spot_cap + 1, 4), dtype=torch.float32, device=dev)
+        gather_buf = torch.empty((world * G, spot_cap + 1, 4), dtype=torch.float32, device=dev)
+    pending = 0
+
+    def flush_gather():
+        nonlocal pending
+        if not use_dist or pending == 0:
+            return
+        for g in range(pending, G):      # unused slots of a partial group: zero spots
+            pack_host[g, spot_cap, 0] = 0
+        pack_dev.copy_(pack_host, non_blocking=True)
+        dist.all_gather_into_tensor(gather_buf.view(-1), pack_dev.view(-1))
+        pending = 0
 
     def gather(results, stream):
-        """one RCCL collective per batch: padded all_gather of (frame_id, x, y, z) per spot
-        (ffs_amd/dist.py; the same layout runs over gloo in tests/test_distributed_gloo.py)"""
-        nonlocal gather_buf, pack_dev
-        if dist is None:
+        nonlocal pending
+        if not use_dist:
             return
-        D.pack_spots_batch(results, stream.last_batch_reflections, spot_cap, pack_host.numpy())
-        if gather_buf is None:
-            gather_buf = torch.empty((world * (spot_cap + 1), 4), dtype=torch.float32, device=dev)
-            pack_dev = torch.empty((spot_cap + 1, 4), dtype=torch.float32, device=dev)
-        pack_dev.copy_(pack_host, non_blocking=True)
-        dist.all_gather_into_tensor(gather_buf, pack_dev)
+        D.pack_spots_batch(results, stream.last_batch_reflections, spot_cap, pack_host[pending].numpy())
+        pending += 1
+        if pending == G:
+            flush_gather()
 
     def run_steps(k):
         """k steps, `streams` batches in flight"""
         inflight = []
-        issued = 0
         spots = 0
         for step in range(k + len(streams)):
             if step < k:
@@ -190,12 +204,12 @@ def main():
                     spots += sum(len(r.boxes) for r in res)
                 s.submit_device(ptr, pitch, fstride, B, first_frame_id=(rank * k + step) * B)
                 inflight.append(s)
-                issued += 1
             elif inflight:
                 done = inflight.pop(0)
                 res = done.wait()
                 gather(res, done)
                 spots += sum(len(r.boxes) for r in res)
+        flush_gather()                   # every frame's spots are gathered before the clock stops
         return spots
 
     def barrier():
@@ -266,6 +280,7 @@ def main():
             "config": {"workload": f"{args.workload}: {W}x{H} {np.dtype(dt).name}, 7x7 dispersion window, "
                                    f"{B} frames/step/GPU resident in HBM, spots+centroids returned to host",
                        "frames_per_step_per_gpu": B, "streams": len(streams),
+                       "spot_gather": (f"RCCL all_gather every {G} batches" if use_dist else "none (single GPU)"),
                        "spots_per_frame": round(spots / max(1, args.steps * B), 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
