@@ -27,22 +27,33 @@ hip: $(PKG)/libffs_hip.so
 $(PKG)/libffs_hip.so: $(HIP_SRCS) $(HIP_HDRS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
 
-CLI_SRCS := $(wildcard $(PKG)/host/*.cc)
+# HDF5 (NXmx reader) is optional: used when its headers are found
+HDF5_PREFIX ?= /opt/conda
+ifneq ($(wildcard $(HDF5_PREFIX)/include/hdf5.h),)
+H5FLAGS := -DFFS_HAVE_HDF5 -I$(HDF5_PREFIX)/include
+H5LIBS  := $(HDF5_PREFIX)/lib/libhdf5.so -Wl,--enable-new-dtags,-rpath,$(HDF5_PREFIX)/lib
+endif
+# The reader lives in its own shared object so that only IT carries the HDF5 prefix as RUNPATH
+# (a conda prefix also ships an older libstdc++ that must not shadow the system one for HIP).
+H5_SRCS := $(PKG)/host/h5_reader.cc $(PKG)/host/h5_writer.cc
+$(PKG)/libffs_h5.so: $(H5_SRCS) $(PKG)/host/reader.hpp $(PKG)/host/codecs.hpp
+	$(CXX) -std=c++20 -O2 -fPIC -shared $(H5FLAGS) -I$(PKG)/host -o $@ $(H5_SRCS) $(H5LIBS)
+CLI_SRCS := $(filter-out $(H5_SRCS),$(wildcard $(PKG)/host/*.cc))
 CLI_HDRS := $(wildcard $(PKG)/host/*.hpp) $(wildcard include/*.h)
 cli: $(PKG)/bin/spotfinder $(PKG)/bin/ffs_hosttool
-$(PKG)/bin/ffs_hosttool: $(PKG)/tools/ffs_hosttool.cc $(PKG)/host/readers.cc $(CLI_HDRS) $(PKG)/libffs_synth.so
+$(PKG)/bin/ffs_hosttool: $(PKG)/tools/ffs_hosttool.cc $(PKG)/host/readers.cc $(CLI_HDRS) $(PKG)/libffs_synth.so $(PKG)/libffs_h5.so
 	mkdir -p $(PKG)/bin && $(CXX) -std=c++20 -O2 -Iinclude -I$(PKG)/host -o $@ $(PKG)/tools/ffs_hosttool.cc \
-	    $(PKG)/host/readers.cc -L$(PKG) -lffs_synth -Wl,-rpath,'$$ORIGIN/..'
+	    $(PKG)/host/readers.cc -L$(PKG) -lffs_synth -lffs_h5 -Wl,-rpath,'$$ORIGIN/..'
 
-$(PKG)/bin/spotfinder: $(CLI_SRCS) $(CLI_HDRS) $(PKG)/libffs_hip.so $(PKG)/libffs_synth.so
+$(PKG)/bin/spotfinder: $(CLI_SRCS) $(CLI_HDRS) $(PKG)/libffs_hip.so $(PKG)/libffs_synth.so $(PKG)/libffs_h5.so
 	@if [ -n "$(CLI_SRCS)" ]; then mkdir -p $(PKG)/bin && \
 	$(CXX) -std=c++20 -O2 -Iinclude -I$(PKG)/host -o $@ $(CLI_SRCS) \
-	    -L$(PKG) -lffs_hip -lffs_synth -Wl,-rpath,'$$ORIGIN/..' -lpthread -ldl && \
+	    -L$(PKG) -lffs_hip -lffs_synth -lffs_h5 -Wl,-rpath,'$$ORIGIN/..' -lpthread -ldl && \
 	ln -sf spotfinder $(PKG)/bin/spotfinder32; \
 	else echo "no CLI sources yet"; fi
 
 clean:
-	rm -f $(PKG)/libffs_hip.so $(PKG)/libffs_synth.so
+	rm -f $(PKG)/libffs_hip.so $(PKG)/libffs_synth.so $(PKG)/libffs_h5.so
 	rm -rf $(PKG)/bin
 	$(MAKE) -C oracle clean
 

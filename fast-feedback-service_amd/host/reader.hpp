@@ -41,6 +41,12 @@ class Reader {
 std::unique_ptr<Reader> make_synth_reader(const std::string& spec);
 std::unique_ptr<Reader> make_cbf_reader(const std::string& templ, size_t num_images, size_t first_index);
 std::unique_ptr<Reader> make_shm_reader(const std::string& dir);
+std::unique_ptr<Reader> make_h5_reader(const std::string& master_file);  // NXmx / Eiger HDF5
+bool h5_ready_for_read(const std::string& master_file);
+bool h5_supported();
+// fixture writer (ffs_hosttool mkh5): frames [0, n_written) get chunks, later ones stay unwritten
+void h5_write_nxmx(Reader& source, const std::string& master_file, const std::string& layout, size_t frames_per_file,
+                   size_t n_written);
 bool shm_ready_for_read(const std::string& dir);
 bool cbf_ready_for_read(const std::string& templ);
 

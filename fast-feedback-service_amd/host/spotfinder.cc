@@ -323,9 +323,8 @@ int main(int argc, char** argv) {
                 }
                 reader_ptr = make_cbf_reader(file, args.images, args.start_index);
             } else {
-                std::printf("Error: HDF5/NeXus input needs an HDF5-enabled build; this build reads /dev/shm "
-                            "directories, ####.cbf templates and synth: sources\n");
-                return 1;
+                wait_ready(file, h5_ready_for_read);
+                reader_ptr = make_h5_reader(file);
             }
         }
     } catch (const std::exception& e) {

@@ -4,6 +4,9 @@
 //                                         (start_1 JSON header, start_4, start_5 int32 mask,
 //                                         image_%06d_2 bitshuffle-LZ4 chunks; spotfinder/shmread.cc)
 //   ffs_hosttool mkcbf <synth:spec> <prefix>  write <prefix>0001.cbf ... (miniCBF, byte-offset codec)
+//   ffs_hosttool mkh5 <synth:spec> <master.h5> [layout [frames_per_file [n_written]]]
+//                                         NXmx master + data files (host/h5_writer.cc)
+//   ffs_hosttool h5info <master.h5>       what the HDF5 reader sees; synthinfo prints the same checksums
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -145,16 +148,78 @@ static int mkcbf(const std::string& spec, const std::string& prefix) {
     return 0;
 }
 
+// mkh5 <synth:spec> <master.h5> [layout [frames_per_file [n_written]]]
+static int mkh5(int argc, char** argv) {
+    auto r = make_synth_reader(argv[2]);
+    const std::string layout = argc > 4 ? argv[4] : "vds-links";
+    const size_t per_file = argc > 5 ? std::strtoull(argv[5], nullptr, 10) : 0;
+    const size_t n_written = argc > 6 ? std::strtoull(argv[6], nullptr, 10) : r->get_number_of_images();
+    h5_write_nxmx(*r, argv[3], layout, per_file, n_written);
+    return 0;
+}
+
+// h5info <master.h5>: what the H5 reader sees (metadata + per-frame availability and a pixel checksum)
+static int h5info(const std::string& file) {
+    auto r = make_h5_reader(file);
+    const size_t H = r->image_shape()[0], W = r->image_shape()[1], es = r->get_element_size();
+    std::printf("images %zu shape %zu %zu bytes %zu trusted %lld %lld\n", r->get_number_of_images(), H, W, es,
+                (long long)r->get_trusted_range()[0], (long long)r->get_trusted_range()[1]);
+    std::printf("wavelength %.6g distance %.6g pixel %.6g %.6g beam %.6g %.6g osc %.6g %.6g\n", *r->get_wavelength(),
+                *r->get_detector_distance(), (*r->get_pixel_size())[0], (*r->get_pixel_size())[1],
+                (*r->get_beam_center())[0], (*r->get_beam_center())[1], r->get_oscillation()[0], r->get_oscillation()[1]);
+    if (auto m = r->get_mask()) {
+        size_t valid = 0;
+        for (auto v : *m) valid += v;
+        std::printf("mask valid %zu\n", valid);
+    } else {
+        std::printf("mask none\n");
+    }
+    std::vector<uint8_t> chunk(W * H * es + 4096), px(W * H * es);
+    for (size_t i = 0; i < r->get_number_of_images(); ++i) {
+        if (!r->is_image_available(i)) {
+            std::printf("frame %zu unavailable\n", i);
+            continue;
+        }
+        auto c = r->get_raw_chunk(i, chunk);
+        if (c.size() < 12 || bshuf_decompress_lz4(c.data() + 12, c.size() - 12, px.data(), W * H, es) < 0)
+            return fail("chunk does not decode");
+        uint64_t h = 1469598103934665603ull;  // FNV-1a over the pixel bytes
+        for (auto b : px) h = (h ^ b) * 1099511628211ull;
+        std::printf("frame %zu chunk %zu fnv %016llx\n", i, c.size(), (unsigned long long)h);
+    }
+    return 0;
+}
+
+// synthinfo <synth:spec>: the same per-frame checksums straight from the synthetic source
+static int synthinfo(const std::string& spec) {
+    auto r = make_synth_reader(spec);
+    const size_t H = r->image_shape()[0], W = r->image_shape()[1], es = r->get_element_size();
+    std::vector<uint8_t> px(W * H * es);
+    for (size_t i = 0; i < r->get_number_of_images(); ++i) {
+        r->get_raw_chunk(i, px);
+        uint64_t h = 1469598103934665603ull;
+        for (auto b : px) h = (h ^ b) * 1099511628211ull;
+        std::printf("frame %zu fnv %016llx\n", i, (unsigned long long)h);
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const std::string cmd = argc > 1 ? argv[1] : "";
     try {
         if (cmd == "selftest") return selftest();
         if (cmd == "mkshm" && argc == 4) return mkshm(argv[2], argv[3]);
         if (cmd == "mkcbf" && argc == 4) return mkcbf(argv[2], argv[3]);
+        if (cmd == "mkh5" && argc >= 4) return mkh5(argc, argv);
+        if (cmd == "h5info" && argc == 3) return h5info(argv[2]);
+        if (cmd == "synthinfo" && argc == 3) return synthinfo(argv[2]);
+        if (cmd == "h5support") { std::printf("%d\n", h5_supported() ? 1 : 0); return 0; }
     } catch (const std::exception& e) {
         std::printf("Error: %s\n", e.what());
         return 1;
     }
-    std::printf("usage: ffs_hosttool selftest | mkshm <synth:spec> <dir> | mkcbf <synth:spec> <prefix>\n");
+    std::printf("usage: ffs_hosttool selftest | mkshm <synth:spec> <dir> | mkcbf <synth:spec> <prefix> |\n"
+                "       mkh5 <synth:spec> <master.h5> [vds-links|vds-files|plain [frames_per_file [n_written]]] |\n"
+                "       h5info <master.h5> | synthinfo <synth:spec> | h5support\n");
     return 2;
 }

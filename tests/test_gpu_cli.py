@@ -143,6 +143,48 @@ def test_shm_and_cbf_readers(tmp_path):
             assert got[i]["file"] == argv[0]
 
 
+@pytest.mark.parametrize("layout", ["vds-links", "plain"])
+def test_hdf5_nxmx_reader(tmp_path, layout):
+    """An NXmx master (virtual dataset over externally linked data files, or one chunked dataset)
+    gives the oracle's answers; wavelength/geometry come from the file so --dmin works unaided."""
+    N = 5
+    master = tmp_path / "coll_master.h5"
+    p = subprocess.run([TOOL, "mkh5", "synth:tiny:%d" % N, str(master), layout, "2"], capture_output=True, text=True)
+    if "HDF5-enabled" in p.stdout:
+        pytest.skip("built without HDF5")
+    assert p.returncode == 0, p.stdout
+    exp = expected(tiny_frames(N), np.ones((200, 300), np.uint8))
+    rc, out, err, lines = run_with_pipe([str(master), "--threads", "2", "--batch", "2"], tmp_path)
+    assert rc == 0 and not err, (out, err)
+    got = {json.loads(l)["file-number"]: json.loads(l) for l in lines}
+    assert sorted(got) == list(range(N))
+    for i, (cc, _) in enumerate(exp):
+        assert got[i]["num_strong_pixels"] == cc.num_strong_pixels
+        assert got[i]["n_spots_total"] == len(cc.boxes)
+        assert got[i]["file"] == str(master)
+    rc, out, err, lines = run_with_pipe([str(master), "--dmin", "40"], tmp_path)
+    assert rc == 0 and not err and len(lines) == N
+    assert sum(json.loads(l)["num_strong_pixels"] for l in lines) < sum(cc.num_strong_pixels for cc, _ in exp)
+
+
+def test_hdf5_rotation_sweep(tmp_path):
+    """omega in the master switches the driver to 3D spot finding, as for the synthetic sweep."""
+    master = tmp_path / "sweep_master.h5"
+    p = subprocess.run([TOOL, "mkh5", "synth:tinysweep:8", str(master), "vds-files", "3"], capture_output=True, text=True)
+    if "HDF5-enabled" in p.stdout:
+        pytest.skip("built without HDF5")
+    a = tmp_path / "a"
+    b = tmp_path / "b"
+    a.mkdir()
+    b.mkdir()
+    rc, out, err, _ = run_with_pipe([str(master), "--min-spot-size-3d", "2"], a)
+    assert rc == 0 and not err, (out, err)
+    rc2, out2, err2, _ = run_with_pipe(["synth:tinysweep:8", "--min-spot-size-3d", "2"], b)
+    assert rc2 == 0
+    assert (a / "3d_reflections.txt").read_text() == (b / "3d_reflections.txt").read_text()
+    assert re.search(spots_match_regex, strip_ansi(out)).group(1) == re.search(spots_match_regex, strip_ansi(out2)).group(1)
+
+
 def test_dtype_exit_code_protocol(tmp_path):
     """With --strict-dtype the binary follows the reference's protocol: exit code = bit depth of the
     data when it does not match the executable (spotfinder.cc:468-476; service.py:503-507)."""
