@@ -14,6 +14,7 @@
 #include "ffs_hip.h"
 #include "kernels_ccl.hpp"
 #include "kernels_threshold.hpp"
+#include "kernels_extended.hpp"
 
 using namespace ffsamd;
 
@@ -53,6 +54,7 @@ struct ffs_stream {
     uint8_t* d_img = nullptr;
     uint8_t* d_bits = nullptr;
     uint8_t* d_sbytes = nullptr;
+    uint8_t *d_dplane = nullptr, *d_eplane = nullptr;  // extended algorithm only (allocated on first use)
     uint32_t *d_tile_counts = nullptr, *d_tile_offsets = nullptr, *d_num_strong = nullptr, *d_row_off = nullptr;
     uint32_t *d_list_k = nullptr, *d_list_i = nullptr, *d_parent = nullptr, *d_comp_id = nullptr;
     uint32_t *d_n_comp = nullptr, *d_overflow = nullptr, *d_summary = nullptr;
@@ -106,6 +108,8 @@ extern "C" void ffs_default_params(ffs_params* p) {
     p->want_reflections = 1;
     p->want_strong_list = 0;
     p->want_strong_mask = 0;
+    p->algorithm = FFS_ALGO_DISPERSION;
+    p->extended_flavour = 0;
 }
 
 extern "C" int ffs_device_count(void) {
@@ -285,6 +289,11 @@ extern "C" int ffs_ctx_set_params(ffs_ctx* c, const ffs_params* p) {
         c->err = "ffs_ctx_set_params: need 2 <= min_count <= 49, nsig_b >= 0, nsig_s >= 0, threshold >= 0";
         return FFS_ERR_INVALID;  // the asserts of standalone.cc:52-63
     }
+    if ((p->algorithm != FFS_ALGO_DISPERSION && p->algorithm != FFS_ALGO_DISPERSION_EXTENDED)
+        || (p->extended_flavour != 0 && p->extended_flavour != 1)) {
+        c->err = "ffs_ctx_set_params: unknown algorithm / extended_flavour";
+        return FFS_ERR_INVALID;
+    }
     c->params = *p;
     return FFS_OK;
 }
@@ -308,7 +317,7 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     (void)hipSetDevice(s->ctx->device);
     if (s->st) (void)hipStreamSynchronize(s->st);
     if (s->st2 && s->st2 != s->st) { (void)hipStreamSynchronize(s->st2); (void)hipStreamDestroy(s->st2); }
-    void* dev[] = {s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_tile_offsets, s->d_num_strong,
+    void* dev[] = {s->d_dplane, s->d_eplane, s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_tile_offsets, s->d_num_strong,
                    s->d_list_k, s->d_list_i, s->d_parent, s->d_comp_id, s->d_n_comp, s->d_overflow,
                    s->d_summary, s->d_acc, s->d_recs};
     for (void* p : dev)
@@ -443,7 +452,44 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
         const char* v = std::getenv("FFS_K1_VARIANT");
         a.variant = v ? std::atoi(v) : 1;
     }
+    a.dplane = s->d_dplane;
+    a.eplane = s->d_eplane;
+    a.ext_flavour = p.extended_flavour;
+    a.ext_strips = (L.pitch_px + kExtOwnedPx - 1) / kExtOwnedPx;
+    {   // one pixel per lane: bands of 64..256 rows keep the 6-row warm-up below 10 %
+        long long er = ((long long)L.H * a.ext_strips * n_frames + 4 * target_waves - 1) / (4 * target_waves);
+        er = std::max<long long>(64, std::min<long long>(er, 256));
+        a.ext_band_rows = (int)er;
+        a.ext_bands = (L.H + a.ext_band_rows - 1) / a.ext_band_rows;
+    }
     return a;
+}
+
+// Extended dispersion: first pass -> erosion -> final threshold (kernels_extended.hpp).  Leaves the
+// strong plane in a.bits, the byte mask and the per-tile counts exactly as launch_exact does.
+static void launch_extended(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
+    const bool u16 = s->ctx->pixel_bytes == 2;
+    (void)hipMemsetAsync(a.strong_bytes, 0, (size_t)n_frames * a.bytes_frame_stride, s->st);
+    dim3 g1((unsigned)(a.ext_strips * a.ext_bands), n_frames);
+    if (u16) hipLaunchKernelGGL(k_ext_first<uint16_t>, g1, dim3(64), 0, s->st, a);
+    else hipLaunchKernelGGL(k_ext_first<uint32_t>, g1, dim3(64), 0, s->st, a);
+    const unsigned dpr = a.mpitch / 4;
+    hipLaunchKernelGGL(k_ext_erode, dim3((dpr + 255) / 256, (unsigned)a.H, n_frames), dim3(256), 0, s->st, a);
+    dim3 g3((unsigned)a.n_tiles, n_frames);
+    if (u16) hipLaunchKernelGGL(k_ext_final<uint16_t>, g3, dim3(256), 0, s->st, a);
+    else hipLaunchKernelGGL(k_ext_final<uint32_t>, g3, dim3(256), 0, s->st, a);
+}
+
+static int ensure_extended_buffers(ffs_stream* s) {
+    if (s->d_dplane) return FFS_OK;
+    ffs_ctx* c = s->ctx;
+    const size_t bytes = (size_t)c->max_batch * c->L.plane_frame_stride;
+    if (dmalloc(&s->d_dplane, bytes) != hipSuccess || dmalloc(&s->d_eplane, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        c->err = "hipMalloc(extended dispersion planes) failed";
+        return FFS_ERR_NOMEM;
+    }
+    return FFS_OK;
 }
 
 static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
@@ -494,9 +540,17 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     s->cur_fstride = fstride;
 
     (void)hipGetLastError();  // drop any stale error state: the check below is for OUR launches
+    if (p.algorithm == FFS_ALGO_DISPERSION_EXTENDED) {
+        const int rc = ensure_extended_buffers(s);
+        if (rc != FFS_OK) return rc;
+    }
     const ThresholdArgs ta = make_threshold_args(s, d_img, pitch, fstride, n);
-    launch_candidates(s, ta, n);
-    launch_exact(s, ta, n);
+    if (p.algorithm == FFS_ALGO_DISPERSION_EXTENDED) {
+        launch_extended(s, ta, n);
+    } else {
+        launch_candidates(s, ta, n);
+        launch_exact(s, ta, n);
+    }
     HIP_TRY(c, hipEventRecord(s->ev[2], s->st));
     if (s->st2 != s->st) HIP_TRY(c, hipStreamWaitEvent(s->st2, s->ev[2], 0));
 
@@ -744,6 +798,28 @@ extern "C" int ffs_stream_debug_planes(ffs_stream* s, const uint8_t** strong_byt
     if (strong_bytes) *strong_bytes = s->d_sbytes;
     if (mask_pitch) *mask_pitch = s->ctx->L.bpitch;
     if (mask_fstride) *mask_fstride = s->ctx->L.bytes_frame_stride;
+    return FFS_OK;
+}
+
+extern "C" int ffs_stream_debug_bitplane(ffs_stream* s, uint32_t frame, int which, uint8_t* host_out) {
+    if (!s || !host_out || which < 0 || which > 2) return FFS_ERR_INVALID;
+    ffs_ctx* c = s->ctx;
+    const Layout& L = c->L;
+    if (s->busy || frame >= c->max_batch) {
+        c->err = "ffs_stream_debug_bitplane: stream busy or frame out of range";
+        return FFS_ERR_INVALID;
+    }
+    const uint8_t* src = which == 0 ? s->d_bits : which == 1 ? s->d_dplane : s->d_eplane;
+    if (!src) {
+        c->err = "ffs_stream_debug_bitplane: that plane exists only after an extended-dispersion batch";
+        return FFS_ERR_INVALID;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<uint8_t> packed(L.plane_frame_stride);
+    HIP_TRY(c, hipMemcpy(packed.data(), src + (size_t)frame * L.plane_frame_stride, packed.size(), hipMemcpyDeviceToHost));
+    for (int y = 0; y < L.H; ++y)
+        for (int x = 0; x < L.W; ++x)
+            host_out[(size_t)y * L.W + x] = (packed[(size_t)y * L.mpitch + (x >> 3)] >> (x & 7)) & 1u;
     return FFS_OK;
 }
 

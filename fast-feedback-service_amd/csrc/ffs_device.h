@@ -55,6 +55,11 @@ struct ThresholdArgs {
     double nsig_b, nsig_s, threshold;
     long long max_valid;       // < 0: no test
     int variant;               // candidate kernel variant: 0 = per-pixel test, 1 = group screen + LDS queue
+    // extended dispersion (kernels_extended.hpp)
+    uint8_t* dplane;           // first-pass "not background" bit planes [n][H][mpitch]
+    uint8_t* eplane;           // eroded signal-region bit planes [n][H][mpitch]
+    int ext_strips, ext_band_rows, ext_bands;
+    int ext_flavour;           // 0 = baseline.cpp rules, 1 = device-kernel rules
 };
 
 // ---- strong-pixel lists and connected components -------------------------------------------------

@@ -1,0 +1,206 @@
+// kernels_extended.hpp (included by ffs_api.hip) -- the extended dispersion algorithm
+// (`-a dispersion_extended`) for gfx950.
+//
+// What the reference does: DispersionExtendedThreshold::threshold, baseline/spotfinder/baseline.cpp:730-761
+// (SAT -> dispersion mask -> erosion -> SAT over the eroded mask -> final threshold); on the device three
+// dense byte-mask kernels, spotfinder/kernels/thresholding.cu:253-342, erosion.cu:53-143,
+// thresholding.cu:360-491, each a shared-memory tile with a (2r+1)^2 loop per pixel.
+//
+// MI355X design: masks are bit planes (1 bit / pixel, as in the standard path), and only the first
+// pass is dense.
+//   X1 `k_ext_first`  streams the frame once: a wave64 marches down a 64-px column strip (one pixel per
+//      lane, 56 owned) with a 7-row register ring; exact integer column sums {n, sum p, sum p^2}
+//      slide vertically, the horizontal 7-tap comes from DPP wave shifts.  The oracle's fp64 test
+//      a > c runs only on lanes that a float32 form with an explicit error allowance cannot reject.
+//      Output: the "not background" plane D.
+//   X2 `k_ext_erode`  5x5 binary erosion of D on the bit planes (shifts + ANDs, 32 px per lane):
+//      the signal region E.  Pixels outside the image never erode; masked pixels erode
+//      (baseline.cpp:552-571) or are skipped (erosion.cu:101-105) according to the flavour.
+//   X3 `k_ext_final`  visits only the pixels of E (a few x the strong pixels): 11x11 sums of the
+//      valid pixels outside E, then mean + nsig_s sqrt(mean) in fp64 (baseline.cpp:580-645).  Same
+//      tile / compaction skeleton as the standard path's exact stage (exact_tile, MODE 1); it leaves
+//      the strong plane, the byte mask and the per-tile counts for the connected-components stage.
+#pragma once
+#include "kernels_threshold.hpp"
+
+namespace ffsamd {
+
+constexpr int kExtOwnedPx = 56;    // lanes 4..59 of a wave own output
+constexpr int kExtLaneOffset = 4;  // lane l sits on x = 56 * strip - 4 + l
+
+template <typename PixelT>
+__global__ __launch_bounds__(64) void k_ext_first(const ThresholdArgs a) {
+    const int lane = threadIdx.x;
+    const int strip = blockIdx.x % a.ext_strips;
+    const int band = blockIdx.x / a.ext_strips;
+    const int frame = blockIdx.y;
+    const int yb0 = band * a.ext_band_rows;
+    const int yb1 = min(yb0 + a.ext_band_rows, a.H);
+    const int x = strip * kExtOwnedPx - kExtLaneOffset + lane;
+    const bool in_x = x >= 0 && x < a.W;
+    const uint8_t* img = (const uint8_t*)a.image + (uint64_t)frame * a.frame_stride;
+    uint8_t* dplane = a.dplane + (uint64_t)frame * a.plane_frame_stride;
+
+    uint32_t ring_p[7];   // masked pixel value of the last 7 rows
+    uint32_t hist = 0;    // bit s: the pixel in ring slot s counted; bit 8+s: its mask bit
+#pragma unroll
+    for (int s = 0; s < 7; ++s) ring_p[s] = 0;
+    int cm = 0;                    // column sums over the 7-row window
+    uint32_t cx = 0;
+    unsigned long long cy = 0;
+    const int total = (yb1 - yb0) + 6;  // incoming rows yb0-3 .. yb1+2
+
+    for (int base = 0;; base += 7) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const int i = base + t;  // incoming row number; ring slot t
+            if (i >= total) return;
+            const int yin = yb0 - 3 + i;
+            uint32_t p = 0, mbit = 0;
+            if (in_x && yin >= 0 && yin < a.H) {
+                p = reinterpret_cast<const PixelT*>(img + (uint64_t)yin * a.pitch)[x];
+                mbit = (a.maskbits[(uint64_t)yin * a.mpitch + (x >> 3)] >> (x & 7)) & 1u;
+            }
+            // mm = mask && src < 2^24, baseline.cpp:379,391
+            const bool inc = mbit && (sizeof(PixelT) == 2 || p < (1u << 24));
+            const uint32_t pn = inc ? p : 0u, po = ring_p[t];
+            cm += (int)inc - (int)((hist >> t) & 1u);
+            cx += pn - po;
+            cy += (unsigned long long)pn * pn - (unsigned long long)po * po;
+            ring_p[t] = pn;
+            hist = (hist & ~(0x101u << t)) | ((uint32_t)inc << t) | (mbit << (8 + t));
+            if (i < 6) continue;  // window not full yet
+
+            // horizontal 7-tap: neighbours at distance 1..3 on both sides by repeated wave shifts
+            uint32_t wm = (uint32_t)cm, wx = cx;
+            unsigned long long wy = cy;
+            {
+                uint32_t lm = (uint32_t)cm, lx = cx, ll = (uint32_t)cy, lh = (uint32_t)(cy >> 32);
+                uint32_t rm = lm, rx = lx, rl = ll, rh = lh;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    lm = from_left(lm); lx = from_left(lx); ll = from_left(ll); lh = from_left(lh);
+                    rm = from_right(rm); rx = from_right(rx); rl = from_right(rl); rh = from_right(rh);
+                    wm += lm + rm;
+                    wx += lx + rx;
+                    wy += (((unsigned long long)lh << 32) | ll) + (((unsigned long long)rh << 32) | rl);
+                }
+            }
+            // centre row = incoming row i - 3 = ring slot (t + 4) % 7
+            constexpr int kDummy = 0;
+            (void)kDummy;
+            const int sc = (t + 4) % 7;
+            const uint32_t centre_mask = (hist >> (8 + sc)) & 1u;
+            const int m = (int)wm;
+            bool d_bit = false;
+            // baseline.cpp:469 (mask[k] && m >= min_count && x >= 0)
+            if (centre_mask && m >= a.min_count) {
+                // exact integers: a = m y - x^2 - x (m - 1)
+                const long long ai = (long long)((unsigned long long)m * wy) - (long long)((unsigned long long)wx * wx)
+                                     - (long long)((unsigned long long)wx * (unsigned)(m - 1));
+                // float32 screen with allowance: all roundings together stay below 2^-21 relative
+                const float af = (float)ai;
+                const float cf = (float)wx * (a.kB * __builtin_sqrtf(2.0f * (float)(m - 1)));
+                if (ai > 0 && af >= cf * (1.0f - 3.8146973e-06f)) {
+                    // :470-472, each operation rounded separately (contraction is off)
+                    const double md = (double)m, xd = (double)wx, yd = (double)wy;
+                    const double t0 = md * yd;
+                    const double t1 = xd * xd;
+                    const double t2 = xd * (md - 1.0);
+                    const double av = (t0 - t1) - t2;
+                    const double cv = (xd * a.nsig_b) * __builtin_sqrt(2.0 * (md - 1.0));
+                    d_bit = av > cv;
+                }
+                if (a.max_valid >= 0) {  // device kernels only, thresholding.cu:318-325
+                    const uint32_t pc = reinterpret_cast<const PixelT*>(img + (uint64_t)(yin - 3) * a.pitch)[x];
+                    if ((long long)pc > a.max_valid) d_bit = false;
+                }
+            }
+            const bool owned = lane >= kExtLaneOffset && lane < kExtLaneOffset + kExtOwnedPx;
+            const unsigned long long bal = __ballot(d_bit && owned) >> kExtLaneOffset;
+            const uint32_t bcol = (uint32_t)strip * (kExtOwnedPx / 8) + (uint32_t)lane;
+            if (lane < kExtOwnedPx / 8 && bcol < a.mpitch)
+                dplane[(uint64_t)(yin - 3) * a.mpitch + bcol] = (uint8_t)(bal >> (8 * lane));
+        }
+    }
+}
+template __global__ void k_ext_first<uint16_t>(const ThresholdArgs);
+template __global__ void k_ext_first<uint32_t>(const ThresholdArgs);
+
+// X2: 5x5 erosion on bit planes.  One lane per 32-pixel word.
+__global__ __launch_bounds__(256) void k_ext_erode(const ThresholdArgs a) {
+    const int dpr = (int)(a.mpitch >> 2);
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, frame = blockIdx.z;
+    if (w >= dpr) return;
+    const uint32_t* dp = reinterpret_cast<const uint32_t*>(a.dplane + (uint64_t)frame * a.plane_frame_stride);
+    const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.maskbits);
+    uint32_t* ep = reinterpret_cast<uint32_t*>(a.eplane + (uint64_t)frame * a.plane_frame_stride);
+    // word with "pixel may erode its neighbours" cleared: outside the image nothing erodes, and in
+    // the device flavour masked pixels do not either
+    auto solid = [&](int yy, int ww) -> uint32_t {
+        if (ww < 0 || ww >= dpr) return ~0u;
+        const int x0 = ww * 32;
+        uint32_t beyond = 0;  // bits at x >= W
+        if (x0 + 32 > a.W) beyond = x0 >= a.W ? ~0u : ~((1u << (a.W - x0)) - 1u);
+        uint32_t v = dp[(uint64_t)yy * dpr + ww] | beyond;
+        if (a.ext_flavour == 1) v |= ~mp[(uint64_t)yy * dpr + ww];
+        return v;
+    };
+    uint32_t keep = ~0u;
+#pragma unroll
+    for (int r = -2; r <= 2; ++r) {
+        const int yy = y + r;
+        if (yy < 0 || yy >= a.H) continue;
+        const uint32_t l = solid(yy, w - 1), c = solid(yy, w), rr = solid(yy, w + 1);
+        keep &= c & ((c << 1) | (l >> 31)) & ((c << 2) | (l >> 30)) & ((c >> 1) | (rr << 31)) & ((c >> 2) | (rr << 30));
+    }
+    ep[(uint64_t)y * dpr + w] = dp[(uint64_t)y * dpr + w] & keep;
+}
+
+// X3 predicate: baseline.cpp:580-645 for one pixel of the signal region E.
+template <typename PixelT>
+__device__ bool ext_final_strong(const ThresholdArgs& a, const uint8_t* img, const uint8_t* eplane, int x, int y) {
+    const int W = a.W, H = a.H;
+    const int xs = max(x - 5, 0), xe = min(x + 5, W - 1);  // kernel + 2, clipped (:591-598)
+    const int ncol = xe - xs + 1;
+    const int dpr = (int)(a.mpitch >> 2);
+    const int w0 = xs >> 5, sh = xs & 31;
+    const uint32_t colmask = (1u << ncol) - 1u;
+    uint32_t m2 = 0;
+    unsigned long long x2 = 0;
+    for (int yy = max(y - 5, 0); yy <= min(y + 5, H - 1); ++yy) {
+        const uint32_t* mrow = reinterpret_cast<const uint32_t*>(a.maskbits) + (uint64_t)yy * dpr;
+        const uint32_t* erow = reinterpret_cast<const uint32_t*>(eplane) + (uint64_t)yy * dpr;
+        const bool two = w0 + 1 < dpr;
+        const unsigned long long mw = (unsigned long long)mrow[w0] | (two ? (unsigned long long)mrow[w0 + 1] << 32 : 0ull);
+        const unsigned long long ew = (unsigned long long)erow[w0] | (two ? (unsigned long long)erow[w0 + 1] << 32 : 0ull);
+        // background for the second SAT: valid and not in the signal region (:552-571, :755)
+        uint32_t inc = (uint32_t)((mw & ~ew) >> sh) & colmask;
+        const PixelT* prow = reinterpret_cast<const PixelT*>(img + (uint64_t)yy * a.pitch) + xs;
+        while (inc) {
+            const int q = __ffs(inc) - 1;
+            inc &= inc - 1;
+            const uint32_t p = prow[q];
+            if (sizeof(PixelT) == 2 || p < (1u << 24)) {  // compute_sat's BIG, :379,391
+                m2 += 1;
+                x2 += p;
+            }
+        }
+    }
+    const uint32_t pc = reinterpret_cast<const PixelT*>(img + (uint64_t)y * a.pitch)[x];
+    if (a.ext_flavour == 1 && m2 == 0) return false;                     // thresholding.cu:472
+    if (a.max_valid >= 0 && (long long)pc > a.max_valid) return false;  // thresholding.cu:440-441
+    const double src = (double)pc;
+    const double mean = m2 >= 2 ? (double)x2 / (double)m2 : 0.0;        // :640
+    const bool global_mask = src > a.threshold;
+    const bool local_mask = src >= (mean + a.nsig_s * __builtin_sqrt(mean));
+    return global_mask && local_mask;
+}
+
+template <typename PixelT>
+__global__ __launch_bounds__(256) void k_ext_final(const ThresholdArgs a) { exact_tile<PixelT, 256, kExactListCap, 1>(a); }
+template __global__ void k_ext_final<uint16_t>(const ThresholdArgs);
+template __global__ void k_ext_final<uint32_t>(const ThresholdArgs);
+
+}  // namespace ffsamd

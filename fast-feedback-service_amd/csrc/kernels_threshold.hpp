@@ -602,7 +602,14 @@ __device__ bool exact_strong(const ThresholdArgs& a, const uint8_t* img, int x, 
     return av > cv && bv > dv;
 }
 
-template <typename PixelT, int NT, int LISTCAP>
+// extended algorithm's final test (kernels_extended.hpp)
+template <typename PixelT>
+__device__ bool ext_final_strong(const ThresholdArgs& a, const uint8_t* img, const uint8_t* eplane, int x, int y);
+
+// MODE 0: candidates come from (and strong pixels go back to) a.bits, predicate exact_strong.
+// MODE 1: extended algorithm -- candidates are the signal-region plane a.eplane (read-only: other
+//         tiles read it for their 11x11 windows), predicate ext_final_strong, result in a.bits.
+template <typename PixelT, int NT, int LISTCAP, int MODE = 0>
 __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
     // The stage is latency-bound (sparse gathers).  Measured dead ends: a smaller LDS footprint
     // (more tiles resident) and one-wave workgroups both made it slower.
@@ -619,12 +626,14 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
     const uint8_t* img = (const uint8_t*)a.image + (uint64_t)frame * a.frame_stride;
     uint32_t* gwords = reinterpret_cast<uint32_t*>(a.bits + (uint64_t)frame * a.plane_frame_stride
                                                    + (uint64_t)y0 * a.mpitch);
+    const uint8_t* eframe = MODE == 1 ? a.eplane + (uint64_t)frame * a.plane_frame_stride : nullptr;
+    const uint32_t* gin = MODE == 1 ? reinterpret_cast<const uint32_t*>(eframe + (uint64_t)y0 * a.mpitch) : gwords;
     uint8_t* sbytes = a.strong_bytes + (uint64_t)frame * a.bytes_frame_stride;
 
     if (tid == 0) { s_cnt = 0; s_total = 0; s_strong = 0; }
     uint32_t mine = 0;
     for (int g = tid; g < ndw; g += NT) {
-        const uint32_t w = gwords[g];
+        const uint32_t w = gin[g];
         s_words[g] = w;
         mine += __popc(w);
     }
@@ -634,6 +643,8 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
     const uint32_t total = s_total;  // block-uniform
     if (total == 0) {
         if (tid == 0) a.tile_counts[(uint64_t)frame * a.n_tiles + tile] = 0;
+        if constexpr (MODE == 1)
+            for (int g = tid; g < ndw; g += NT) gwords[g] = 0;
         return;
     }
 
@@ -652,7 +663,10 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
             const int row = g / dpr;
             const int x = (int)((g - row * dpr) * 32u + bit);
             const int y = y0 + row;
-            if (exact_strong<PixelT>(a, img, x, y)) {
+            bool strong;
+            if constexpr (MODE == 1) strong = ext_final_strong<PixelT>(a, img, eframe, x, y);
+            else strong = exact_strong<PixelT>(a, img, x, y);
+            if (strong) {
                 sbytes[(uint64_t)y * a.bpitch + x] = 1;
             } else {
                 atomicAnd(&s_words[g], ~(1u << bit));

@@ -259,14 +259,14 @@ int main(int argc, char** argv) {
     Args args = parse_args(argc, argv);
     const std::string file = args.file;
 
+    int algorithm = FFS_ALGO_DISPERSION;
     {  // DispersionAlgorithm, spotfinder.cc:180-203
         std::string lower = args.algorithm;
         std::transform(lower.begin(), lower.end(), lower.begin(), ::tolower);
         if (lower == "dispersion") std::printf("Algorithm: Dispersion\n");
         else if (lower == "dispersion_extended") {
             std::printf("Algorithm: Dispersion Extended\n");
-            std::printf("Error: the extended dispersion algorithm is not part of this build\n");
-            return 1;
+            algorithm = FFS_ALGO_DISPERSION_EXTENDED;
         } else {
             std::printf("Error: Invalid algorithm specified\n");
             return 1;
@@ -439,6 +439,7 @@ int main(int argc, char** argv) {
     prm.max_peak_centroid_separation = args.max_sep;
     prm.want_reflections = (!rotation && (args.save_h5 || args.output_for_index)) ? 1 : 0;
     prm.want_strong_mask = args.writeout ? 1 : 0;
+    prm.algorithm = algorithm;
     FFS_CHECK(ctx, ffs_ctx_set_params(ctx, &prm));
     if (args.validate)
         std::printf("Note: --validate is not linked into this build (the CPU baseline is test infrastructure: "

@@ -27,7 +27,10 @@ class Params(C.Structure):
                 ("min_spot_size", C.c_uint32), ("min_spot_size_3d", C.c_uint32),
                 ("max_peak_centroid_separation", C.c_float),
                 ("want_reflections", C.c_int32), ("want_strong_list", C.c_int32),
-                ("want_strong_mask", C.c_int32)]
+                ("want_strong_mask", C.c_int32), ("algorithm", C.c_int32), ("extended_flavour", C.c_int32)]
+
+
+ALGO_DISPERSION, ALGO_DISPERSION_EXTENDED = 0, 1
 
 
 class _Box(C.Structure):
@@ -70,7 +73,7 @@ EXPORTS = [
     "ffs_ctx_apply_resolution_mask", "ffs_ctx_get_mask", "ffs_ctx_set_params",
     "ffs_stream_create", "ffs_stream_destroy", "ffs_stream_host_buffer", "ffs_submit",
     "ffs_submit_device", "ffs_ctx_device_layout", "ffs_wait", "ffs_stream_batch_arrays", "ffs_stream_timings",
-    "ffs_bench_threshold", "ffs_stream_debug_planes", "ffs_selftest_sqrt", "ffs_stack3d_create",
+    "ffs_bench_threshold", "ffs_stream_debug_planes", "ffs_stream_debug_bitplane", "ffs_selftest_sqrt", "ffs_stack3d_create",
     "ffs_stack3d_destroy", "ffs_stack3d_add_batch", "ffs_stack3d_add_slice", "ffs_stack3d_finish",
 ]
 
@@ -109,6 +112,7 @@ def load_library():
                                           C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.ffs_stream_debug_planes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                               C.POINTER(C.c_size_t)]
+        L.ffs_stream_debug_bitplane.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.ffs_selftest_sqrt.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
         L.ffs_device_name.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         L.ffs_device_total_mem.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
@@ -326,6 +330,13 @@ class Stream:
                                                       frame_stride_bytes, n_frames, iters,
                                                       C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def debug_bitplane(self, frame_in_batch: int, which: int) -> np.ndarray:
+        """0 = strong plane, 1 = extended first pass, 2 = extended eroded signal region (H x W uint8)."""
+        out = np.empty((self.ctx.H, self.ctx.W), np.uint8)
+        self.ctx._check(self._lib.ffs_stream_debug_bitplane(self._h, frame_in_batch, which,
+                                                            out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def close(self):
         if self._h:

@@ -54,7 +54,15 @@ typedef struct {
     int32_t want_reflections; /* compute find_2d_components output per frame (spotfinder.cc:919-933) */
     int32_t want_strong_list; /* return the sparse strong-pixel list (k, intensity) per frame */
     int32_t want_strong_mask; /* return the dense W*H byte mask per frame (reference D2H, :887-897) */
+    int32_t algorithm;        /* FFS_ALGO_DISPERSION (default) or FFS_ALGO_DISPERSION_EXTENDED:
+                                 `--algorithm`, spotfinder.cc:338-342, 572-590 */
+    int32_t extended_flavour; /* extended only.  0 = baseline.cpp:730-761 rules (default); 1 = where the
+                                 device kernels differ structurally: erosion skips masked neighbours
+                                 (erosion.cu:101-105), second pass needs n > 0 (thresholding.cu:472) */
 } ffs_params;
+
+#define FFS_ALGO_DISPERSION 0
+#define FFS_ALGO_DISPERSION_EXTENDED 1
 
 void ffs_default_params(ffs_params *p);
 
@@ -177,6 +185,11 @@ int ffs_bench_threshold(ffs_stream *s, const void *device_pixels, size_t pitch_b
  * mask_pitch apart) -- for parity tests that want the raw kernel output. */
 int ffs_stream_debug_planes(ffs_stream *s, const uint8_t **device_strong_bytes,
                             size_t *mask_pitch, size_t *mask_frame_stride);
+/* Copies one frame's bit plane of the last completed batch to host memory, unpacked to W*H
+ * bytes (0/1): which = 0 strong pixels, 1 the extended algorithm's first-pass "not background"
+ * mask (first_pass_dispersion_result in the reference's --writeout, spotfinder.cu:268-279),
+ * 2 its eroded signal region (eroded_dispersion_result, :300-311). */
+int ffs_stream_debug_bitplane(ffs_stream *s, uint32_t frame_in_batch, int which, uint8_t *host_out);
 
 /* Known-answer self test of the one non-trivial fp64 operation the exact predicate relies on:
  * sum (mod 2^64) of the bit patterns of sqrt((double)n) for integers n in [begin, end), computed on

@@ -185,6 +185,253 @@ int ffs_oracle_dispersion_u32(const uint32_t *image, const uint8_t *mask, int wi
 }
 
 /* ---------------------------------------------------------------------------
+ * Extended dispersion: DispersionExtendedThreshold, baseline/spotfinder/baseline.cpp:325-776
+ * (the DIALS class; it does not compile here -- scitbx/dials headers -- so this part is a
+ * restatement from the text, "parity unpinned").  threshold() at :730-761 is
+ *   compute_sat(mask) -> compute_dispersion_threshold -> erode_dispersion_mask
+ *   -> compute_sat(eroded mask) -> compute_final_threshold.
+ * ------------------------------------------------------------------------- */
+
+/* the SAT window walk shared by baseline.cpp:432-467 and :597-626 (identical to
+ * standalone.cc:126-160 above) */
+static void sat_window(const sat_entry *table, size_t i, size_t j, int kxsize, int kysize,
+                       size_t xsize, size_t ysize, double *pm, double *px, double *py) {
+    int i0 = (int)i - kxsize - 1, i1 = (int)i + kxsize;
+    int j0 = (int)j - kysize - 1, j1 = (int)j + kysize;
+    i1 = i1 < (int)xsize ? i1 : (int)xsize - 1;
+    j1 = j1 < (int)ysize ? j1 : (int)ysize - 1;
+    long k0 = (long)j0 * (long)xsize;
+    long k1 = (long)j1 * (long)xsize;
+    double m = 0, x = 0, y = 0;
+    if (i0 >= 0 && j0 >= 0) {
+        const sat_entry *d00 = &table[k0 + i0];
+        const sat_entry *d10 = &table[k1 + i0];
+        const sat_entry *d01 = &table[k0 + i1];
+        m += d00->m - (d10->m + d01->m);
+        x += d00->x - (d10->x + d01->x);
+        y += d00->y - (d10->y + d01->y);
+    } else if (i0 >= 0) {
+        const sat_entry *d10 = &table[k1 + i0];
+        m -= d10->m;
+        x -= d10->x;
+        y -= d10->y;
+    } else if (j0 >= 0) {
+        const sat_entry *d01 = &table[k0 + i1];
+        m -= d01->m;
+        x -= d01->x;
+        y -= d01->y;
+    }
+    const sat_entry *d11 = &table[k1 + i1];
+    m += d11->m;
+    x += d11->x;
+    y += d11->y;
+    *pm = m;
+    *px = x;
+    *py = y;
+}
+
+/* compute_dispersion_threshold, baseline.cpp:415-475: dst = 1 where the window's index of
+ * dispersion is above the background threshold ("not background"). */
+static void ext_dispersion_threshold(const sat_entry *table, const double *src,
+                                     const uint8_t *mask, uint8_t *dst, size_t xsize,
+                                     size_t ysize, const ffs_oracle_disp_params *p,
+                                     double max_valid) {
+    size_t k = 0;
+    for (size_t j = 0; j < ysize; ++j) {
+        for (size_t i = 0; i < xsize; ++i, ++k) {
+            double m, x, y;
+            sat_window(table, i, j, p->kernel_half_x, p->kernel_half_y, xsize, ysize, &m, &x, &y);
+            dst[k] = 0; /* :468-473 */
+            if (mask[k] && m >= p->min_count && x >= 0) {
+                double a = m * y - x * x - x * (m - 1);
+                double c = x * p->nsig_b * sqrt(2 * (m - 1));
+                dst[k] = (a > c) ? 1 : 0;
+            }
+            /* the device kernels' validity guard (thresholding.cu:318-325): not in baseline.cpp,
+             * active only when the caller sets max_valid >= 0 */
+            if (max_valid >= 0 && src[k] > max_valid) dst[k] = 0;
+        }
+    }
+}
+
+/* chebyshev_distance(src, value, dst): DIALS dials/algorithms/image/filter/distance.h -- not
+ * under /root/reference (baseline.cpp:558 calls it).  Its published algorithm is the two-pass
+ * chamfer transform below, which yields the exact Chebyshev distance to the nearest pixel equal
+ * to `value`; pixels outside the image are not sources (distance height + width). */
+static void chebyshev_distance(const uint8_t *src, uint8_t value, int *dst, size_t xsize,
+                               size_t ysize) {
+    const int max_distance = (int)(xsize + ysize);
+    for (size_t j = 0; j < ysize; ++j) {
+        for (size_t i = 0; i < xsize; ++i) {
+            size_t k = j * xsize + i;
+            if ((src[k] != 0) == (value != 0)) {
+                dst[k] = 0;
+            } else {
+                int N = max_distance, NW = max_distance, NE = max_distance, W = max_distance;
+                if (j > 0) N = dst[k - xsize];
+                if (i > 0) W = dst[k - 1];
+                if (j > 0 && i > 0) NW = dst[k - xsize - 1];
+                if (j > 0 && i + 1 < xsize) NE = dst[k - xsize + 1];
+                int a = N < NW ? N : NW, b = NE < W ? NE : W;
+                dst[k] = 1 + (a < b ? a : b);
+            }
+        }
+    }
+    for (size_t j = ysize; j > 0; --j) {
+        for (size_t i = xsize; i > 0; --i) {
+            size_t k = (j - 1) * xsize + (i - 1);
+            int S = max_distance, SE = max_distance, SW = max_distance, E = max_distance;
+            if (j < ysize) S = dst[k + xsize];
+            if (i < xsize) E = dst[k + 1];
+            if (j < ysize && i < xsize) SE = dst[k + xsize + 1];
+            if (j < ysize && i > 1) SW = dst[k + xsize - 1];
+            int a = S < SE ? S : SE, b = SW < E ? SW : E;
+            int d = 1 + (a < b ? a : b);
+            if (d < dst[k]) dst[k] = d;
+        }
+    }
+}
+
+/* erode_dispersion_mask, baseline.cpp:552-571.  In: dst = 1 for "not background".  Out: dst = 1
+ * for every valid pixel that counts as background in the second pass, i.e. everything except
+ * the not-background pixels at Chebyshev distance >= min(kernel) = 3 from the nearest pixel that
+ * is not one (masked pixels included: their dst is 0). */
+static int ext_erode_baseline(const uint8_t *mask, uint8_t *dst, size_t xsize, size_t ysize,
+                              const ffs_oracle_disp_params *p) {
+    size_t n = xsize * ysize;
+    int *distance = (int *)malloc(n * sizeof(int));
+    if (!distance) return -1;
+    chebyshev_distance(dst, 0, distance, xsize, ysize);
+    int erosion_distance = p->kernel_half_x < p->kernel_half_y ? p->kernel_half_x : p->kernel_half_y;
+    for (size_t k = 0; k < n; ++k) {
+        if (mask[k])
+            dst[k] = !(dst[k] && distance[k] >= erosion_distance);
+        else
+            dst[k] = 0;
+    }
+    free(distance);
+    return 0;
+}
+
+/* The device flavour of the same step, spotfinder/kernels/erosion.cu:53-143: a not-background
+ * pixel is given back to the background when a VALID, in-image pixel within Chebyshev distance 2
+ * is background; masked neighbours are skipped (:101-105) instead of eroding.  Output in the
+ * baseline's polarity (1 = background for the second pass, 0 for masked pixels). */
+static int ext_erode_device(const uint8_t *mask, uint8_t *dst, size_t xsize, size_t ysize) {
+    size_t n = xsize * ysize;
+    uint8_t *first = (uint8_t *)malloc(n);
+    if (!first) return -1;
+    memcpy(first, dst, n);
+    for (size_t j = 0; j < ysize; ++j)
+        for (size_t i = 0; i < xsize; ++i) {
+            size_t k = j * xsize + i;
+            if (!first[k]) { /* :76-84 (then excluded again by the pixel mask in the second pass) */
+                dst[k] = mask[k] ? 1 : 0;
+                continue;
+            }
+            int erase = 0;
+            for (int dj = -2; dj <= 2 && !erase; ++dj)
+                for (int di = -2; di <= 2; ++di) {
+                    long lx = (long)i + di, ly = (long)j + dj;
+                    if (lx < 0 || ly < 0 || lx >= (long)xsize || ly >= (long)ysize) continue;
+                    size_t kk = (size_t)ly * xsize + (size_t)lx;
+                    if (mask[kk] == 0) continue;
+                    if (!first[kk]) {
+                        erase = 1;
+                        break;
+                    }
+                }
+            dst[k] = erase ? 1 : 0;
+        }
+    free(first);
+    return 0;
+}
+
+/* compute_final_threshold, baseline.cpp:580-645.  table = SAT over the eroded mask (m, x only);
+ * dst in: eroded mask, out: strong pixels.  kernel + 2 (:591-592). */
+static void ext_final_threshold(const sat_entry *table, const double *src, const uint8_t *mask,
+                                uint8_t *dst, size_t xsize, size_t ysize,
+                                const ffs_oracle_disp_params *p, int flavour, double max_valid) {
+    const int kxsize = p->kernel_half_x + 2, kysize = p->kernel_half_y + 2;
+    size_t k = 0;
+    for (size_t j = 0; j < ysize; ++j) {
+        for (size_t i = 0; i < xsize; ++i, ++k) {
+            double m, x, y;
+            sat_window(table, i, j, kxsize, kysize, xsize, ysize, &m, &x, &y);
+            (void)y;
+            int ok = mask[k] && m >= 0 && x >= 0; /* :636 */
+            if (flavour == 1 && !(m > 0)) ok = 0; /* thresholding.cu:472 `n > 0` */
+            if (max_valid >= 0 && src[k] > max_valid) ok = 0; /* thresholding.cu:440-441 */
+            if (ok) {
+                int dispersion_mask = !dst[k];
+                int global_mask = src[k] > p->threshold;
+                double mean = (m >= 2 ? (x / m) : 0);
+                int local_mask = src[k] >= (mean + p->nsig_s * sqrt(mean));
+                dst[k] = dispersion_mask && global_mask && local_mask;
+            } else {
+                dst[k] = 0;
+            }
+        }
+    }
+}
+
+int ffs_oracle_dispersion_extended_f64(const double *image, const uint8_t *mask, int width,
+                                       int height, const ffs_oracle_disp_params *pp, int flavour,
+                                       double max_valid, uint8_t *dst, uint8_t *dbg_first,
+                                       uint8_t *dbg_eroded) {
+    ffs_oracle_disp_params dflt;
+    if (!pp) {
+        ffs_oracle_default_disp_params(&dflt);
+        pp = &dflt;
+    }
+    size_t xsize = (size_t)width, ysize = (size_t)height, n = xsize * ysize;
+    sat_entry *table = (sat_entry *)malloc(n * sizeof(sat_entry));
+    if (!table) return -1;
+    int rc = 0;
+    compute_sat(table, image, mask, xsize, ysize);                               /* :744 */
+    ext_dispersion_threshold(table, image, mask, dst, xsize, ysize, pp, max_valid); /* :749 */
+    if (dbg_first) memcpy(dbg_first, dst, n);
+    rc = flavour == 1 ? ext_erode_device(mask, dst, xsize, ysize)
+                      : ext_erode_baseline(mask, dst, xsize, ysize, pp);         /* :752 */
+    if (rc == 0) {
+        if (dbg_eroded) /* 1 = pixel stays in the dispersion-masked (signal) region */
+            for (size_t k = 0; k < n; ++k) dbg_eroded[k] = mask[k] && !dst[k];
+        compute_sat(table, image, dst, xsize, ysize);                            /* :755 */
+        ext_final_threshold(table, image, mask, dst, xsize, ysize, pp, flavour, max_valid); /* :758 */
+    }
+    free(table);
+    return rc;
+}
+
+int ffs_oracle_dispersion_extended_u16(const uint16_t *image, const uint8_t *mask, int width,
+                                       int height, const ffs_oracle_disp_params *p, int flavour,
+                                       double max_valid, uint8_t *dst, uint8_t *dbg_first,
+                                       uint8_t *dbg_eroded) {
+    size_t n = (size_t)width * (size_t)height;
+    double *img = (double *)malloc(n * sizeof(double));
+    if (!img) return -1;
+    for (size_t i = 0; i < n; ++i) img[i] = (double)image[i];
+    int rc = ffs_oracle_dispersion_extended_f64(img, mask, width, height, p, flavour, max_valid, dst,
+                                                dbg_first, dbg_eroded);
+    free(img);
+    return rc;
+}
+
+int ffs_oracle_dispersion_extended_u32(const uint32_t *image, const uint8_t *mask, int width,
+                                       int height, const ffs_oracle_disp_params *p, int flavour,
+                                       double max_valid, uint8_t *dst, uint8_t *dbg_first,
+                                       uint8_t *dbg_eroded) {
+    size_t n = (size_t)width * (size_t)height;
+    double *img = (double *)malloc(n * sizeof(double));
+    if (!img) return -1;
+    for (size_t i = 0; i < n; ++i) img[i] = (double)image[i];
+    int rc = ffs_oracle_dispersion_extended_f64(img, mask, width, height, p, flavour, max_valid, dst,
+                                                dbg_first, dbg_eroded);
+    free(img);
+    return rc;
+}
+
+/* ---------------------------------------------------------------------------
  * Connected components.
  *
  * The reference builds a Boost adjacency_list whose vertex ids are assigned in

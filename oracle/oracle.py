@@ -102,6 +102,29 @@ def dispersion(image: np.ndarray, mask: np.ndarray, params: DispParams | None = 
     return dst
 
 
+def dispersion_extended(image: np.ndarray, mask: np.ndarray, params: DispParams | None = None, flavour: int = 0,
+                        max_valid: float = -1.0, debug: bool = False):
+    """Oracle extended-dispersion strong mask (baseline.cpp:730-761).  With debug=True also returns the
+    first-pass 'not background' mask and the eroded dispersion mask (1 = signal region)."""
+    image = np.ascontiguousarray(image)
+    H, W = image.shape
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    assert mask.shape == (H, W)
+    dst = np.empty((H, W), np.uint8)
+    first = np.empty((H, W), np.uint8) if debug else None
+    eroded = np.empty((H, W), np.uint8) if debug else None
+    fn = {np.dtype(np.uint16): lib().ffs_oracle_dispersion_extended_u16,
+          np.dtype(np.uint32): lib().ffs_oracle_dispersion_extended_u32,
+          np.dtype(np.float64): lib().ffs_oracle_dispersion_extended_f64}[image.dtype]
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
+                   C.c_void_p]
+    rc = fn(_ptr(image), _ptr(mask), W, H, C.byref(params) if params else None, flavour, max_valid, _ptr(dst),
+            _ptr(first) if debug else None, _ptr(eroded) if debug else None)
+    if rc != 0:
+        raise MemoryError("oracle extended dispersion failed")
+    return (dst, first, eroded) if debug else dst
+
+
 class PortSpotfinder:
     """Our restatement with the table kept across calls (for timing)."""
 

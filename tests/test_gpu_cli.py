@@ -177,12 +177,29 @@ def test_hdf5_rotation_sweep(tmp_path):
     b = tmp_path / "b"
     a.mkdir()
     b.mkdir()
-    rc, out, err, _ = run_with_pipe([str(master), "--min-spot-size-3d", "2"], a)
+    rc, out, err, _ = run_with_pipe([str(master), "--min-spot-size-3d", "2", "--writeout"], a)
     assert rc == 0 and not err, (out, err)
-    rc2, out2, err2, _ = run_with_pipe(["synth:tinysweep:8", "--min-spot-size-3d", "2"], b)
+    rc2, out2, err2, _ = run_with_pipe(["synth:tinysweep:8", "--min-spot-size-3d", "2", "--writeout"], b)
     assert rc2 == 0
     assert (a / "3d_reflections.txt").read_text() == (b / "3d_reflections.txt").read_text()
     assert re.search(spots_match_regex, strip_ansi(out)).group(1) == re.search(spots_match_regex, strip_ansi(out2)).group(1)
+
+
+def test_extended_algorithm_flag(tmp_path):
+    """`-a dispersion_extended` (spotfinder.cc:338-342): per-frame counts from the oracle's extended mask."""
+    from oracle import oracle as O
+    N = 3
+    frames = tiny_frames(N)
+    rc, out, err, lines = run_with_pipe(["synth:tiny:%d" % N, "-a", "Dispersion_Extended", "--threads", "2"], tmp_path)
+    assert rc == 0 and not err, (out, err)
+    assert "Algorithm: Dispersion Extended" in out
+    got = {json.loads(l)["file-number"]: json.loads(l) for l in lines}
+    mask = np.ones((200, 300), np.uint8)
+    for i, img in enumerate(frames):
+        strong = O.dispersion_extended(img, mask)
+        cc = O.cc2d(strong, img, 3)
+        assert got[i]["num_strong_pixels"] == cc.num_strong_pixels == int(strong.sum())
+        assert got[i]["n_spots_total"] == len(cc.boxes)
 
 
 def test_dtype_exit_code_protocol(tmp_path):

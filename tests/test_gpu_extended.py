@@ -1,0 +1,113 @@
+"""GPU parity for `-a dispersion_extended` (baseline/spotfinder/baseline.cpp:730-761): every stage of
+the HIP path -- first-pass mask, eroded signal region, strong pixels, components, centroids -- against the
+oracle on the same inputs, bit-exact, for both flavours, 16- and 32-bit pixels, masks, image edges,
+parameter changes and batches; then the full-size detector frame."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from util import assert_frame_matches_oracle, make_frame
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    dict(W=97, H=61, dtype=np.uint16, seed=1, n_spots=12),
+    dict(W=200, H=150, dtype=np.uint16, seed=2, n_spots=60, masked=True),
+    dict(W=130, H=90, dtype=np.uint32, seed=3, n_spots=20, masked=True),
+    dict(W=64, H=64, dtype=np.uint16, seed=4, n_spots=200),     # everything is "not background"
+    dict(W=40, H=9, dtype=np.uint16, seed=5, n_spots=4),        # shorter than the 11x11 window
+    dict(W=517, H=389, dtype=np.uint16, seed=6, n_spots=150, masked=True),
+    dict(W=1100, H=75, dtype=np.uint32, seed=7, n_spots=80, masked=True),
+    dict(W=56, H=300, dtype=np.uint16, seed=8, n_spots=30),     # exactly one strip wide
+    dict(W=57, H=130, dtype=np.uint16, seed=9, n_spots=20),     # one pixel into the second strip
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d-%s" % (c["W"], c["H"], np.dtype(c["dtype"]).name))
+@pytest.mark.parametrize("flavour", [0, 1])
+def test_every_stage_matches_oracle(ffs, case, flavour):
+    img, mask = make_frame(**case)
+    H, W = img.shape
+    ctx = ffs.Context(W, H, img.dtype, max_batch=2)
+    ctx.set_mask(mask)
+    ctx.set_params(algorithm=ffs.ALGO_DISPERSION_EXTENDED, extended_flavour=flavour, want_strong_mask=1,
+                   want_strong_list=1, want_reflections=1)
+    st = ctx.stream()
+    fr = st.process(img)[0]
+    strong, first, eroded = O.dispersion_extended(img, mask, flavour=flavour, debug=True)
+    got_first, got_eroded = st.debug_bitplane(0, 1), st.debug_bitplane(0, 2)
+    d = np.argwhere(got_first != first)
+    assert d.size == 0, f"first pass: {len(d)} mismatches, first at (y,x)={d[:5].tolist()}"
+    d = np.argwhere(got_eroded != eroded)
+    assert d.size == 0, f"erosion: {len(d)} mismatches, first at (y,x)={d[:5].tolist()}"
+    assert np.array_equal(st.debug_bitplane(0, 0), strong)
+    assert_frame_matches_oracle(fr, img, mask, strong=strong)
+
+
+def test_batch_of_different_frames_and_parameters(ffs):
+    W, H = 260, 140
+    frames, masks = zip(*[make_frame(W=W, H=H, seed=20 + i, n_spots=10 + 25 * i, masked=True) for i in range(4)])
+    mask = masks[0]
+    ctx = ffs.Context(W, H, np.uint16, max_batch=4)
+    ctx.set_mask(mask)
+    ctx.set_params(algorithm=ffs.ALGO_DISPERSION_EXTENDED, extended_flavour=1, min_count=3, nsig_b=4.0, nsig_s=2.5,
+                   max_valid=2000, want_strong_mask=1, want_strong_list=1, min_spot_size=2)
+    st = ctx.stream()
+    res = st.process(np.stack(frames), first_frame_id=3)
+    p = O.DispParams()
+    O.lib().ffs_oracle_default_disp_params(O.C.byref(p))
+    p.min_count, p.nsig_b, p.nsig_s = 3, 4.0, 2.5
+    total = 0
+    for fr, img in zip(res, frames):
+        strong = O.dispersion_extended(img, mask, p, flavour=1, max_valid=2000.0)
+        assert_frame_matches_oracle(fr, img, mask, min_spot_size=2, strong=strong)
+        total += int(strong.sum())
+    assert total > 0
+    # and back to the standard algorithm on the same stream
+    ctx.set_params(algorithm=ffs.ALGO_DISPERSION, extended_flavour=0, min_count=2, nsig_b=6.0, nsig_s=3.0, max_valid=-1,
+                   min_spot_size=3)
+    assert_frame_matches_oracle(st.process(frames[1])[0], frames[1], mask)
+
+
+def test_empty_and_fully_masked(ffs):
+    W, H = 90, 50
+    img, _ = make_frame(W=W, H=H, seed=40, n_spots=10)
+    ctx = ffs.Context(W, H, np.uint16, max_batch=1)
+    ctx.set_params(algorithm=ffs.ALGO_DISPERSION_EXTENDED, want_strong_mask=1)
+    st = ctx.stream()
+    assert_frame_matches_oracle(st.process(img)[0], img, np.ones((H, W), np.uint8),
+                                strong=O.dispersion_extended(img, np.ones((H, W), np.uint8)))
+    ctx.set_mask(np.zeros((H, W), np.uint8))
+    fr = st.process(img)[0]
+    assert fr.num_strong_pixels == 0 and fr.strong_mask.sum() == 0
+    ctx.set_mask(np.ones((H, W), np.uint8))
+    fr = st.process(np.zeros((H, W), np.uint16))[0]
+    assert fr.num_strong_pixels == 0
+
+
+def test_invalid_algorithm_is_rejected(ffs):
+    ctx = ffs.Context(64, 64, np.uint16, max_batch=1)
+    with pytest.raises(ffs.FfsError):
+        ctx.set_params(algorithm=7)
+    ctx.set_params(algorithm=0)
+    with pytest.raises(ffs.FfsError):
+        ctx.set_params(extended_flavour=2)
+
+
+def test_eiger16m_frame(ffs):
+    """Full detector size, module-gap mask: all three stages and the frame summary."""
+    from ffs_amd import synth
+    p = synth.eiger16m_params(seed=2100, n_spots=1200)
+    mask = synth.mask_eiger16m()
+    img = synth.frame(p, 0)
+    H, W = img.shape
+    ctx = ffs.Context(W, H, np.uint16, max_batch=1)
+    ctx.set_mask(mask)
+    ctx.set_params(algorithm=ffs.ALGO_DISPERSION_EXTENDED, want_strong_list=1)
+    st = ctx.stream()
+    fr = st.process(img)[0]
+    strong, first, eroded = O.dispersion_extended(img, mask, debug=True)
+    assert np.array_equal(st.debug_bitplane(0, 1), first)
+    assert np.array_equal(st.debug_bitplane(0, 2), eroded)
+    assert_frame_matches_oracle(fr, img, mask, strong=strong)
+    assert fr.num_strong_pixels > 1000

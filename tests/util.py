@@ -4,9 +4,24 @@ import numpy as np
 from oracle import oracle as O
 
 
-def oracle_frame(img, mask, min_spot_size=3, max_sep=2.0):
+def make_frame(W, H, dtype=np.uint16, seed=0, n_spots=20, masked=False, background=2.0, peak=(30.0, 3000.0)):
+    """One deterministic synthetic frame (+ mask: module gaps, dead pixels and a rectangle when masked)."""
+    from ffs_amd import synth
+    p = synth.params(W, H, dtype, seed=seed, background=background, n_spots=n_spots, sigma=(0.7, 1.8), peak=peak,
+                     max_value=65535 if dtype == np.uint16 else (1 << 20))
+    img = synth.frame(p, 0)
+    mask = np.ones((H, W), np.uint8)
+    if masked:
+        mask = synth.mask_modules(W, H, max(W // 3, 8), max(H // 2, 8), 3, 4)
+        mask = synth.mask_dead_pixels(mask, seed + 100, max(W * H // 400, 1))
+        mask = synth.mask_rect(mask, W // 5, W // 5 + 9, H // 4, H // 4 + 7)
+    return img, mask
+
+
+def oracle_frame(img, mask, min_spot_size=3, max_sep=2.0, strong=None):
     """Everything the reference's worker would know about one frame, from the oracle."""
-    strong = O.dispersion(img, mask)
+    if strong is None:
+        strong = O.dispersion(img, mask)
     cc = O.cc2d(strong, img, min_spot_size)
     refl = O.cc2d_reflections(cc.k, cc.intensity, img.shape[1], img.shape[0], min_spot_size, max_sep)
     return strong, cc, refl
@@ -29,8 +44,8 @@ def assert_reflections_equal(got, want, tol=0.0):
             np.testing.assert_allclose(got[f], want[f], rtol=0, atol=tol, err_msg=f)
 
 
-def assert_frame_matches_oracle(fr, img, mask, min_spot_size=3, max_sep=2.0):
-    strong, cc, refl = oracle_frame(img, mask, min_spot_size, max_sep)
+def assert_frame_matches_oracle(fr, img, mask, min_spot_size=3, max_sep=2.0, strong=None):
+    strong, cc, refl = oracle_frame(img, mask, min_spot_size, max_sep, strong)
     if fr.strong_mask is not None:
         diff = np.argwhere(fr.strong_mask != strong)
         assert diff.size == 0, f"{len(diff)} strong-mask mismatches, first at (y,x)={diff[:5].tolist()}"
