@@ -70,7 +70,7 @@ def pmc_traffic(workload, batch):
     return None, None
 
 
-def cpu_baseline(frames, mask, budget_s=20.0):
+def cpu_baseline(frames, mask, ext=False, budget_s=20.0):
     """Reference CPU path timed on this box's host cores: dispersion threshold by the
     reference's own standalone.cc when oracle/_ref is present (else our restatement), then the
     oracle's connected components; one frame per thread, the reference's threading model
@@ -79,7 +79,7 @@ def cpu_baseline(frames, mask, budget_s=20.0):
     from oracle import oracle as O
     H, W = mask.shape
     cores = max(1, min(os.cpu_count() or 1, 16, len(frames)))
-    kind = "reference" if O.have_ref() else "port"
+    kind = "reference" if O.have_ref() and not ext else "port"   # baseline.cpp's extended class needs DIALS
 
     def worker(idx_list):
         sf = O.RefSpotfinder(W, H) if kind == "reference" else O.PortSpotfinder(W, H)
@@ -88,8 +88,11 @@ def cpu_baseline(frames, mask, budget_s=20.0):
         t_end = time.perf_counter() + budget_s
         for i in idx_list:
             img = frames[i]
-            f64 = img.astype(np.float64)          # the reference converts too (spotfinder.cc:1024)
-            sf.run_f64(f64, mask, dst)
+            if ext:
+                dst = O.dispersion_extended(img, mask)
+            else:
+                f64 = img.astype(np.float64)          # the reference converts too (spotfinder.cc:1024)
+                sf.run_f64(f64, mask, dst)
             O.cc2d(dst, img, 3)
             done += 1
             if time.perf_counter() > t_end:
@@ -105,7 +108,7 @@ def cpu_baseline(frames, mask, budget_s=20.0):
     return {
         "value": round(done / dt, 3), "unit": "frames/s", "cores": cores, "kind": kind,
         "sample": f"{done} {W}x{H} frames of the same workload, one frame per thread on {cores} threads; "
-                  f"threshold = {'reference baseline/spotfinder/standalone.cc (oracle/_ref)' if kind == 'reference' else 'oracle port'}"
+                  f"threshold = {'reference baseline/spotfinder/standalone.cc (oracle/_ref)' if kind == 'reference' else 'oracle port' + (' of baseline.cpp DispersionExtendedThreshold' if ext else '')}"
                   f", connected components = oracle port (Boost.Graph absent); {dt:.1f} s wall",
     }
 
@@ -119,6 +122,9 @@ def main():
     ap.add_argument("--workload", default="eiger16m", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=2, help="batches in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--algorithm", default="dispersion", choices=["dispersion", "dispersion_extended"],
+                    help="dispersion = the headline metric; dispersion_extended = the second algorithm of the "
+                         "same CLI flag (SURVEY 8f), reported as its own metric")
     ap.add_argument("--gather-every", type=int, default=4,
                     help="N>1: batches whose spot lists are gathered by one RCCL collective")
     ap.add_argument("--streamed", action="store_true",
@@ -148,7 +154,8 @@ def main():
 
     ctx = ffs_amd.Context(W, H, dt, max_batch=B, device=local_rank)
     ctx.set_mask(mask)
-    ctx.set_params(want_reflections=1)
+    ext = args.algorithm == "dispersion_extended"
+    ctx.set_params(want_reflections=1, algorithm=1 if ext else 0)
     pitch, fstride = ctx.device_layout()
     # inputs resident in HBM, in the library's pitched layout
     host = np.zeros((B, H, pitch // np.dtype(dt).itemsize), dt)
@@ -234,7 +241,7 @@ def main():
     alg_bytes = float(W) * H * bytes_per_px * B
     achieved = alg_bytes / (ms_cand * 1e-3) / 1e9
     tm = streams[0].timings()
-    traffic, traffic_src = pmc_traffic(args.workload, B)
+    traffic, traffic_src = (None, None) if ext else pmc_traffic(args.workload, B)
 
     streamed = None
     if args.streamed:
@@ -264,8 +271,8 @@ def main():
     if rank == 0:
         total_frames = world * args.steps * B
         out = {
-            "metric": "detector frames/s (Eiger-16M 4362x4148 uint16)" if args.workload == "eiger16m"
-                      else f"detector frames/s ({args.workload})",
+            "metric": ("detector frames/s (Eiger-16M 4362x4148 uint16)" if args.workload == "eiger16m"
+                       else f"detector frames/s ({args.workload})") + (", extended dispersion" if ext else ""),
             "value": round(total_frames / elapsed, 2),
             "unit": "frames/s",
             "n_gpus": world,
@@ -277,7 +284,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u16" if dt == np.uint16 else "u32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {W}x{H} {np.dtype(dt).name}, 7x7 dispersion window, "
+            "config": {"workload": f"{args.workload}: {W}x{H} {np.dtype(dt).name}, "
+                                   + ("extended dispersion (7x7 first pass, 5x5 erosion, 11x11 second pass), " if ext
+                                      else "7x7 dispersion window, ") +
                                    f"{B} frames/step/GPU resident in HBM, spots+centroids returned to host",
                        "frames_per_step_per_gpu": B, "streams": len(streams),
                        "spot_gather": (f"RCCL all_gather every {G} batches" if use_dist else "none (single GPU)"),
@@ -285,7 +294,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel": "k_candidates", "ms_per_launch": round(ms_cand, 4),
+                         "kernel": "k_candidates_u16<ext>" if ext else "k_candidates", "ms_per_launch": round(ms_cand, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "exact_kernel_ms_per_launch": round(ms_exact, 4)},
             "stage_ms_last_batch": {k: round(v, 4) for k, v in tm.items()},
@@ -296,7 +305,7 @@ def main():
         if streamed is not None:
             out["streamed_frames_per_s"] = round(streamed * world, 1)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames, mask)
+            out["cpu_baseline"] = cpu_baseline(frames, mask, ext)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

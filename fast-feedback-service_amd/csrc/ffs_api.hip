@@ -455,6 +455,10 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
     a.dplane = s->d_dplane;
     a.eplane = s->d_eplane;
     a.ext_flavour = p.extended_flavour;
+    {
+        const char* v = std::getenv("FFS_EXT_VARIANT");
+        a.ext_variant = v ? std::atoi(v) : 1;
+    }
     a.ext_strips = (L.pitch_px + kExtOwnedPx - 1) / kExtOwnedPx;
     {   // one pixel per lane: bands of 64..256 rows keep the 6-row warm-up below 10 %
         long long er = ((long long)L.H * a.ext_strips * n_frames + 4 * target_waves - 1) / (4 * target_waves);
@@ -467,17 +471,38 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
 
 // Extended dispersion: first pass -> erosion -> final threshold (kernels_extended.hpp).  Leaves the
 // strong plane in a.bits, the byte mask and the per-tile counts exactly as launch_exact does.
-static void launch_extended(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
-    const bool u16 = s->ctx->pixel_bytes == 2;
-    (void)hipMemsetAsync(a.strong_bytes, 0, (size_t)n_frames * a.bytes_frame_stride, s->st);
+// First pass.  16-bit pixels: the streaming candidate kernel in its extended mode + the exact
+// dispersion test on its candidates (ext_variant 1, default); k_ext_first is the plain one-pixel-
+// per-lane kernel that computes the same plane directly (32-bit pixels, and FFS_EXT_VARIANT=0).
+static bool ext_fast_first(const ffs_stream* s, const ThresholdArgs& a) {
+    return s->ctx->pixel_bytes == 2 && a.ext_variant == 1;
+}
+static void launch_ext_first(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
+    if (ext_fast_first(s, a)) {
+        const int bands8 = (a.n_bands + 7) / 8 * 8;
+        hipLaunchKernelGGL((k_candidates_u16<true, true>), dim3((unsigned)(a.n_strips * bands8), n_frames), dim3(64), 0,
+                           s->st, a);
+        return;
+    }
     dim3 g1((unsigned)(a.ext_strips * a.ext_bands), n_frames);
-    if (u16) hipLaunchKernelGGL(k_ext_first<uint16_t>, g1, dim3(64), 0, s->st, a);
+    if (s->ctx->pixel_bytes == 2) hipLaunchKernelGGL(k_ext_first<uint16_t>, g1, dim3(64), 0, s->st, a);
     else hipLaunchKernelGGL(k_ext_first<uint32_t>, g1, dim3(64), 0, s->st, a);
-    const unsigned dpr = a.mpitch / 4;
-    hipLaunchKernelGGL(k_ext_erode, dim3((dpr + 255) / 256, (unsigned)a.H, n_frames), dim3(256), 0, s->st, a);
+}
+static void launch_ext_rest(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
+    const bool u16 = s->ctx->pixel_bytes == 2;
+    if (ext_fast_first(s, a))  // (the candidate kernel also zero-filled the byte mask)
+        hipLaunchKernelGGL(k_exact_disp<uint16_t>, dim3((unsigned)a.n_tiles, n_frames), dim3(256), 0, s->st, a);
+    else
+        (void)hipMemsetAsync(a.strong_bytes, 0, (size_t)n_frames * a.bytes_frame_stride, s->st);
+    const unsigned erode_lanes = (a.mpitch / 4) * (unsigned)((a.H + kErodeRows - 1) / kErodeRows);
+    hipLaunchKernelGGL(k_ext_erode, dim3((erode_lanes + 255) / 256, n_frames), dim3(256), 0, s->st, a);
     dim3 g3((unsigned)a.n_tiles, n_frames);
     if (u16) hipLaunchKernelGGL(k_ext_final<uint16_t>, g3, dim3(256), 0, s->st, a);
     else hipLaunchKernelGGL(k_ext_final<uint32_t>, g3, dim3(256), 0, s->st, a);
+}
+static void launch_extended(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
+    launch_ext_first(s, a, n_frames);
+    launch_ext_rest(s, a, n_frames);
 }
 
 static int ensure_extended_buffers(ffs_stream* s) {
@@ -835,16 +860,26 @@ extern "C" int ffs_bench_threshold(ffs_stream* s, const void* device_pixels, siz
     if (rc != FFS_OK) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     s->batch_params = c->params;
+    const bool ext = c->params.algorithm == FFS_ALGO_DISPERSION_EXTENDED;
+    if (ext) {
+        rc = ensure_extended_buffers(s);
+        if (rc != FFS_OK) return rc;
+    }
     const ThresholdArgs ta = make_threshold_args(s, device_pixels, pitch, fstride, n_frames);
-    // (1) `iters` launches of the candidate kernel back to back, HIP events on this stream
+    // (1) `iters` launches of the dense kernel (candidates / extended first pass) back to back, HIP
+    //     events on this stream
     HIP_TRY(c, hipEventRecord(s->ev[0], s->st));
-    for (uint32_t i = 0; i < iters; ++i) launch_candidates(s, ta, n_frames);
+    for (uint32_t i = 0; i < iters; ++i) ext ? launch_ext_first(s, ta, n_frames) : launch_candidates(s, ta, n_frames);
     HIP_TRY(c, hipEventRecord(s->ev[1], s->st));
-    // (2) candidate + exact pairs (the exact kernel filters the plane in place, so it must
-    //     always be preceded by the candidate kernel); exact = (pair - candidate)
+    // (2) dense + sparse stages together (the exact kernel filters the plane in place, so it must
+    //     always be preceded by the candidate kernel); sparse = (pair - dense)
     for (uint32_t i = 0; i < iters; ++i) {
-        launch_candidates(s, ta, n_frames);
-        launch_exact(s, ta, n_frames);
+        if (ext) {
+            launch_extended(s, ta, n_frames);
+        } else {
+            launch_candidates(s, ta, n_frames);
+            launch_exact(s, ta, n_frames);
+        }
     }
     HIP_TRY(c, hipEventRecord(s->ev[2], s->st));
     HIP_TRY(c, hipGetLastError());

@@ -60,6 +60,7 @@ struct ThresholdArgs {
     uint8_t* eplane;           // eroded signal-region bit planes [n][H][mpitch]
     int ext_strips, ext_band_rows, ext_bands;
     int ext_flavour;           // 0 = baseline.cpp rules, 1 = device-kernel rules
+    int ext_variant;           // first pass, 16-bit pixels: 1 = candidate kernel + exact stage, 0 = k_ext_first
 };
 
 // ---- strong-pixel lists and connected components -------------------------------------------------

@@ -127,35 +127,54 @@ __global__ __launch_bounds__(64) void k_ext_first(const ThresholdArgs a) {
 template __global__ void k_ext_first<uint16_t>(const ThresholdArgs);
 template __global__ void k_ext_first<uint32_t>(const ThresholdArgs);
 
-// X2: 5x5 erosion on bit planes.  One lane per 32-pixel word.
+// X2: 5x5 erosion on bit planes.  One lane per 32-pixel word column and band of kErodeRows rows:
+// the lane walks down its column with the horizontally eroded words of the last five rows in
+// registers, so every plane word is fetched once (plus its two neighbours, which the adjacent
+// lanes fetch as their own word: L1 hits).
+constexpr int kErodeRows = 32;
 __global__ __launch_bounds__(256) void k_ext_erode(const ThresholdArgs a) {
     const int dpr = (int)(a.mpitch >> 2);
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y, frame = blockIdx.z;
-    if (w >= dpr) return;
+    const int n_bands = (a.H + kErodeRows - 1) / kErodeRows;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int frame = blockIdx.y;
+    if (t >= dpr * n_bands) return;
+    const int w = t % dpr, band = t / dpr;
+    const int y0 = band * kErodeRows, y1 = min(y0 + kErodeRows, a.H);
     const uint32_t* dp = reinterpret_cast<const uint32_t*>(a.dplane + (uint64_t)frame * a.plane_frame_stride);
     const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.maskbits);
     uint32_t* ep = reinterpret_cast<uint32_t*>(a.eplane + (uint64_t)frame * a.plane_frame_stride);
-    // word with "pixel may erode its neighbours" cleared: outside the image nothing erodes, and in
-    // the device flavour masked pixels do not either
-    auto solid = [&](int yy, int ww) -> uint32_t {
-        if (ww < 0 || ww >= dpr) return ~0u;
-        const int x0 = ww * 32;
-        uint32_t beyond = 0;  // bits at x >= W
-        if (x0 + 32 > a.W) beyond = x0 >= a.W ? ~0u : ~((1u << (a.W - x0)) - 1u);
-        uint32_t v = dp[(uint64_t)yy * dpr + ww] | beyond;
-        if (a.ext_flavour == 1) v |= ~mp[(uint64_t)yy * dpr + ww];
-        return v;
+    // bits of this word column that lie beyond the image width: they never erode anything
+    const int x0 = w * 32;
+    const uint32_t beyond_c = x0 + 32 > a.W ? (x0 >= a.W ? ~0u : ~((1u << (a.W - x0)) - 1u)) : 0u;
+    const uint32_t beyond_r = x0 + 64 > a.W ? (x0 + 32 >= a.W ? ~0u : ~((1u << (a.W - x0 - 32)) - 1u)) : 0u;
+    const bool dev_rules = a.ext_flavour == 1;  // masked pixels do not erode either (erosion.cu:101-105)
+    // row yy of the plane with "does not erode its neighbours" pixels set, eroded horizontally by 2
+    auto hrow = [&](int yy, uint32_t& centre) -> uint32_t {
+        if (yy < 0 || yy >= a.H) { centre = 0; return ~0u; }
+        const uint32_t* row = dp + (uint64_t)yy * dpr;
+        const uint32_t* mrow = mp + (uint64_t)yy * dpr;
+        centre = row[w];
+        uint32_t c = centre | beyond_c, l = ~0u, r = ~0u;
+        if (w > 0) l = row[w - 1];
+        if (w + 1 < dpr) r = row[w + 1] | beyond_r;
+        if (dev_rules) {
+            c |= ~mrow[w];
+            if (w > 0) l |= ~mrow[w - 1];
+            if (w + 1 < dpr) r |= ~mrow[w + 1];
+        }
+        return c & ((c << 1) | (l >> 31)) & ((c << 2) | (l >> 30)) & ((c >> 1) | (r << 31)) & ((c >> 2) | (r << 30));
     };
-    uint32_t keep = ~0u;
-#pragma unroll
-    for (int r = -2; r <= 2; ++r) {
-        const int yy = y + r;
-        if (yy < 0 || yy >= a.H) continue;
-        const uint32_t l = solid(yy, w - 1), c = solid(yy, w), rr = solid(yy, w + 1);
-        keep &= c & ((c << 1) | (l >> 31)) & ((c << 2) | (l >> 30)) & ((c >> 1) | (rr << 31)) & ((c >> 2) | (rr << 30));
+    uint32_t h0, h1, h2, h3, h4, c2, c3, c4, dummy;
+    h0 = hrow(y0 - 2, dummy);
+    h1 = hrow(y0 - 1, dummy);
+    h2 = hrow(y0, c2);
+    h3 = hrow(y0 + 1, c3);
+    for (int y = y0; y < y1; ++y) {
+        h4 = hrow(y + 2, c4);
+        ep[(uint64_t)y * dpr + w] = c2 & h0 & h1 & h2 & h3 & h4;
+        h0 = h1; h1 = h2; h2 = h3; h3 = h4;
+        c2 = c3; c3 = c4;
     }
-    ep[(uint64_t)y * dpr + w] = dp[(uint64_t)y * dpr + w] & keep;
 }
 
 // X3 predicate: baseline.cpp:580-645 for one pixel of the signal region E.

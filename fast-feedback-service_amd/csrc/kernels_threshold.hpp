@@ -117,6 +117,8 @@ constexpr int kQCap = 64;        // lane-group queue entries per wave (8 KB of L
 constexpr int kQWords = 32;
 // Deliberately a rolled loop reading LDS word by word: the drain runs once per ~20 rows, and
 // keeping its live registers to a handful is what lets the streaming loop keep 4 waves per SIMD.
+// EXT (extended algorithm's first pass): the dispersion test alone decides.
+template <bool EXT>
 __device__ __forceinline__ uint32_t group_tests8(const uint32_t (*q)[kQCap], int e, float kS, float kB) {
     uint32_t wq = 0;  // window j sums cq[j .. j+6]
 #pragma nounroll
@@ -128,7 +130,7 @@ __device__ __forceinline__ uint32_t group_tests8(const uint32_t (*q)[kQCap], int
         const uint32_t x = W & kXMask, m = W >> 22, pv = A & kXMask;
         const int32_t b = (int32_t)(m * pv) - (int32_t)x;
         const float bf = (float)b, tf = (float)(x * m);
-        const bool sig = bf * __builtin_fabsf(bf) > kS * tf;
+        const bool sig = EXT || bf * __builtin_fabsf(bf) > kS * tf;
         const float mf = (float)m, xf = (float)x, yf = (float)wq;
         const float t0 = mf * yf;
         const float af = (t0 - xf * xf) - xf * (mf - 1.0f);
@@ -149,8 +151,13 @@ __device__ __forceinline__ uint32_t group_tests8(const uint32_t (*q)[kQCap], int
 //   the per-pixel signal AND dispersion tests on dense lanes (group_tests8).  The candidate plane
 //   then holds little more than the true strong pixels, so the exact kernel no longer re-reads the
 //   batch from HBM.  Both variants are supersets of the oracle's strong pixels.
-template <bool SCREEN>
+// EXT = true (needs SCREEN): first pass of the extended algorithm (baseline.cpp:415-475).  The plane
+//   written is a.dplane and holds candidates for "index of dispersion above background": the group
+//   screen bounds a = m y - x^2 - x (m-1) from above with the largest sum p^2 and the smallest sum p
+//   of the group's eight windows, queued groups take the per-pixel dispersion test.
+template <bool SCREEN, bool EXT = false>
 __global__ __launch_bounds__(64, 4) void k_candidates_u16(const ThresholdArgs a) {  // <= 128 VGPRs: 4 waves per SIMD
+    static_assert(SCREEN || !EXT, "the extended first pass is built on the screening variant");
     __shared__ uint32_t s_q[SCREEN ? kQWords : 1][SCREEN ? kQCap : 1];
 
     const int lane = threadIdx.x;
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(64, 4) void k_candidates_u16(const ThresholdArgs a)
     const rsrc_t r_mask = make_rsrc(a.maskbits, (uint32_t)a.H * a.mpitch);
     const rsrc_t r_sb = make_rsrc(a.strong_bytes + (uint64_t)frame * a.bytes_frame_stride,
                                   (uint32_t)a.H * a.bpitch);
-    const rsrc_t r_cb = make_rsrc(a.bits + (uint64_t)frame * a.plane_frame_stride,
+    const rsrc_t r_cb = make_rsrc((EXT ? a.dplane : a.bits) + (uint64_t)frame * a.plane_frame_stride,
                                   (uint32_t)a.H * a.mpitch);
     // Offsets with bit 31 set are out of range for every resource: such loads return 0 and such
     // stores are dropped.  Used instead of branches (inactive / not-owned lanes, rows outside the
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(64, 4) void k_candidates_u16(const ThresholdArgs a)
     int qn = 0;  // queued lane-groups (wave-uniform)
     auto drain = [&]() {
         if constexpr (SCREEN) if (lane < qn) {
-            const uint32_t cb = group_tests8(s_q, lane, kS, kB);
+            const uint32_t cb = group_tests8<EXT>(s_q, lane, kS, kB);
             const uint32_t tag = s_q[30][lane], row = tag >> 6, ln = tag & 63u;
             __builtin_amdgcn_raw_buffer_store_b8((uint8_t)cb, r_cb, row * a.mpitch + (uint32_t)(sx0 >> 3) + ln, 0, 0);
         }
@@ -311,12 +318,41 @@ __global__ __launch_bounds__(64, 4) void k_candidates_u16(const ThresholdArgs a)
                                               min(min(Wn[4], Wn[5]), min(Wn[6], Wn[7])));
                     const uint32_t wmax = max(max(max(Wn[0], Wn[1]), max(Wn[2], Wn[3])),
                                               max(max(Wn[4], Wn[5]), max(Wn[6], Wn[7])));
-                    const uint32_t amax = max(max(max(ring[sc][0], ring[sc][1]), max(ring[sc][2], ring[sc][3])),
-                                              max(max(ring[sc][4], ring[sc][5]), max(ring[sc][6], ring[sc][7])));
-                    const uint32_t x = wmin & kXMask, m = wmin >> 22, pv = amax & kXMask;
-                    const int32_t b = (int32_t)(m * pv) - (int32_t)x;
-                    const float bf = (float)b, tf = (float)(x * m);
-                    const bool pass = (bf * __builtin_fabsf(bf) > kS * tf) || ((wmin ^ wmax) >> 22) != 0;
+                    const uint32_t x = wmin & kXMask, m = wmin >> 22;
+                    bool pass;
+                    uint32_t QL5 = 0, QL6 = 0, QL7 = 0, QR0 = 0, QR1 = 0, QR2 = 0;
+                    if constexpr (EXT) {
+                        // the group's 14 column sums of p^2 (own 8 + 3 from each neighbour lane); the
+                        // eight window sums slide over them, only their maximum is kept
+                        QL5 = from_left(colq[5]); QL6 = from_left(colq[6]); QL7 = from_left(colq[7]);
+                        QR0 = from_right(colq[0]); QR1 = from_right(colq[1]); QR2 = from_right(colq[2]);
+                        uint32_t wq = (QL5 + QL6 + QL7) + (colq[0] + colq[1] + colq[2]) + colq[3];
+                        uint32_t ymax = wq;
+                        wq += colq[4] - QL5; ymax = max(ymax, wq);
+                        wq += colq[5] - QL6; ymax = max(ymax, wq);
+                        wq += colq[6] - QL7; ymax = max(ymax, wq);
+                        wq += colq[7] - colq[0]; ymax = max(ymax, wq);
+                        wq += QR0 - colq[1]; ymax = max(ymax, wq);
+                        wq += QR1 - colq[2]; ymax = max(ymax, wq);
+                        wq += QR2 - colq[3]; ymax = max(ymax, wq);
+                        // a_j <= m ymax - xmin^2 - xmin (m-1) and c_j >= nsig_b xmin sqrt(2 (m-1)) for
+                        // every pixel j of a group whose windows hold the same count m; float32 with
+                        // the same allowance as group_tests8.  The 32-bit sums of p^2 are exact while
+                        // x < 8192; brighter groups, and groups with unequal counts, always pass.
+                        const float mf = (float)m, xf = (float)x, yf = (float)ymax;
+                        const float t0 = mf * yf;
+                        const float af = (t0 - xf * xf) - xf * (mf - 1.0f);
+                        const float cf = xf * (kB * __builtin_sqrtf(2.0f * (mf - 1.0f)));
+                        pass = (af + t0 * 9.5367431640625e-07f >= cf) || (wmax & kXMask) >= 4096u
+                               || ((wmin ^ wmax) >> 22) != 0;
+                    } else {
+                        const uint32_t amax = max(max(max(ring[sc][0], ring[sc][1]), max(ring[sc][2], ring[sc][3])),
+                                                  max(max(ring[sc][4], ring[sc][5]), max(ring[sc][6], ring[sc][7])));
+                        const uint32_t pv = amax & kXMask;
+                        const int32_t b = (int32_t)(m * pv) - (int32_t)x;
+                        const float bf = (float)b, tf = (float)(x * m);
+                        pass = (bf * __builtin_fabsf(bf) > kS * tf) || ((wmin ^ wmax) >> 22) != 0;
+                    }
                     const bool flag = owned && pass;
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, so_bytes, 0);
                     // queued groups get their byte from drain(); everybody else stores 0 now
@@ -325,9 +361,11 @@ __global__ __launch_bounds__(64, 4) void k_candidates_u16(const ThresholdArgs a)
                     if (fm) {  // wave-uniform
                         const int nf = __popcll(fm);
                         if (qn + nf > kQCap) drain();
-                        // the group's 14 column sums of p^2 (own 8 + 3 from each neighbour lane)
-                        const uint32_t QL5 = from_left(colq[5]), QL6 = from_left(colq[6]), QL7 = from_left(colq[7]);
-                        const uint32_t QR0 = from_right(colq[0]), QR1 = from_right(colq[1]), QR2 = from_right(colq[2]);
+                        if constexpr (!EXT) {
+                            // the group's 14 column sums of p^2 (own 8 + 3 from each neighbour lane)
+                            QL5 = from_left(colq[5]); QL6 = from_left(colq[6]); QL7 = from_left(colq[7]);
+                            QR0 = from_right(colq[0]); QR1 = from_right(colq[1]); QR2 = from_right(colq[2]);
+                        }
                         if (flag) {
                             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32),
                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
@@ -361,6 +399,7 @@ rows_done:
 }
 template __global__ void k_candidates_u16<false>(const ThresholdArgs);
 template __global__ void k_candidates_u16<true>(const ThresholdArgs);
+template __global__ void k_candidates_u16<true, true>(const ThresholdArgs);
 
 // ================================================================================================
 // K1: candidates, uint32 pixels (the reference's PIXEL_DATA_32BIT build, h5read.h:16-20)
@@ -528,7 +567,8 @@ __global__ __launch_bounds__(64) void k_candidates_u32(const ThresholdArgs a) {
 // Exact integer window sums + the oracle predicate, standalone.cc:113-174 operation for operation.
 // All seven window rows (pixels and mask bits) are requested before any is used, so a candidate
 // costs one memory round trip, not seven.
-template <typename PixelT>
+// DISP_ONLY: the extended algorithm's first pass (baseline.cpp:468-473) -- same sums, a > c alone.
+template <typename PixelT, bool DISP_ONLY = false>
 __device__ bool exact_strong(const ThresholdArgs& a, const uint8_t* img, int x, int y) {
     const int W = a.W, H = a.H;
     const int xs = max(x - 3, 0), xe = min(x + 3, W - 1);  // window clipped to the image, :126-130
@@ -588,7 +628,7 @@ __device__ bool exact_strong(const ThresholdArgs& a, const uint8_t* img, int x, 
 
     // :165  mask[k] && m >= min_count && x >= 0 && src[k] > threshold
     const double src = (double)pc;
-    if (!(centre_valid && (int)m >= a.min_count && src > a.threshold)) return false;
+    if (!(centre_valid && (int)m >= a.min_count && (DISP_ONLY || src > a.threshold))) return false;
     if (a.max_valid >= 0 && (long long)pc > a.max_valid) return false;  // GPU reference only, thresholding.cu:208-215
     const double md = (double)m, xd = (double)sx, yd = (double)sy;
     // :166-170, each operation rounded separately (contraction is off for this library)
@@ -599,6 +639,7 @@ __device__ bool exact_strong(const ThresholdArgs& a, const uint8_t* img, int x, 
     const double bv = md * src - xd;
     const double cv = (xd * a.nsig_b) * __builtin_sqrt(2.0 * (md - 1.0));
     const double dv = a.nsig_s * __builtin_sqrt(xd * md);
+    if constexpr (DISP_ONLY) return av > cv;
     return av > cv && bv > dv;
 }
 
@@ -609,6 +650,8 @@ __device__ bool ext_final_strong(const ThresholdArgs& a, const uint8_t* img, con
 // MODE 0: candidates come from (and strong pixels go back to) a.bits, predicate exact_strong.
 // MODE 1: extended algorithm -- candidates are the signal-region plane a.eplane (read-only: other
 //         tiles read it for their 11x11 windows), predicate ext_final_strong, result in a.bits.
+// MODE 2: extended algorithm's first pass after k_candidates_u16<true, true>: a.dplane filtered in
+//         place by the exact dispersion test; no byte mask.
 template <typename PixelT, int NT, int LISTCAP, int MODE = 0>
 __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
     // The stage is latency-bound (sparse gathers).  Measured dead ends: a smaller LDS footprint
@@ -624,7 +667,7 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
     const int dpr = a.mpitch >> 2;  // dwords per row
     const int ndw = rows * dpr;
     const uint8_t* img = (const uint8_t*)a.image + (uint64_t)frame * a.frame_stride;
-    uint32_t* gwords = reinterpret_cast<uint32_t*>(a.bits + (uint64_t)frame * a.plane_frame_stride
+    uint32_t* gwords = reinterpret_cast<uint32_t*>((MODE == 2 ? a.dplane : a.bits) + (uint64_t)frame * a.plane_frame_stride
                                                    + (uint64_t)y0 * a.mpitch);
     const uint8_t* eframe = MODE == 1 ? a.eplane + (uint64_t)frame * a.plane_frame_stride : nullptr;
     const uint32_t* gin = MODE == 1 ? reinterpret_cast<const uint32_t*>(eframe + (uint64_t)y0 * a.mpitch) : gwords;
@@ -642,7 +685,7 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
     __syncthreads();
     const uint32_t total = s_total;  // block-uniform
     if (total == 0) {
-        if (tid == 0) a.tile_counts[(uint64_t)frame * a.n_tiles + tile] = 0;
+        if (MODE != 2 && tid == 0) a.tile_counts[(uint64_t)frame * a.n_tiles + tile] = 0;
         if constexpr (MODE == 1)
             for (int g = tid; g < ndw; g += NT) gwords[g] = 0;
         return;
@@ -665,9 +708,10 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
             const int y = y0 + row;
             bool strong;
             if constexpr (MODE == 1) strong = ext_final_strong<PixelT>(a, img, eframe, x, y);
+            else if constexpr (MODE == 2) strong = exact_strong<PixelT, true>(a, img, x, y);
             else strong = exact_strong<PixelT>(a, img, x, y);
             if (strong) {
-                sbytes[(uint64_t)y * a.bpitch + x] = 1;
+                if constexpr (MODE != 2) sbytes[(uint64_t)y * a.bpitch + x] = 1;
             } else {
                 atomicAnd(&s_words[g], ~(1u << bit));
             }
@@ -709,7 +753,7 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
     }
     if (cnt) atomicAdd(&s_strong, cnt);
     __syncthreads();
-    if (tid == 0) a.tile_counts[(uint64_t)frame * a.n_tiles + tile] = s_strong;
+    if (MODE != 2 && tid == 0) a.tile_counts[(uint64_t)frame * a.n_tiles + tile] = s_strong;
 }
 
 // NB: __launch_bounds__ must be a literal here -- with a template parameter hipcc 7.2 silently
@@ -722,4 +766,8 @@ __global__ __launch_bounds__(64) void k_exact_w64(const ThresholdArgs a) { exact
 template __global__ void k_exact<uint16_t>(const ThresholdArgs);
 template __global__ void k_exact<uint32_t>(const ThresholdArgs);
 template __global__ void k_exact_w64<uint16_t>(const ThresholdArgs);
+// extended first pass, exact stage (many more candidates per tile than the standard path)
+template <typename PixelT>
+__global__ __launch_bounds__(256) void k_exact_disp(const ThresholdArgs a) { exact_tile<PixelT, 256, kExactListCap, 2>(a); }
+template __global__ void k_exact_disp<uint16_t>(const ThresholdArgs);
 }  // namespace ffsamd

@@ -20,12 +20,20 @@ CASES = [
     dict(W=1100, H=75, dtype=np.uint32, seed=7, n_spots=80, masked=True),
     dict(W=56, H=300, dtype=np.uint16, seed=8, n_spots=30),     # exactly one strip wide
     dict(W=57, H=130, dtype=np.uint16, seed=9, n_spots=20),     # one pixel into the second strip
+    dict(W=1030, H=64, dtype=np.uint16, seed=10, n_spots=60, masked=True, peak=(2000.0, 60000.0)),  # x >= 8192 windows
+    dict(W=300, H=200, dtype=np.uint16, seed=11, n_spots=40, background=400.0),   # bright background
 ]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d-%s" % (c["W"], c["H"], np.dtype(c["dtype"]).name))
 @pytest.mark.parametrize("flavour", [0, 1])
-def test_every_stage_matches_oracle(ffs, case, flavour):
+@pytest.mark.parametrize("variant", ["1", "0"])
+def test_every_stage_matches_oracle(ffs, case, flavour, variant, monkeypatch):
+    # FFS_EXT_VARIANT: 1 = candidate kernel in extended mode + exact stage (16-bit default),
+    # 0 = the one-pixel-per-lane first-pass kernel (what 32-bit pixels always use)
+    monkeypatch.setenv("FFS_EXT_VARIANT", variant)
+    if variant == "0" and case["dtype"] == np.uint32:
+        pytest.skip("32-bit pixels have one first-pass kernel")
     img, mask = make_frame(**case)
     H, W = img.shape
     ctx = ffs.Context(W, H, img.dtype, max_batch=2)
