@@ -15,6 +15,7 @@
 #include "kernels_ccl.hpp"
 #include "kernels_threshold.hpp"
 #include "kernels_extended.hpp"
+#include "kernels_decode.hpp"
 
 using namespace ffsamd;
 
@@ -55,6 +56,9 @@ struct ffs_stream {
     uint8_t* d_bits = nullptr;
     uint8_t* d_sbytes = nullptr;
     uint8_t *d_dplane = nullptr, *d_eplane = nullptr;  // extended algorithm only (allocated on first use)
+    uint8_t* d_comp = nullptr;                         // compressed chunks (allocated on first use)
+    uint2 *d_tab = nullptr, *h_tab = nullptr;          // per-block (offset, length) tables
+    uint32_t dec_blocks = 0, dec_last = 0, dec_tail = 0, dec_block_elems = 0;
     uint32_t *d_tile_counts = nullptr, *d_tile_offsets = nullptr, *d_num_strong = nullptr, *d_row_off = nullptr;
     uint32_t *d_list_k = nullptr, *d_list_i = nullptr, *d_parent = nullptr, *d_comp_id = nullptr;
     uint32_t *d_n_comp = nullptr, *d_overflow = nullptr, *d_summary = nullptr;
@@ -317,12 +321,12 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     (void)hipSetDevice(s->ctx->device);
     if (s->st) (void)hipStreamSynchronize(s->st);
     if (s->st2 && s->st2 != s->st) { (void)hipStreamSynchronize(s->st2); (void)hipStreamDestroy(s->st2); }
-    void* dev[] = {s->d_dplane, s->d_eplane, s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_tile_offsets, s->d_num_strong,
+    void* dev[] = {s->d_comp, s->d_tab, s->d_dplane, s->d_eplane, s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_tile_offsets, s->d_num_strong,
                    s->d_list_k, s->d_list_i, s->d_parent, s->d_comp_id, s->d_n_comp, s->d_overflow,
                    s->d_summary, s->d_acc, s->d_recs};
     for (void* p : dev)
         if (p) (void)hipFree(p);
-    void* host[] = {s->h_img, s->h_counts, s->h_recs, s->h_list_k, s->h_list_i, s->h_mask};
+    void* host[] = {s->h_tab, s->h_img, s->h_counts, s->h_recs, s->h_list_k, s->h_list_i, s->h_mask};
     for (void* p : host)
         if (p) (void)hipHostFree(p);
     for (auto& e : s->ev)
@@ -393,7 +397,8 @@ extern "C" int ffs_stream_create(ffs_ctx* c, ffs_stream** out) {
     STREAM_TRY(dmalloc(&s->d_summary, B * 8 * 4));
     STREAM_TRY(dmalloc(&s->d_acc, B * (size_t)c->max_comp * sizeof(CompAcc)));
     STREAM_TRY(dmalloc(&s->d_recs, B * (size_t)c->max_comp * sizeof(ReflOut)));
-    s->h_img_bytes = B * (size_t)L.W * L.H * c->pixel_bytes;
+    // raw frames, or bitshuffle-LZ4 chunks (which can exceed the raw size by < 1 % when incompressible)
+    s->h_img_bytes = B * ((size_t)L.W * L.H * c->pixel_bytes + (size_t)L.W * L.H * c->pixel_bytes / 128 + 4096);
     STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_img), s->h_img_bytes, hipHostMallocDefault));
     STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), (B * 10 + 1) * 4, hipHostMallocDefault));
     STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_recs), B * (size_t)c->max_comp * sizeof(ReflOut),
@@ -691,6 +696,195 @@ extern "C" int ffs_submit(ffs_stream* s, const void* host_pixels, uint32_t n_fra
     return enqueue_batch(s, s->d_img, L.pitch, L.frame_stride, n_frames);
 }
 
+
+// ---- compressed input -------------------------------------------------------------------------------
+
+static int ensure_decode_buffers(ffs_stream* s) {
+    ffs_ctx* c = s->ctx;
+    if (s->d_comp) return FFS_OK;
+    const size_t es = c->pixel_bytes, nelem = (size_t)c->L.W * c->L.H;
+    // bitshuffle's blocking (bshuf_default_block_size, and the loop of bshuf_blocked_wrap_fun)
+    const size_t block = (size_t)kDecBlockBytes / es;
+    const size_t n_full = nelem / block, rem = nelem - n_full * block;
+    s->dec_block_elems = (uint32_t)block;
+    s->dec_blocks = (uint32_t)(n_full + (rem >= 8 ? 1 : 0));
+    s->dec_last = (uint32_t)(rem >= 8 ? rem / 8 * 8 : block);
+    s->dec_tail = (uint32_t)(rem % 8);
+    const size_t tab_bytes = (size_t)c->max_batch * (s->dec_blocks + 1) * sizeof(uint2);
+    if (dmalloc(&s->d_comp, s->h_img_bytes + 64) != hipSuccess || dmalloc(&s->d_tab, tab_bytes) != hipSuccess
+        || hipHostMalloc(reinterpret_cast<void**>(&s->h_tab), tab_bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        c->err = "allocation of the compressed-chunk buffers failed";
+        return FFS_ERR_NOMEM;
+    }
+    return FFS_OK;
+}
+
+static inline uint32_t be32(const uint8_t* p) {
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+}
+
+// Places the chunks in the pinned staging buffer, indexes their blocks, copies both to the device
+// and enqueues the decode kernel on s->st.  On return the decoded frames are (will be) in s->d_img.
+static int stage_and_decode(ffs_stream* s, const void* const* chunks, const size_t* chunk_bytes, uint32_t n) {
+    ffs_ctx* c = s->ctx;
+    const Layout& L = c->L;
+    int rc = ensure_decode_buffers(s);
+    if (rc != FFS_OK) return rc;
+    const size_t es = c->pixel_bytes, raw_bytes = (size_t)L.W * L.H * es;
+    uint32_t in_place = 0;
+    for (uint32_t f = 0; f < n; ++f) {
+        if (!chunks[f] || chunk_bytes[f] < 12) {
+            c->err = "ffs_submit_compressed: a chunk is shorter than its 12-byte header";
+            return FFS_ERR_INVALID;
+        }
+        const uint8_t* p = static_cast<const uint8_t*>(chunks[f]);
+        uint64_t total = 0;
+        for (int i = 0; i < 8; ++i) total = (total << 8) | p[i];
+        if (total != raw_bytes) {
+            c->err = "ffs_submit_compressed: chunk header says " + std::to_string(total) + " bytes, the context's frames have "
+                     + std::to_string(raw_bytes);
+            return FFS_ERR_INVALID;
+        }
+        if (p >= s->h_img && p + chunk_bytes[f] <= s->h_img + s->h_img_bytes) ++in_place;
+    }
+    if (in_place != 0 && in_place != n) {
+        c->err = "ffs_submit_compressed: either all chunks lie in the stream's host buffer or none";
+        return FFS_ERR_INVALID;
+    }
+    std::vector<size_t> base(n);
+    size_t lo = 0, hi = 0;
+    if (in_place) {
+        lo = SIZE_MAX;
+        for (uint32_t f = 0; f < n; ++f) {
+            base[f] = (size_t)(static_cast<const uint8_t*>(chunks[f]) - s->h_img);
+            lo = std::min(lo, base[f]);
+            hi = std::max(hi, base[f] + chunk_bytes[f]);
+        }
+        lo &= ~(size_t)15;
+    } else {
+        size_t cur = 0;
+        for (uint32_t f = 0; f < n; ++f) {
+            if (cur + chunk_bytes[f] > s->h_img_bytes) {
+                c->err = "ffs_submit_compressed: the batch's chunks exceed the staging buffer";
+                return FFS_ERR_INVALID;
+            }
+            std::memcpy(s->h_img + cur, chunks[f], chunk_bytes[f]);
+            base[f] = cur;
+            cur = (cur + chunk_bytes[f] + 15) & ~(size_t)15;
+        }
+        hi = cur;
+    }
+    if (hi > 0xFFFFFFF0ull) {
+        c->err = "ffs_submit_compressed: more than 4 GiB of chunks in one batch";
+        return FFS_ERR_INVALID;
+    }
+    // Index the blocks: each frame is a chain of [4-byte length][payload]; the frames' chains are walked
+    // side by side so that the cache misses of different frames overlap.
+    const uint32_t nb = s->dec_blocks, stride = nb + 1;
+    std::vector<size_t> pos(n, 12);
+    bool ok = true;
+    for (uint32_t b = 0; b < nb && ok; ++b)
+        for (uint32_t f = 0; f < n; ++f) {
+            if (pos[f] + 4 > chunk_bytes[f]) { ok = false; break; }
+            const uint32_t clen = be32(s->h_img + base[f] + pos[f]);
+            s->h_tab[(size_t)f * stride + b] = make_uint2((uint32_t)(base[f] + pos[f] + 4), clen);
+            pos[f] += 4 + (size_t)clen;
+        }
+    for (uint32_t f = 0; f < n && ok; ++f) {
+        const size_t tail = (size_t)s->dec_tail * es;
+        if (pos[f] + tail > chunk_bytes[f]) ok = false;
+        s->h_tab[(size_t)f * stride + nb] = make_uint2((uint32_t)(base[f] + pos[f]), (uint32_t)tail);
+    }
+    if (!ok) {
+        c->err = "ffs_submit_compressed: block lengths run past the end of a chunk";
+        return FFS_ERR_INVALID;
+    }
+    HIP_TRY(c, hipMemcpyAsync(s->d_comp + lo, s->h_img + lo, hi - lo, hipMemcpyHostToDevice, s->st));
+    HIP_TRY(c, hipMemcpyAsync(s->d_tab, s->h_tab, (size_t)n * stride * sizeof(uint2), hipMemcpyHostToDevice, s->st));
+    return FFS_OK;
+}
+
+static void launch_decode(ffs_stream* s, uint32_t n) {
+    ffs_ctx* c = s->ctx;
+    DecodeArgs da{};
+    da.comp = s->d_comp;
+    da.table = s->d_tab;
+    da.image = s->d_img;
+    da.frame_stride = c->L.frame_stride;
+    da.pitch = c->L.pitch;
+    da.W = c->L.W;
+    da.H = c->L.H;
+    da.elem_bytes = c->pixel_bytes;
+    da.blocks_per_frame = s->dec_blocks;
+    da.block_elems = s->dec_block_elems;
+    da.last_block_elems = s->dec_last;
+    da.tail_elems = s->dec_tail;
+    da.error = s->d_overflow;
+    const dim3 grid(s->dec_blocks + 1, n);
+    if (c->pixel_bytes == 2) hipLaunchKernelGGL(k_bshuf_lz4_decode<2>, grid, dim3(64), 0, s->st, da);
+    else hipLaunchKernelGGL(k_bshuf_lz4_decode<4>, grid, dim3(64), 0, s->st, da);
+}
+
+extern "C" int ffs_submit_compressed(ffs_stream* s, const void* const* chunks, const size_t* chunk_bytes,
+                                     uint32_t n_frames, int64_t first_frame_id) {
+    if (!s || !chunks || !chunk_bytes) return FFS_ERR_INVALID;
+    ffs_ctx* c = s->ctx;
+    if (s->busy) {
+        c->err = "stream already has a batch in flight: call ffs_wait() first";
+        return FFS_ERR_INVALID;
+    }
+    if (n_frames == 0 || n_frames > c->max_batch) {
+        c->err = "n_frames must be in 1..max_batch";
+        return FFS_ERR_INVALID;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventRecord(s->ev[0], s->st));
+    int rc = stage_and_decode(s, chunks, chunk_bytes, n_frames);
+    if (rc != FFS_OK) return rc;
+    (void)hipGetLastError();
+    launch_decode(s, n_frames);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(s->ev[1], s->st));
+    s->first_id = first_frame_id;
+    return enqueue_batch(s, s->d_img, c->L.pitch, c->L.frame_stride, n_frames);
+}
+
+extern "C" int ffs_decode_only(ffs_stream* s, const void* const* chunks, const size_t* chunk_bytes, uint32_t n_frames,
+                               uint32_t iters, float* ms_decode, void* host_out) {
+    if (!s || !chunks || !chunk_bytes || iters == 0) return FFS_ERR_INVALID;
+    ffs_ctx* c = s->ctx;
+    if (s->busy || n_frames == 0 || n_frames > c->max_batch) {
+        c->err = "ffs_decode_only: stream busy or n_frames out of range";
+        return FFS_ERR_INVALID;
+    }
+    const Layout& L = c->L;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = stage_and_decode(s, chunks, chunk_bytes, n_frames);
+    if (rc != FFS_OK) return rc;
+    (void)hipGetLastError();
+    HIP_TRY(c, hipEventRecord(s->ev[0], s->st));
+    for (uint32_t i = 0; i < iters; ++i) launch_decode(s, n_frames);
+    HIP_TRY(c, hipEventRecord(s->ev[1], s->st));
+    HIP_TRY(c, hipGetLastError());
+    uint32_t flag = 0;
+    HIP_TRY(c, hipMemcpyAsync(&flag, s->d_overflow, 4, hipMemcpyDeviceToHost, s->st));
+    HIP_TRY(c, hipStreamSynchronize(s->st));
+    float ms = 0;
+    HIP_TRY(c, hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
+    if (ms_decode) *ms_decode = ms / iters;
+    if (host_out) {
+        const size_t row = (size_t)L.W * c->pixel_bytes;
+        HIP_TRY(c, hipMemcpy2D(host_out, row, s->d_img, L.pitch, row, (size_t)L.H * n_frames, hipMemcpyDeviceToHost));
+    }
+    if (flag & 4u) {
+        HIP_TRY(c, hipMemset(s->d_overflow, 0, 4));
+        c->err = "corrupt bitshuffle-LZ4 chunk: an LZ4 block did not decode to its block size";
+        return FFS_ERR_INVALID;
+    }
+    return FFS_OK;
+}
+
 static int ensure_list_host(ffs_stream* s) {
     ffs_ctx* c = s->ctx;
     if (!s->h_list_k) {
@@ -722,6 +916,10 @@ extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_
     if (overflow) {
         (void)hipMemsetAsync(s->d_overflow, 0, 4, s->st2);
         (void)hipStreamSynchronize(s->st2);
+        if (overflow & 4u) {
+            c->err = "corrupt bitshuffle-LZ4 chunk: an LZ4 block did not decode to its block size";
+            return FFS_ERR_INVALID;
+        }
         c->err = (overflow & 1u) ? "a frame has more strong pixels than max_strong_per_frame"
                                  : "a frame has more connected components than the context holds";
         return FFS_ERR_OVERFLOW;

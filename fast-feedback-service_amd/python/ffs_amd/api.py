@@ -73,7 +73,7 @@ EXPORTS = [
     "ffs_ctx_apply_resolution_mask", "ffs_ctx_get_mask", "ffs_ctx_set_params",
     "ffs_stream_create", "ffs_stream_destroy", "ffs_stream_host_buffer", "ffs_submit",
     "ffs_submit_device", "ffs_ctx_device_layout", "ffs_wait", "ffs_stream_batch_arrays", "ffs_stream_timings",
-    "ffs_bench_threshold", "ffs_stream_debug_planes", "ffs_stream_debug_bitplane", "ffs_selftest_sqrt", "ffs_stack3d_create",
+    "ffs_submit_compressed", "ffs_decode_only", "ffs_bench_threshold", "ffs_stream_debug_planes", "ffs_stream_debug_bitplane", "ffs_selftest_sqrt", "ffs_stack3d_create",
     "ffs_stack3d_destroy", "ffs_stack3d_add_batch", "ffs_stack3d_add_slice", "ffs_stack3d_finish",
 ]
 
@@ -112,6 +112,9 @@ def load_library():
                                           C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.ffs_stream_debug_planes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                               C.POINTER(C.c_size_t)]
+        L.ffs_submit_compressed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64]
+        L.ffs_decode_only.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                      C.POINTER(C.c_float), C.c_void_p]
         L.ffs_stream_debug_bitplane.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.ffs_selftest_sqrt.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
         L.ffs_device_name.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
@@ -255,8 +258,39 @@ class Stream:
         """The stream's pinned staging area as a (max_batch, H, W) array."""
         p, n = C.c_void_p(), C.c_size_t()
         self.ctx._check(self._lib.ffs_stream_host_buffer(self._h, C.byref(p), C.byref(n)))
-        buf = (C.c_uint8 * n.value).from_address(p.value)
+        frames = self.ctx.max_batch * self.ctx.H * self.ctx.W * self.ctx.dtype.itemsize  # (+ slack for chunks)
+        buf = (C.c_uint8 * frames).from_address(p.value)
         return np.frombuffer(buf, dtype=self.ctx.dtype).reshape(self.ctx.max_batch, self.ctx.H, self.ctx.W)
+
+    def host_bytes(self) -> np.ndarray:
+        """The same staging area as bytes, including its slack (for compressed chunks placed in it)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self.ctx._check(self._lib.ffs_stream_host_buffer(self._h, C.byref(p), C.byref(n)))
+        return np.frombuffer((C.c_uint8 * n.value).from_address(p.value), dtype=np.uint8)
+
+    def _chunk_args(self, chunks):
+        keep = [np.frombuffer(c, np.uint8) if not isinstance(c, np.ndarray) else c for c in chunks]
+        ptrs = (C.c_void_p * len(keep))(*[k.ctypes.data for k in keep])
+        sizes = (C.c_size_t * len(keep))(*[k.size for k in keep])
+        return keep, ptrs, sizes
+
+    def submit_compressed(self, chunks, first_frame_id: int = 0):
+        """chunks: bitshuffle-LZ4 chunks (bytes / uint8 arrays, 12-byte header included), one per frame."""
+        self._keep, ptrs, sizes = self._chunk_args(chunks)
+        self.ctx._check(self._lib.ffs_submit_compressed(self._h, ptrs, sizes, len(self._keep), first_frame_id))
+
+    def process_compressed(self, chunks, first_frame_id: int = 0):
+        self.submit_compressed(chunks, first_frame_id)
+        return self.wait()
+
+    def decode_only(self, chunks, iters: int = 1, want_frames: bool = True):
+        """GPU decode alone: (average ms per launch, decoded frames or None)."""
+        keep, ptrs, sizes = self._chunk_args(chunks)
+        ms = C.c_float()
+        out = np.empty((len(keep), self.ctx.H, self.ctx.W), self.ctx.dtype) if want_frames else None
+        self.ctx._check(self._lib.ffs_decode_only(self._h, ptrs, sizes, len(keep), iters, C.byref(ms),
+                                                  out.ctypes.data_as(C.c_void_p) if want_frames else None))
+        return ms.value, out
 
     def submit(self, frames: np.ndarray, first_frame_id: int = 0):
         f = np.ascontiguousarray(frames, dtype=self.ctx.dtype)

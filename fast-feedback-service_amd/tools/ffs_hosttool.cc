@@ -12,6 +12,7 @@
 #include <cstring>
 #include <filesystem>
 #include <fstream>
+#include <iterator>
 #include <random>
 
 #include "codecs.hpp"
@@ -204,6 +205,20 @@ static int synthinfo(const std::string& spec) {
     return 0;
 }
 
+// chunkfnv <chunk file> <nelem> <elem bytes>: decode one bitshuffle-LZ4 chunk with the host codec and
+// print the FNV-1a of the pixels (cross-check for chunk writers)
+static int chunkfnv(const std::string& path, size_t nelem, size_t es) {
+    std::ifstream f(path, std::ios::binary);
+    std::vector<uint8_t> c((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    std::vector<uint8_t> px(nelem * es);
+    if (c.size() < 12 || bshuf_decompress_lz4(c.data() + 12, c.size() - 12, px.data(), nelem, es) < 0)
+        return fail("chunk does not decode");
+    uint64_t h = 1469598103934665603ull;
+    for (auto b : px) h = (h ^ b) * 1099511628211ull;
+    std::printf("fnv %016llx\n", (unsigned long long)h);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const std::string cmd = argc > 1 ? argv[1] : "";
     try {
@@ -213,6 +228,8 @@ int main(int argc, char** argv) {
         if (cmd == "mkh5" && argc >= 4) return mkh5(argc, argv);
         if (cmd == "h5info" && argc == 3) return h5info(argv[2]);
         if (cmd == "synthinfo" && argc == 3) return synthinfo(argv[2]);
+        if (cmd == "chunkfnv" && argc == 5)
+            return chunkfnv(argv[2], std::strtoull(argv[3], nullptr, 10), std::strtoull(argv[4], nullptr, 10));
         if (cmd == "h5support") { std::printf("%d\n", h5_supported() ? 1 : 0); return 0; }
     } catch (const std::exception& e) {
         std::printf("Error: %s\n", e.what());

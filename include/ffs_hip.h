@@ -161,6 +161,22 @@ int ffs_submit_device(ffs_stream *s, const void *device_pixels, size_t pitch_byt
 int ffs_ctx_device_layout(const ffs_ctx *ctx, size_t *pitch_bytes, size_t *frame_stride_bytes);
 
 /* Blocks until the stream's batch is done; results[i] describes frame i of the batch. */
+/* Same as ffs_submit, but each frame arrives as the raw bitshuffle-LZ4 chunk the detector wrote
+ * (12-byte header + blocks: what Reader::get_raw_chunk returns, h5read.c:428-456, shmread.cc) and is
+ * decoded on the GPU -- replaces bshuf_decompress_lz4 on the worker thread (spotfinder.cc:823-842,
+ * h5read/src/read_chunks.cc:22-24) and moves 4-6x fewer bytes over PCIe.  chunks[i] may point
+ * anywhere (copied into the stream's pinned staging buffer) or, for zero copy, inside the buffer
+ * ffs_stream_host_buffer returns (then all of them must).  A chunk whose header does not say
+ * width*height*pixel_bytes, or whose block lengths run past chunk_bytes[i], is refused here
+ * (FFS_ERR_INVALID); a corrupt LZ4 stream is reported by ffs_wait (FFS_ERR_INVALID). */
+int ffs_submit_compressed(ffs_stream *s, const void *const *chunks, const size_t *chunk_bytes,
+                          uint32_t n_frames, int64_t first_frame_id);
+/* Decode only, for tests and benchmarks: n_frames chunks -> the stream's device image buffer
+ * (default layout); the average duration of one decode launch in ms_decode (HIP events, iters
+ * launches).  host_out (may be NULL) receives the decoded frames, W*H*pixel_bytes each. */
+int ffs_decode_only(ffs_stream *s, const void *const *chunks, const size_t *chunk_bytes,
+                    uint32_t n_frames, uint32_t iters, float *ms_decode, void *host_out);
+
 int ffs_wait(ffs_stream *s, const ffs_frame_result **results, uint32_t *n_results);
 
 /* The whole batch's boxes and reflections as two contiguous arrays (frame i's slice starts

@@ -50,3 +50,30 @@ def test_bad_algorithm_and_thread_count():
 
 def test_spotfinder32_alias_exists():
     assert os.path.exists(os.path.join(BIN, "spotfinder32"))
+
+
+def _fnv(data: bytes) -> int:
+    h = 1469598103934665603
+    for b in data:
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.mark.parametrize("encoder", ["lz4", "literals"])
+@pytest.mark.parametrize("shape,dtype", [((61, 97), "uint16"), ((31, 33), "uint32"), ((1, 7), "uint16")])
+def test_numpy_chunk_writer_against_host_codec(tmp_path, encoder, shape, dtype):
+    """The numpy/liblz4 chunk writer used for GPU decode tests produces what the host's bitshuffle-LZ4
+    decoder (the restatement of the reference's read path) reads back bit for bit."""
+    import numpy as np
+    from ffs_amd import bslz4
+    if encoder == "lz4" and bslz4.liblz4() is None:
+        pytest.skip("no liblz4")
+    rng = np.random.default_rng(5)
+    img = rng.poisson(3.0, shape).astype(dtype)
+    img[0, 0] = np.iinfo(dtype).max
+    chunk = bslz4.compress(img, encoder)
+    (tmp_path / "c.bin").write_bytes(chunk)
+    p = subprocess.run([TOOL, "chunkfnv", str(tmp_path / "c.bin"), str(img.size), str(img.dtype.itemsize)],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout
+    assert p.stdout.split()[1] == "%016x" % _fnv(img.tobytes())
