@@ -2,6 +2,7 @@
 // The C ABI is declared in include/ffs_hip.h; every entry point there names the reference
 // interface it replaces.  No exceptions leave this file.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -9,6 +10,8 @@
 #include <map>
 #include <new>
 #include <string>
+#include <thread>
+#include <atomic>
 #include <vector>
 
 #include "ffs_hip.h"
@@ -59,6 +62,9 @@ struct ffs_stream {
     uint8_t* d_comp = nullptr;                         // compressed chunks (allocated on first use)
     uint2 *d_tab = nullptr, *h_tab = nullptr;          // per-block (offset, length) tables
     uint32_t dec_blocks = 0, dec_last = 0, dec_tail = 0, dec_block_elems = 0;
+    std::thread job;          // ffs_submit_compressed's helper (block index + launches); joined by ffs_wait
+    int job_rc = 0;
+    std::string job_err;
     uint32_t *d_tile_counts = nullptr, *d_tile_offsets = nullptr, *d_num_strong = nullptr, *d_row_off = nullptr;
     uint32_t *d_list_k = nullptr, *d_list_i = nullptr, *d_parent = nullptr, *d_comp_id = nullptr;
     uint32_t *d_n_comp = nullptr, *d_overflow = nullptr, *d_summary = nullptr;
@@ -319,6 +325,7 @@ static hipError_t dmalloc(T** p, size_t n_bytes) {
 extern "C" void ffs_stream_destroy(ffs_stream* s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
+    if (s->job.joinable()) s->job.join();
     if (s->st) (void)hipStreamSynchronize(s->st);
     if (s->st2 && s->st2 != s->st) { (void)hipStreamSynchronize(s->st2); (void)hipStreamDestroy(s->st2); }
     void* dev[] = {s->d_comp, s->d_tab, s->d_dplane, s->d_eplane, s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_tile_offsets, s->d_num_strong,
@@ -560,10 +567,11 @@ static int check_layout(ffs_stream* s, size_t pitch, size_t fstride, uint32_t n_
     return FFS_OK;
 }
 
-static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride, uint32_t n) {
+static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride, uint32_t n,
+                         const ffs_params* snapshot = nullptr) {
     ffs_ctx* c = s->ctx;
     const Layout& L = c->L;
-    s->batch_params = c->params;
+    s->batch_params = snapshot ? *snapshot : c->params;
     const ffs_params& p = s->batch_params;
     s->cur_img = d_img;
     s->cur_pitch = pitch;
@@ -724,9 +732,11 @@ static inline uint32_t be32(const uint8_t* p) {
     return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
 }
 
-// Places the chunks in the pinned staging buffer, indexes their blocks, copies both to the device
-// and enqueues the decode kernel on s->st.  On return the decoded frames are (will be) in s->d_img.
-static int stage_and_decode(ffs_stream* s, const void* const* chunks, const size_t* chunk_bytes, uint32_t n) {
+// Step 1 (caller's thread): validates the headers, places the chunks in the pinned staging buffer
+// (unless they already are there) and starts their copy to the device.  Fills base[] = offset of every
+// chunk in the staging / device buffer.
+static int stage_chunks(ffs_stream* s, const void* const* chunks, const size_t* chunk_bytes, uint32_t n,
+                        std::vector<size_t>& base) {
     ffs_ctx* c = s->ctx;
     const Layout& L = c->L;
     int rc = ensure_decode_buffers(s);
@@ -752,7 +762,7 @@ static int stage_and_decode(ffs_stream* s, const void* const* chunks, const size
         c->err = "ffs_submit_compressed: either all chunks lie in the stream's host buffer or none";
         return FFS_ERR_INVALID;
     }
-    std::vector<size_t> base(n);
+    base.assign(n, 0);
     size_t lo = 0, hi = 0;
     if (in_place) {
         lo = SIZE_MAX;
@@ -779,29 +789,59 @@ static int stage_and_decode(ffs_stream* s, const void* const* chunks, const size
         c->err = "ffs_submit_compressed: more than 4 GiB of chunks in one batch";
         return FFS_ERR_INVALID;
     }
-    // Index the blocks: each frame is a chain of [4-byte length][payload]; the frames' chains are walked
-    // side by side so that the cache misses of different frames overlap.
+    HIP_TRY(c, hipMemcpyAsync(s->d_comp + lo, s->h_img + lo, hi - lo, hipMemcpyHostToDevice, s->st));
+    return FFS_OK;
+}
+
+// Step 2 (may run on the stream's helper thread while the chunks cross PCIe): indexes the blocks --
+// each frame is a chain of [4-byte length][payload], a pointer chase of ~2 ms for 32 Eiger frames;
+// the frames' chains are walked side by side so that their cache misses overlap -- and enqueues the
+// table copy.  Errors go to `err`, not to the context (another thread may own that string).
+static int index_blocks(ffs_stream* s, const std::vector<size_t>& base, const std::vector<size_t>& chunk_bytes,
+                        std::string& err) {
+    ffs_ctx* c = s->ctx;
+    const uint32_t n = (uint32_t)base.size();
+    const size_t es = c->pixel_bytes;
     const uint32_t nb = s->dec_blocks, stride = nb + 1;
     std::vector<size_t> pos(n, 12);
-    bool ok = true;
-    for (uint32_t b = 0; b < nb && ok; ++b)
-        for (uint32_t f = 0; f < n; ++f) {
-            if (pos[f] + 4 > chunk_bytes[f]) { ok = false; break; }
-            const uint32_t clen = be32(s->h_img + base[f] + pos[f]);
-            s->h_tab[(size_t)f * stride + b] = make_uint2((uint32_t)(base[f] + pos[f] + 4), clen);
-            pos[f] += 4 + (size_t)clen;
+    std::atomic<bool> ok{true};
+    static const bool trace = std::getenv("FFS_TRACE_SUBMIT") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto walk = [&](uint32_t f0, uint32_t f1) {  // frames [f0, f1), chains interleaved
+        for (uint32_t b = 0; b < nb; ++b)
+            for (uint32_t f = f0; f < f1; ++f) {
+                if (pos[f] + 4 > chunk_bytes[f]) { ok = false; return; }
+                const uint32_t clen = be32(s->h_img + base[f] + pos[f]);
+                s->h_tab[(size_t)f * stride + b] = make_uint2((uint32_t)(base[f] + pos[f] + 4), clen);
+                pos[f] += 4 + (size_t)clen;
+            }
+        for (uint32_t f = f0; f < f1; ++f) {
+            const size_t tail = (size_t)s->dec_tail * es;
+            if (pos[f] + tail > chunk_bytes[f]) ok = false;
+            s->h_tab[(size_t)f * stride + nb] = make_uint2((uint32_t)(base[f] + pos[f]), (uint32_t)tail);
         }
-    for (uint32_t f = 0; f < n && ok; ++f) {
-        const size_t tail = (size_t)s->dec_tail * es;
-        if (pos[f] + tail > chunk_bytes[f]) ok = false;
-        s->h_tab[(size_t)f * stride + nb] = make_uint2((uint32_t)(base[f] + pos[f]), (uint32_t)tail);
+    };
+    const uint32_t n_thr = (uint64_t)n * nb >= 32768 ? std::min<uint32_t>(4, n) : 1;
+    if (n_thr <= 1) {
+        walk(0, n);
+    } else {
+        std::vector<std::thread> th;
+        for (uint32_t t = 1; t < n_thr; ++t) th.emplace_back(walk, n * t / n_thr, n * (t + 1) / n_thr);
+        walk(0, n / n_thr);
+        for (auto& t : th) t.join();
     }
+    if (trace)
+        std::fprintf(stderr, "[ffs] indexed %u blocks in %.3f ms (%u threads)\n", n * nb,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), n_thr);
     if (!ok) {
-        c->err = "ffs_submit_compressed: block lengths run past the end of a chunk";
+        err = "ffs_submit_compressed: block lengths run past the end of a chunk";
         return FFS_ERR_INVALID;
     }
-    HIP_TRY(c, hipMemcpyAsync(s->d_comp + lo, s->h_img + lo, hi - lo, hipMemcpyHostToDevice, s->st));
-    HIP_TRY(c, hipMemcpyAsync(s->d_tab, s->h_tab, (size_t)n * stride * sizeof(uint2), hipMemcpyHostToDevice, s->st));
+    const hipError_t e = hipMemcpyAsync(s->d_tab, s->h_tab, (size_t)n * stride * sizeof(uint2), hipMemcpyHostToDevice, s->st);
+    if (e != hipSuccess) {
+        err = std::string("hipMemcpyAsync(block table): ") + hipGetErrorString(e);
+        return FFS_ERR_DEVICE;
+    }
     return FFS_OK;
 }
 
@@ -840,14 +880,42 @@ extern "C" int ffs_submit_compressed(ffs_stream* s, const void* const* chunks, c
     }
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipEventRecord(s->ev[0], s->st));
-    int rc = stage_and_decode(s, chunks, chunk_bytes, n_frames);
+    std::vector<size_t> base;
+    int rc = stage_chunks(s, chunks, chunk_bytes, n_frames, base);
     if (rc != FFS_OK) return rc;
-    (void)hipGetLastError();
-    launch_decode(s, n_frames);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(s->ev[1], s->st));
+    // The rest -- block index, table copy, decode kernel and the hot path's launches -- is enqueued by a
+    // helper thread, so that the caller gets its thread back while the index is built; ffs_wait joins it.
     s->first_id = first_frame_id;
-    return enqueue_batch(s, s->d_img, c->L.pitch, c->L.frame_stride, n_frames);
+    s->n_frames = n_frames;
+    s->busy = true;
+    s->job_rc = FFS_OK;
+    s->job_err.clear();
+    const ffs_params snap = c->params;
+    std::vector<size_t> sizes(chunk_bytes, chunk_bytes + n_frames);
+    s->job = std::thread([s, c, snap, n_frames, base = std::move(base), sizes = std::move(sizes)]() {
+        if (hipSetDevice(c->device) != hipSuccess) {
+            s->job_rc = FFS_ERR_DEVICE;
+            s->job_err = "hipSetDevice failed on the stream's helper thread";
+            return;
+        }
+        int r = index_blocks(s, base, sizes, s->job_err);
+        if (r == FFS_OK) {
+            (void)hipGetLastError();
+            launch_decode(s, n_frames);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipEventRecord(s->ev[1], s->st);
+            if (e != hipSuccess) {
+                s->job_err = std::string("decode launch: ") + hipGetErrorString(e);
+                r = FFS_ERR_DEVICE;
+            }
+        }
+        if (r == FFS_OK) {
+            r = enqueue_batch(s, s->d_img, c->L.pitch, c->L.frame_stride, n_frames, &snap);
+            if (r != FFS_OK) s->job_err = c->err;
+        }
+        s->job_rc = r;
+    });
+    return FFS_OK;
 }
 
 extern "C" int ffs_decode_only(ffs_stream* s, const void* const* chunks, const size_t* chunk_bytes, uint32_t n_frames,
@@ -860,8 +928,17 @@ extern "C" int ffs_decode_only(ffs_stream* s, const void* const* chunks, const s
     }
     const Layout& L = c->L;
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = stage_and_decode(s, chunks, chunk_bytes, n_frames);
-    if (rc != FFS_OK) return rc;
+    std::vector<size_t> base;
+    int rc = stage_chunks(s, chunks, chunk_bytes, n_frames, base);
+    if (rc == FFS_OK) {
+        std::string err;
+        rc = index_blocks(s, base, std::vector<size_t>(chunk_bytes, chunk_bytes + n_frames), err);
+        if (rc != FFS_OK) c->err = err;
+    }
+    if (rc != FFS_OK) {
+        (void)hipStreamSynchronize(s->st);
+        return rc;
+    }
     (void)hipGetLastError();
     HIP_TRY(c, hipEventRecord(s->ev[0], s->st));
     for (uint32_t i = 0; i < iters; ++i) launch_decode(s, n_frames);
@@ -903,6 +980,15 @@ extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_
         return FFS_ERR_INVALID;
     }
     HIP_TRY(c, hipSetDevice(c->device));
+    if (s->job.joinable()) {
+        s->job.join();
+        if (s->job_rc != FFS_OK) {
+            (void)hipStreamSynchronize(s->st);
+            s->busy = false;
+            c->err = s->job_err;
+            return s->job_rc;
+        }
+    }
     HIP_TRY(c, hipEventSynchronize(s->ev[4]));
     const uint32_t n = s->n_frames;
     const size_t B = c->max_batch;

@@ -54,6 +54,7 @@ struct Args {
     float max_sep = 2.0f, timeout = 30.0f, dmin = -1.f, dmax = -1.f, wavelength = 0.f;
     int pipe_fd = -1, device = 0;
     std::string algorithm = "dispersion", detector_json;
+    bool cpu_decode = false;
 };
 
 static void usage() {
@@ -62,7 +63,9 @@ static void usage() {
       "                  [-n NUM] [--validate] [--images NUM] [--writeout] [--min-spot-size N]\n"
       "                  [--min-spot-size-3d N] [--max-peak-centroid-separation N] [--start-index N]\n"
       "                  [-t S] [-fd FD] [-a ALGO] [--dmin MIN D] [--dmax MAX D] [-w \xce\xbb] [--detector JSON]\n"
-      "                  [-h5] [--output-for-index] [--batch N]\n"
+      "                  [-h5] [--output-for-index] [--batch N] [--cpu-decode] [--strict-dtype]\n"
+      "--cpu-decode: decompress bitshuffle-LZ4 chunks on the worker thread (the reference's way) instead\n"
+      "              of sending them to the GPU as they are\n"
       "FILE: NXmx .nxs/.h5 (needs an HDF5 build), a /dev/shm directory, a ####.cbf template, or\n"
       "      synth:<eiger16m|jungfrau9m|plumbing1k|sweep16m|tiny|tinysweep>[:n_images[:seed]]\n");
 }
@@ -126,6 +129,7 @@ static Args parse_args(int argc, char** argv) {
         else if (s == "-t" || s == "--timeout") r.timeout = f32(need(i, s), s);
         else if (s == "-fd" || s == "--pipe_fd") r.pipe_fd = std::stoi(need(i, s));
         else if (s == "-a" || s == "--algorithm") r.algorithm = need(i, s);
+        else if (s == "--cpu-decode") r.cpu_decode = true;
         else if (s == "--dmin") r.dmin = f32(need(i, s), s);
         else if (s == "--dmax") r.dmax = f32(need(i, s), s);
         else if (s == "-w" || s == "--wavelength" || s == "-\xce\xbb") { r.wavelength = f32(need(i, s), s); r.wavelength_set = true; }
@@ -475,12 +479,19 @@ int main(int argc, char** argv) {
         uint8_t* host = static_cast<uint8_t*>(host_v);
         const size_t frame_bytes = (size_t)width * height * bytes_per_pixel;
         std::vector<uint8_t> raw(frame_bytes * (bytes_per_pixel == 2 ? 2 : 1) + 4096);
+        // bitshuffle-LZ4 chunks go to the GPU as they are (read straight into the pinned staging buffer)
+        // unless the pixels are needed on the host (--writeout) or --cpu-decode asks for the reference's way
+        const bool gpu_decode = reader.get_raw_chunk_compression() == Reader::BITSHUFFLE_LZ4 && !args.cpu_decode
+                                && !args.writeout;
+        std::vector<const void*> chunk_ptr(batch);
+        std::vector<size_t> chunk_len(batch);
         auto last_received = std::chrono::steady_clock::now();
         while (!g_stop.load() && !failed.load()) {
             const uint32_t first = next_image.fetch_add(batch);  // a run of frames instead of one (:752)
             if (first >= num_images) break;
             const uint32_t n = std::min(batch, num_images - first);
             uint32_t got = 0;
+            size_t cursor = 0;  // gpu_decode: fill position in the pinned buffer
             for (; got < n && !g_stop.load(); ++got) {
                 const uint32_t image_num = first + got;
                 const uint32_t offset_image_num = image_num + args.start_index;  // :756
@@ -501,11 +512,18 @@ int main(int argc, char** argv) {
                     last_received = std::chrono::steady_clock::now();
                     time_waiting += std::chrono::duration<double>(last_received - w0).count();
                     for (;;) {  // zero-length reads on /dev/shm: retry (:805-821)
-                        chunk = reader.get_raw_chunk(offset_image_num, raw);
+                        chunk = gpu_decode ? reader.get_raw_chunk(offset_image_num, {host + cursor, host_bytes - cursor})
+                                           : reader.get_raw_chunk(offset_image_num, raw);
                         if (chunk.size() != 0) break;
                         std::printf("\033[1mRace Condition?!?? Got buffer size 0 for image %u. Sleeping.\033[0m\n", image_num);
                         std::this_thread::sleep_for(100ms);
                     }
+                }
+                if (gpu_decode) {
+                    chunk_ptr[got] = chunk.data();
+                    chunk_len[got] = chunk.size();
+                    cursor = (size_t)(chunk.data() - host) + ((chunk.size() + 63) & ~(size_t)63);
+                    continue;
                 }
                 uint8_t* dst = host + (size_t)got * frame_bytes;  // decode outside the lock (:823-842)
                 switch (reader.get_raw_chunk_compression()) {
@@ -527,7 +545,9 @@ int main(int argc, char** argv) {
             if (got == 0 || failed.load()) break;
             const ffs_frame_result* res = nullptr;
             uint32_t nres = 0;
-            if (ffs_submit(s, host, got, first) != FFS_OK || ffs_wait(s, &res, &nres) != FFS_OK) {
+            const int sub = gpu_decode ? ffs_submit_compressed(s, chunk_ptr.data(), chunk_len.data(), got, first)
+                                       : ffs_submit(s, host, got, first);
+            if (sub != FFS_OK || ffs_wait(s, &res, &nres) != FFS_OK) {
                 std::printf("Error: %s\n", ffs_last_error(ctx));
                 failed = 1;
                 break;

@@ -166,9 +166,11 @@ int ffs_ctx_device_layout(const ffs_ctx *ctx, size_t *pitch_bytes, size_t *frame
  * decoded on the GPU -- replaces bshuf_decompress_lz4 on the worker thread (spotfinder.cc:823-842,
  * h5read/src/read_chunks.cc:22-24) and moves 4-6x fewer bytes over PCIe.  chunks[i] may point
  * anywhere (copied into the stream's pinned staging buffer) or, for zero copy, inside the buffer
- * ffs_stream_host_buffer returns (then all of them must).  A chunk whose header does not say
- * width*height*pixel_bytes, or whose block lengths run past chunk_bytes[i], is refused here
- * (FFS_ERR_INVALID); a corrupt LZ4 stream is reported by ffs_wait (FFS_ERR_INVALID). */
+ * ffs_stream_host_buffer returns (then all of them must).  The call starts the PCIe copy and returns;
+ * a helper thread of the stream indexes the blocks and enqueues the kernels meanwhile (ffs_wait
+ * joins it).  A chunk whose header does not say width*height*pixel_bytes is refused here
+ * (FFS_ERR_INVALID); block lengths that run past chunk_bytes[i] and corrupt LZ4 streams are
+ * reported by ffs_wait (FFS_ERR_INVALID). */
 int ffs_submit_compressed(ffs_stream *s, const void *const *chunks, const size_t *chunk_bytes,
                           uint32_t n_frames, int64_t first_frame_id);
 /* Decode only, for tests and benchmarks: n_frames chunks -> the stream's device image buffer

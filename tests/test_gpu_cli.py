@@ -132,6 +132,7 @@ def test_shm_and_cbf_readers(tmp_path):
     det = json.dumps({"pixel_size_x": 0.075, "pixel_size_y": 0.075, "beam_center_x": 11.25, "beam_center_y": 7.5,
                       "distance": 300.0})
     for argv in (["%s" % shm, "--threads", "2"],
+                 ["%s" % shm, "--threads", "2", "--batch", "3", "--cpu-decode"],
                  [str(tmp_path / "img_####.cbf"), "--images", str(N), "--start-index", "1", "--wavelength", "0.976",
                   "--detector", det]):
         rc, out, err, lines = run_with_pipe(argv, tmp_path)

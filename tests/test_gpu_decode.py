@@ -101,6 +101,10 @@ def test_bad_chunks_are_refused(ffs):
         st.decode_only([bytes(bad)])
     with pytest.raises(ffs.FfsError, match="corrupt"):
         st.process_compressed([bytes(bad)])
+    with pytest.raises(ffs.FfsError, match="run past"):
+        st.process_compressed([good[:len(good) // 2]])
+    with pytest.raises(ffs.FfsError, match="header says"):
+        st.submit_compressed([wrong])
     # a literal run longer than the block (literals-only block with its length bytes raised)
     lits = bslz4.compress(img, "literals")
     b2 = bytearray(lits)
