@@ -99,6 +99,9 @@ struct ffs_stack3d {
     };
     std::map<int64_t, Slice> slices;
     std::vector<ffs_reflection> out;
+    // per-signal view of the last finish (vertex order)
+    std::vector<uint32_t> sig_x, sig_y, sig_i;
+    std::vector<int32_t> sig_z, sig_refl;
     // device scratch (allocated in finish)
 };
 
@@ -1245,6 +1248,18 @@ extern "C" int ffs_stack3d_add_batch(ffs_stack3d* st, ffs_stream* s) {
     return FFS_OK;
 }
 
+extern "C" int ffs_stack3d_signals(ffs_stack3d* st, const uint32_t** x, const uint32_t** y, const int32_t** z,
+                                   const uint32_t** intensity, const int32_t** reflection, uint64_t* n) {
+    if (!st) return FFS_ERR_INVALID;
+    if (x) *x = st->sig_x.data();
+    if (y) *y = st->sig_y.data();
+    if (z) *z = st->sig_z.data();
+    if (intensity) *intensity = st->sig_i.data();
+    if (reflection) *reflection = st->sig_refl.data();
+    if (n) *n = st->sig_refl.size();
+    return FFS_OK;
+}
+
 extern "C" int ffs_stack3d_finish(ffs_stack3d* st, const ffs_reflection** reflections, uint32_t* n_refl,
                                   uint32_t* n_calculated, uint32_t* n_f_size, uint32_t* n_f_sep) {
     if (!st) return FFS_ERR_INVALID;
@@ -1346,18 +1361,44 @@ extern "C" int ffs_stack3d_finish(ffs_stack3d* st, const ffs_reflection** reflec
         ST_TRY(hipMemcpy(&n_calc, d_nc, 4, hipMemcpyDeviceToHost));
         std::vector<ReflOut> recs(n_calc);
         if (n_calc) ST_TRY(hipMemcpy(recs.data(), d_recs, (size_t)n_calc * sizeof(ReflOut), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> h_par(N), h_cid(N);
+        ST_TRY(hipMemcpy(h_par.data(), d_par, (size_t)N * 4, hipMemcpyDeviceToHost));
+        ST_TRY(hipMemcpy(h_cid.data(), d_cid, (size_t)N * 4, hipMemcpyDeviceToHost));
         cleanup();
+        // signal -> component: parents always point to a smaller index (union by minimum), so one
+        // ascending sweep resolves every root
+        st->sig_refl.assign(N, -1);
+        for (uint32_t i = 0; i < N; ++i) {
+            if (h_par[i] != i) h_par[i] = h_par[h_par[i]];  // root of the parent is final already
+            st->sig_refl[i] = (int32_t)h_cid[h_par[i]];      // component number (label order), remapped below
+        }
+        st->sig_x.resize(N);
+        st->sig_y.resize(N);
+        st->sig_z.resize(N);
+        st->sig_i = hi;
+        for (int z = 0; z < nz; ++z)
+            for (uint32_t e = begin[z]; e < begin[z + 1]; ++e) {
+                st->sig_x[e] = hk[e] % (uint32_t)c->L.W;
+                st->sig_y[e] = hk[e] / (uint32_t)c->L.W;
+                st->sig_z[e] = z;
+            }
 #undef ST_TRY
 #undef ST_ALLOC
-        for (const ReflOut& r : recs) {
+        std::vector<int32_t> kept_index(n_calc, -1);
+        for (uint32_t q = 0; q < n_calc; ++q) {
+            const ReflOut& r = recs[q];
             if (r.flags & 1u) ++fs;
             else if (r.flags & 2u) ++fp;
             else {
                 ffs_reflection o;
                 std::memcpy(&o, &r, sizeof(o));
+                kept_index[q] = (int32_t)st->out.size();
                 st->out.push_back(o);
             }
         }
+        for (auto& l : st->sig_refl) l = (l >= 0 && (uint32_t)l < n_calc) ? kept_index[l] : -1;
+    } else {
+        st->sig_x.clear(); st->sig_y.clear(); st->sig_z.clear(); st->sig_i.clear(); st->sig_refl.clear();
     }
     if (reflections) *reflections = st->out.data();
     if (n_refl) *n_refl = (uint32_t)st->out.size();

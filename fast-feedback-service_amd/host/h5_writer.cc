@@ -10,6 +10,7 @@
 #ifdef FFS_HAVE_HDF5
 #include <hdf5.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <stdexcept>
 #include <string>
@@ -157,6 +158,92 @@ void h5_write_nxmx(Reader& r, const std::string& master_path, const std::string&
     H5Fclose(master);
     H5Pclose(fapl);
 }
+
+// results_ffs.h5: the reflection table of spotfinder.cc:1219-1300 (dx2 ReflectionTable::write into
+// "dials/processing/group_0"): one dataset per column under the group.
+namespace {
+void put_column(hid_t grp, const char* name, hid_t type, hsize_t n, hsize_t width, const void* data) {
+    hsize_t dims[2] = {n, width};
+    hid_t sp = H5Screate_simple(width > 1 ? 2 : 1, dims, nullptr);
+    hid_t d = H5Dcreate2(grp, name, type, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    if (d < 0) throw std::runtime_error(std::string("results_ffs.h5: cannot create column ") + name);
+    if (n > 0) H5Dwrite(d, type, H5S_ALL, H5S_ALL, H5P_DEFAULT, data);
+    H5Dclose(d);
+    H5Sclose(sp);
+}
+}  // namespace
+
+void h5_write_reflection_table(const std::string& path, const std::string& group, const std::vector<double>& xyz,
+                               const std::vector<int>& id, const std::vector<double>* sigma_b_variance,
+                               const std::vector<double>* sigma_m_variance, const std::vector<int>* spot_extent_z) {
+    const hsize_t n = id.size();
+    if (xyz.size() != 3 * n) throw std::runtime_error("results_ffs.h5: xyzobs.px.value and id disagree in length");
+    hid_t f = H5Fcreate(path.c_str(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+    if (f < 0) throw std::runtime_error("cannot create " + path);
+    hid_t lcpl = H5Pcreate(H5P_LINK_CREATE);
+    H5Pset_create_intermediate_group(lcpl, 1);
+    hid_t grp = H5Gcreate2(f, ("/" + group).c_str(), lcpl, H5P_DEFAULT, H5P_DEFAULT);
+    H5Pclose(lcpl);
+    if (grp < 0) {
+        H5Fclose(f);
+        throw std::runtime_error("results_ffs.h5: cannot create group " + group);
+    }
+    put_column(grp, "xyzobs.px.value", H5T_NATIVE_DOUBLE, n, 3, xyz.data());
+    put_column(grp, "id", H5T_NATIVE_INT, n, 1, id.data());
+    if (sigma_b_variance) put_column(grp, "sigma_b_variance", H5T_NATIVE_DOUBLE, n, 1, sigma_b_variance->data());
+    if (sigma_m_variance) put_column(grp, "sigma_m_variance", H5T_NATIVE_DOUBLE, n, 1, sigma_m_variance->data());
+    if (spot_extent_z) put_column(grp, "spot_extent_z", H5T_NATIVE_INT, n, 1, spot_extent_z->data());
+    {   // number of rows, as an attribute of the group
+        hid_t sp = H5Screate(H5S_SCALAR);
+        hid_t a = H5Acreate2(grp, "num_reflections", H5T_NATIVE_HSIZE, sp, H5P_DEFAULT, H5P_DEFAULT);
+        H5Awrite(a, H5T_NATIVE_HSIZE, &n);
+        H5Aclose(a);
+        H5Sclose(sp);
+    }
+    H5Gclose(grp);
+    H5Fclose(f);
+}
+
+// "<name> <rows> <cols> min.. max.. mean.." for every dataset of a group (what the reference's tests
+// read back with h5py, tests/test_spotfinder.py:96-104)
+void h5_print_group_stats(const std::string& path, const std::string& group) {
+    hid_t f = H5Fopen(path.c_str(), H5F_ACC_RDONLY, H5P_DEFAULT);
+    if (f < 0) throw std::runtime_error("cannot open " + path);
+    hid_t grp = H5Gopen2(f, ("/" + group).c_str(), H5P_DEFAULT);
+    if (grp < 0) {
+        H5Fclose(f);
+        throw std::runtime_error("no group " + group);
+    }
+    H5G_info_t info;
+    H5Gget_info(grp, &info);
+    for (hsize_t i = 0; i < info.nlinks; ++i) {
+        char name[256];
+        H5Lget_name_by_idx(grp, ".", H5_INDEX_NAME, H5_ITER_INC, i, name, sizeof name, H5P_DEFAULT);
+        hid_t d = H5Dopen2(grp, name, H5P_DEFAULT);
+        if (d < 0) continue;
+        hid_t sp = H5Dget_space(d);
+        hsize_t dims[2] = {0, 1};
+        const int nd = H5Sget_simple_extent_dims(sp, dims, nullptr);
+        const size_t rows = dims[0], cols = nd > 1 ? dims[1] : 1;
+        std::vector<double> v(rows * cols);
+        if (!v.empty()) H5Dread(d, H5T_NATIVE_DOUBLE, H5S_ALL, H5S_ALL, H5P_DEFAULT, v.data());
+        std::printf("%s %zu %zu", name, rows, cols);
+        for (int what = 0; what < 3; ++what)
+            for (size_t c = 0; c < cols; ++c) {
+                double acc = what == 0 ? 1e300 : what == 1 ? -1e300 : 0.0;
+                for (size_t r = 0; r < rows; ++r) {
+                    const double x = v[r * cols + c];
+                    acc = what == 0 ? std::min(acc, x) : what == 1 ? std::max(acc, x) : acc + x;
+                }
+                std::printf(" %.17g", what == 2 && rows ? acc / rows : acc);
+            }
+        std::printf("\n");
+        H5Sclose(sp);
+        H5Dclose(d);
+    }
+    H5Gclose(grp);
+    H5Fclose(f);
+}
 }  // namespace ffshost
 #else
 #include <stdexcept>
@@ -165,6 +252,13 @@ void h5_write_nxmx(Reader& r, const std::string& master_path, const std::string&
 namespace ffshost {
 void h5_write_nxmx(Reader&, const std::string&, const std::string&, size_t, size_t) {
     throw std::runtime_error("mkh5 needs an HDF5-enabled build");
+}
+void h5_write_reflection_table(const std::string&, const std::string&, const std::vector<double>&, const std::vector<int>&,
+                               const std::vector<double>*, const std::vector<double>*, const std::vector<int>*) {
+    throw std::runtime_error("results_ffs.h5 needs an HDF5-enabled build");
+}
+void h5_print_group_stats(const std::string&, const std::string&) {
+    throw std::runtime_error("needs an HDF5-enabled build");
 }
 }  // namespace ffshost
 #endif

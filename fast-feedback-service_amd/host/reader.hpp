@@ -47,6 +47,11 @@ bool h5_supported();
 // fixture writer (ffs_hosttool mkh5): frames [0, n_written) get chunks, later ones stay unwritten
 void h5_write_nxmx(Reader& source, const std::string& master_file, const std::string& layout, size_t frames_per_file,
                    size_t n_written);
+// results_ffs.h5 (spotfinder.cc:1219-1300): columns under `group`; the optional ones are written when given
+void h5_write_reflection_table(const std::string& path, const std::string& group, const std::vector<double>& xyzobs_px,
+                               const std::vector<int>& id, const std::vector<double>* sigma_b_variance,
+                               const std::vector<double>* sigma_m_variance, const std::vector<int>* spot_extent_z);
+void h5_print_group_stats(const std::string& path, const std::string& group);
 bool shm_ready_for_read(const std::string& dir);
 bool cbf_ready_for_read(const std::string& templ);
 

@@ -26,6 +26,7 @@
 #include "codecs.hpp"
 #include "ffs_hip.h"
 #include "minijson.hpp"
+#include "kabsch_space.hpp"
 #include "reader.hpp"
 
 using namespace ffshost;
@@ -448,9 +449,10 @@ int main(int argc, char** argv) {
     if (args.validate)
         std::printf("Note: --validate is not linked into this build (the CPU baseline is test infrastructure: "
                     "run `pytest -m gpu`, which compares every stage with it)\n");
-    if (args.save_h5)
-        std::printf("Note: results_ffs.h5 output needs the dx2/HDF5 reflection-table writer, which is not part "
-                    "of this build\n");
+    if (args.save_h5 && !h5_supported()) {
+        std::printf("Error: --save-h5 needs an HDF5-enabled build\n");
+        return 1;
+    }
 
     std::printf("Dataset type: %s\n", rotation ? "Rotation set" : "Still set");
     ffs_stack3d* stack = nullptr;
@@ -465,6 +467,8 @@ int main(int argc, char** argv) {
     std::atomic<uint32_t> completed{0};
     double time_waiting = 0.0;
     std::atomic<int> failed{0};
+    std::map<uint32_t, std::vector<float>> reflection_centers_2d;  // spotfinder.cc:706-708
+    std::mutex reflection_centers_2d_mutex;
 
     auto worker = [&](int thread_id) {
         ffs_stream* s = nullptr;
@@ -598,6 +602,16 @@ int main(int argc, char** argv) {
                     std::snprintf(name, sizeof name, "image_%05u.png", image_num);
                     write_png_rgb(name, img.data(), width, height);
                 }
+                if (args.save_h5 && !rotation) {  // :919-933
+                    std::vector<float> coms;
+                    for (uint32_t q = 0; q < r.n_reflections; ++q) {
+                        coms.push_back(r.reflections[q].com_x);
+                        coms.push_back(r.reflections[q].com_y);
+                        coms.push_back(r.reflections[q].com_z);
+                    }
+                    std::lock_guard<std::mutex> lock(reflection_centers_2d_mutex);
+                    reflection_centers_2d[image_num + args.start_index] = std::move(coms);
+                }
                 if (pipe) {  // keys in alphabetical order, as nlohmann dumps them (:997-1008)
                     std::string j = "{\"file\":" + json_escape(file) + ",\"file-number\":" + std::to_string(image_num)
                                     + ",\"n_spots_total\":" + std::to_string(r.n_boxes)
@@ -662,8 +676,54 @@ int main(int argc, char** argv) {
                     << "COM: (" << r.com_x << ", " << r.com_y << ", " << r.com_z << ")\n";
             }
         }
+        {   // spot variances for integration (:1152-1215)
+            const uint32_t *sx, *sy, *si;
+            const int32_t *sz, *sr;
+            uint64_t n_sig = 0;
+            FFS_CHECK(ctx, ffs_stack3d_signals(stack, &sx, &sy, &sz, &si, &sr, &n_sig));
+            const KabschGeometry geom{detector.distance * 1000.0, detector.beam_center_x, detector.beam_center_y,
+                                      detector.pixel_size_x * 1000.0, detector.pixel_size_y * 1000.0, wavelength,
+                                      oscillation_start, oscillation_width};
+            const KabschVariances kv = kabsch_variances(geom, refl, n, sx, sy, sz, si, sr, n_sig);
+            if (n) std::printf("Estimated sigma_b (degrees): %.6f\n", kv.est_sigma_b_deg);
+            if (kv.n_sigma_m)
+                std::printf("Estimated sigma_m (degrees): %.6f, calculated on %d spots\n", kv.est_sigma_m_deg, kv.n_sigma_m);
+            if (args.save_h5) {  // :1217-1262
+                try {
+                    std::vector<double> flat;
+                    for (uint32_t i = 0; i < n; ++i) {
+                        flat.push_back(refl[i].com_x);
+                        flat.push_back(refl[i].com_y);
+                        flat.push_back(refl[i].com_z);
+                    }
+                    const std::vector<int> id(n, 0);
+                    h5_write_reflection_table("results_ffs.h5", "dials/processing/group_0", flat, id, &kv.sigma_b_variance,
+                                              &kv.sigma_m_variance, &kv.bbox_depth);
+                    std::printf("Successfully wrote 3D reflections to HDF5 file\n");
+                } catch (const std::exception& e) {
+                    std::printf("Error writing data to HDF5 file: %s\n", e.what());
+                }
+            }
+        }
         std::printf("3D spot analysis complete\n");
         ffs_stack3d_destroy(stack);
+    } else if (args.save_h5) {  // :1265-1306
+        std::printf("Processing 2D spots\n");
+        try {
+            std::vector<double> flat;
+            std::vector<int> ids;
+            int id = 0;
+            for (const auto& kv : reflection_centers_2d) {  // std::map: ascending image number
+                for (float v : kv.second) flat.push_back((double)v);
+                ids.insert(ids.end(), kv.second.size() / 3, id);
+                ++id;
+            }
+            h5_write_reflection_table("results_ffs.h5", "dials/processing/group_0", flat, ids, nullptr, nullptr, nullptr);
+            std::printf("Successfully wrote %zu 2D reflections to HDF5 file\n", ids.size());
+        } catch (const std::exception& e) {
+            std::printf("Error writing data to HDF5 file: %s\n", e.what());
+        }
+        std::printf("2D spot analysis complete\n");
     }
 
     const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - all_start).count();

@@ -74,7 +74,7 @@ EXPORTS = [
     "ffs_stream_create", "ffs_stream_destroy", "ffs_stream_host_buffer", "ffs_submit",
     "ffs_submit_device", "ffs_ctx_device_layout", "ffs_wait", "ffs_stream_batch_arrays", "ffs_stream_timings",
     "ffs_submit_compressed", "ffs_decode_only", "ffs_bench_threshold", "ffs_stream_debug_planes", "ffs_stream_debug_bitplane", "ffs_selftest_sqrt", "ffs_stack3d_create",
-    "ffs_stack3d_destroy", "ffs_stack3d_add_batch", "ffs_stack3d_add_slice", "ffs_stack3d_finish",
+    "ffs_stack3d_destroy", "ffs_stack3d_add_batch", "ffs_stack3d_add_slice", "ffs_stack3d_finish", "ffs_stack3d_signals",
 ]
 
 _lib = None
@@ -115,6 +115,7 @@ def load_library():
         L.ffs_submit_compressed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64]
         L.ffs_decode_only.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                       C.POINTER(C.c_float), C.c_void_p]
+        L.ffs_stack3d_signals.argtypes = [C.c_void_p] * 7
         L.ffs_stream_debug_bitplane.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.ffs_selftest_sqrt.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
         L.ffs_device_name.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
@@ -411,6 +412,18 @@ class Stack3D:
         self.ctx._check(self._lib.ffs_stack3d_finish(self._h, C.byref(r), C.byref(n), C.byref(nc),
                                                      C.byref(fs), C.byref(fp)))
         return _copy_array(r, n.value, _Refl, REFL_DT), nc.value, fs.value, fp.value
+
+    def signals(self):
+        """Per-signal view of the last finish(): dict of x, y, z, intensity, reflection (-1 = filtered)."""
+        px, py, pi = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)()
+        pz, pr = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+        n = C.c_uint64()
+        self.ctx._check(self._lib.ffs_stack3d_signals(self._h, C.byref(px), C.byref(py), C.byref(pz), C.byref(pi),
+                                                      C.byref(pr), C.byref(n)))
+        def arr(p, dt):
+            return np.ctypeslib.as_array(p, (n.value,)).astype(dt) if n.value else np.zeros(0, dt)
+        return {"x": arr(px, np.uint32), "y": arr(py, np.uint32), "z": arr(pz, np.int32),
+                "intensity": arr(pi, np.uint32), "reflection": arr(pr, np.int32)}
 
     def close(self):
         if self._h:

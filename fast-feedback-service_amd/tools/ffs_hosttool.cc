@@ -230,6 +230,7 @@ int main(int argc, char** argv) {
         if (cmd == "synthinfo" && argc == 3) return synthinfo(argv[2]);
         if (cmd == "chunkfnv" && argc == 5)
             return chunkfnv(argv[2], std::strtoull(argv[3], nullptr, 10), std::strtoull(argv[4], nullptr, 10));
+        if (cmd == "h5stats" && argc == 4) { h5_print_group_stats(argv[2], argv[3]); return 0; }
         if (cmd == "h5support") { std::printf("%d\n", h5_supported() ? 1 : 0); return 0; }
     } catch (const std::exception& e) {
         std::printf("Error: %s\n", e.what());
@@ -237,6 +238,7 @@ int main(int argc, char** argv) {
     }
     std::printf("usage: ffs_hosttool selftest | mkshm <synth:spec> <dir> | mkcbf <synth:spec> <prefix> |\n"
                 "       mkh5 <synth:spec> <master.h5> [vds-links|vds-files|plain [frames_per_file [n_written]]] |\n"
-                "       h5info <master.h5> | synthinfo <synth:spec> | h5support\n");
+                "       h5info <master.h5> | synthinfo <synth:spec> | h5support | h5stats <file.h5> <group> |\n"
+                "       chunkfnv <chunk> <nelem> <elem bytes>\n");
     return 2;
 }

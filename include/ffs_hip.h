@@ -232,6 +232,14 @@ int ffs_stack3d_add_slice(ffs_stack3d *st, int64_t frame_id, const uint32_t *k,
 int ffs_stack3d_finish(ffs_stack3d *st, const ffs_reflection **reflections,
                        uint32_t *n_reflections, uint32_t *n_calculated,
                        uint32_t *n_filtered_size, uint32_t *n_filtered_sep);
+/* Per-signal view of the last ffs_stack3d_finish: every strong pixel of the stack in the reference's
+ * vertex order (slice by slice, ascending linear index -- the order Reflection3D::signals_ is filled
+ * in, connected_components.cc:409-446) with the index of its reflection in the array finish
+ * returned, or -1 if that spot was filtered.  For per-signal sums the caller owns, e.g.
+ * Reflection3D::variances_in_kabsch_space (connected_components.cc:159-203).  Pointers stay valid
+ * until the next finish / destroy. */
+int ffs_stack3d_signals(ffs_stack3d *st, const uint32_t **x, const uint32_t **y, const int32_t **z,
+                        const uint32_t **intensity, const int32_t **reflection, uint64_t *n);
 
 #ifdef __cplusplus
 }

@@ -1,3 +1,4 @@
+#define _GNU_SOURCE
 /*
  * ffs_oracle.c -- CPU restatement of the reference spot-finder hot path.
  * TEST INFRASTRUCTURE ONLY (see ffs_oracle.h).  Build with
@@ -595,11 +596,11 @@ typedef struct {
     uint32_t pint;
 } refl_acc;
 
-int ffs_oracle_cc3d(const ffs_oracle_slice *slices, size_t n_slices, uint32_t width,
-                    uint32_t height, uint32_t min_spot_size,
-                    float max_peak_centroid_separation, ffs_oracle_reflection **out,
-                    size_t *n_out, size_t *n_calculated, size_t *n_filtered_size_out,
-                    size_t *n_filtered_sep_out) {
+static int cc3d_impl(const ffs_oracle_slice *slices, size_t n_slices, uint32_t width,
+                     uint32_t height, uint32_t min_spot_size,
+                     float max_peak_centroid_separation, ffs_oracle_reflection **out,
+                     size_t *n_out, size_t *n_calculated, size_t *n_filtered_size_out,
+                     size_t *n_filtered_sep_out, int32_t *signal_reflection) {
     (void)height;
     size_t total = 0;
     for (size_t s = 0; s < n_slices; ++s) total += slices[s].n;
@@ -723,8 +724,14 @@ int ffs_oracle_cc3d(const ffs_oracle_slice *slices, size_t n_slices, uint32_t wi
             ++f_sep;
             continue;
         }
+        acc[i].num_pixels = -(int)kept - 1; /* reuse: -(index of the kept reflection) - 1 */
         res[kept++] = o;
     }
+    if (signal_reflection) /* membership of every signal, in vertex order (Reflection3D::signals_) */
+        for (size_t v = 0; v < total; ++v) {
+            int np = acc[labels[v]].num_pixels;
+            signal_reflection[v] = np < 0 ? -np - 1 : -1;
+        }
     *out = res;
     *n_out = kept;
     if (n_calculated) *n_calculated = num_labels;
@@ -734,6 +741,109 @@ int ffs_oracle_cc3d(const ffs_oracle_slice *slices, size_t n_slices, uint32_t wi
     free(base);
     free(parent);
     free(labels);
+    return 0;
+}
+
+int ffs_oracle_cc3d(const ffs_oracle_slice *slices, size_t n_slices, uint32_t width,
+                    uint32_t height, uint32_t min_spot_size,
+                    float max_peak_centroid_separation, ffs_oracle_reflection **out,
+                    size_t *n_out, size_t *n_calculated, size_t *n_filtered_size_out,
+                    size_t *n_filtered_sep_out) {
+    return cc3d_impl(slices, n_slices, width, height, min_spot_size, max_peak_centroid_separation,
+                     out, n_out, n_calculated, n_filtered_size_out, n_filtered_sep_out, NULL);
+}
+
+int ffs_oracle_cc3d_signals(const ffs_oracle_slice *slices, size_t n_slices, uint32_t width,
+                            uint32_t height, uint32_t min_spot_size,
+                            float max_peak_centroid_separation, int32_t *signal_reflection) {
+    ffs_oracle_reflection *tmp = NULL;
+    size_t n = 0;
+    int rc = cc3d_impl(slices, n_slices, width, height, min_spot_size,
+                       max_peak_centroid_separation, &tmp, &n, NULL, NULL, NULL, signal_reflection);
+    free(tmp);
+    return rc;
+}
+
+/* Spot variances in Kabsch space: the loop of spotfinder/spotfinder.cc:1152-1215 around
+ * Reflection3D::variances_in_kabsch_space (connected_components.cc:159-203).
+ * Panel / Scan come from the dx2 submodule, which is not under /root/reference ("parity unpinned");
+ * restated here is the flat single panel its (distance, beam centre, pixel size, image size)
+ * constructor describes: fast axis +x, slow axis -y, origin (-bx px, +by py, -distance) in mm,
+ * px_to_mm = pixel * pixel_size (no parallax correction), lab = origin + x fast + y slow. */
+static void panel_lab(const ffs_oracle_geometry *g, double xpx, double ypx, double s[3]) {
+    double xmm = xpx * g->pixel_size_x_mm, ymm = ypx * g->pixel_size_y_mm;
+    s[0] = -g->beam_center_x_px * g->pixel_size_x_mm + xmm;
+    s[1] = g->beam_center_y_px * g->pixel_size_y_mm - ymm;
+    s[2] = -g->distance_mm;
+}
+static void cross3(const double a[3], const double b[3], double o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void normalize3(double a[3]) {
+    double n = sqrt(dot3(a, a));
+    a[0] /= n;
+    a[1] /= n;
+    a[2] /= n;
+}
+
+int ffs_oracle_kabsch_variances(const ffs_oracle_slice *slices, size_t n_slices, uint32_t width,
+                                const int32_t *signal_reflection,
+                                const ffs_oracle_reflection *refl, size_t n_refl,
+                                const ffs_oracle_geometry *g, double *sigma_b_variance,
+                                double *sigma_m_variance, int32_t *bbox_depth) {
+    const double deg_to_rad = M_PI / 180.0;
+    const int image_range_0 = 1; /* Scan({1, num_images}, ...), spotfinder.cc:1164-1166 */
+    double *acc = (double *)calloc(n_refl ? n_refl * 4 : 1, sizeof(double));
+    double *frame = (double *)malloc((n_refl ? n_refl : 1) * 12 * sizeof(double));
+    if (!acc || !frame) return -1;
+    const double s0[3] = {0.0, 0.0, -1.0 / g->wavelength};
+    const double m2[3] = {1.0, 0.0, 0.0};
+    for (size_t r = 0; r < n_refl; ++r) { /* spotfinder.cc:1187-1194, cc.cc:166-175 */
+        double *f = frame + r * 12; /* s1[3] e1[3] e2[3] mags1 zeta phi */
+        panel_lab(g, (double)refl[r].com_x, (double)refl[r].com_y, f);
+        cross3(f, s0, f + 3);
+        normalize3(f + 3);
+        cross3(f, f + 3, f + 6);
+        normalize3(f + 6);
+        f[9] = sqrt(dot3(f, f));
+        f[10] = dot3(m2, f + 3);
+        f[11] = (g->oscillation_start + ((double)refl[r].com_z - image_range_0) * g->oscillation_width) * deg_to_rad;
+    }
+    size_t v = 0;
+    for (size_t z = 0; z < n_slices; ++z)
+        for (size_t i = 0; i < slices[z].n; ++i, ++v) { /* cc.cc:177-193, signals in vertex order */
+            int32_t r = signal_reflection[v];
+            if (r < 0) continue;
+            const double *f = frame + (size_t)r * 12;
+            uint64_t k = slices[z].linear_index[i];
+            double x = (double)(k % width) + 0.5, y = (double)(k / width) + 0.5, zz = (double)z + 0.5;
+            double s1p[3], d[3];
+            panel_lab(g, x, y, s1p);
+            d[0] = s1p[0] - f[0];
+            d[1] = s1p[1] - f[1];
+            d[2] = s1p[2] - f[2];
+            double eps1 = dot3(f + 3, d) / f[9];
+            double eps2 = dot3(f + 6, d) / f[9];
+            double phi_dash = (g->oscillation_start + (zz - image_range_0) * g->oscillation_width) * deg_to_rad;
+            double eps3 = (phi_dash - f[11]) * f[10];
+            double inten = (double)slices[z].intensity[i];
+            acc[4 * r + 0] += inten * eps1 * eps1;
+            acc[4 * r + 1] += inten * eps2 * eps2;
+            acc[4 * r + 2] += inten * eps3 * eps3;
+            acc[4 * r + 3] += inten;
+        }
+    for (size_t r = 0; r < n_refl; ++r) { /* cc.cc:194-199 */
+        double varx = acc[4 * r] / acc[4 * r + 3], vary = acc[4 * r + 1] / acc[4 * r + 3];
+        double varz = acc[4 * r + 2] / acc[4 * r + 3];
+        sigma_b_variance[r] = (varx + vary) / 2.0;
+        sigma_m_variance[r] = varz;
+        bbox_depth[r] = refl[r].z_max - refl[r].z_min + 1;
+    }
+    free(acc);
+    free(frame);
     return 0;
 }
 

@@ -257,6 +257,53 @@ def cc3d(slices, width: int, height: int, min_spot_size: int = 3,
     return CC3D(refl, n_calc.value, n_fs.value, n_fp.value)
 
 
+class Geometry(C.Structure):
+    """ffs_oracle_geometry: mm, pixels, Angstrom, degrees (spotfinder.cc:1157-1166)."""
+    _fields_ = [(n, C.c_double) for n in ("distance_mm", "beam_center_x_px", "beam_center_y_px", "pixel_size_x_mm",
+                                          "pixel_size_y_mm", "wavelength", "oscillation_start", "oscillation_width")]
+
+
+def _slices(slices):
+    keep = []
+    arr = (Slice * max(len(slices), 1))()
+    for i, (k, inten) in enumerate(slices):
+        k = np.ascontiguousarray(k, dtype=np.uint64)
+        inten = np.ascontiguousarray(inten, dtype=np.uint32)
+        keep.append((k, inten))
+        arr[i].n = len(k)
+        arr[i].linear_index = k.ctypes.data_as(C.POINTER(C.c_uint64))
+        arr[i].intensity = inten.ctypes.data_as(C.POINTER(C.c_uint32))
+    return arr, keep
+
+
+def cc3d_signals(slices, width, height, min_spot_size=3, max_sep=2.0) -> np.ndarray:
+    """Index of the reflection (in cc3d's output) every strong pixel belongs to, vertex order; -1 = filtered."""
+    arr, keep = _slices(slices)
+    total = sum(len(k) for k, _ in keep)
+    out = np.full(max(total, 1), -1, np.int32)
+    f = lib().ffs_oracle_cc3d_signals
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
+    if f(arr, len(slices), width, height, min_spot_size, max_sep, _ptr(out)) != 0:
+        raise MemoryError("oracle cc3d failed")
+    return out[:total]
+
+
+def kabsch_variances(slices, width, signal_reflection, reflections, geometry: Geometry):
+    """(sigma_b_variance, sigma_m_variance, bbox_depth) per reflection, spotfinder.cc:1152-1215."""
+    arr, keep = _slices(slices)
+    n = len(reflections)
+    sb, sm, depth = np.zeros(max(n, 1)), np.zeros(max(n, 1)), np.zeros(max(n, 1), np.int32)
+    refl = np.zeros(max(n, 1), REFL_DT)
+    refl[:n] = reflections
+    sig = np.ascontiguousarray(signal_reflection, np.int32)
+    f = lib().ffs_oracle_kabsch_variances
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                  C.c_void_p, C.c_void_p]
+    if f(arr, len(slices), width, _ptr(sig), _ptr(refl), n, C.byref(geometry), _ptr(sb), _ptr(sm), _ptr(depth)) != 0:
+        raise MemoryError("oracle kabsch variances failed")
+    return sb[:n], sm[:n], depth[:n]
+
+
 def cc2d_reflections(k, intensity, width, height, min_spot_size=3, max_sep=2.0) -> CC3D:
     """find_2d_components (connected_components.cc:238-266): one slice, z = 0."""
     return cc3d([(k, intensity)], width, height, min_spot_size, max_sep)

@@ -186,6 +186,83 @@ def test_hdf5_rotation_sweep(tmp_path):
     assert re.search(spots_match_regex, strip_ansi(out)).group(1) == re.search(spots_match_regex, strip_ansi(out2)).group(1)
 
 
+def _h5stats(path):
+    p = subprocess.run([TOOL, "h5stats", str(path), "dials/processing/group_0"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = {}
+    for line in p.stdout.strip().split("\n"):
+        f = line.split()
+        rows, cols = int(f[1]), int(f[2])
+        v = np.array([float(x) for x in f[3:]]).reshape(3, cols)   # min, max, mean per column
+        out[f[0]] = (rows, v)
+    return out
+
+
+def test_save_h5_rotation(tmp_path):
+    """results_ffs.h5 for a sweep (spotfinder.cc:1152-1262): centroids, ids, spot extents and the
+    Kabsch-space variances, against the oracle's restatement; same summation order, so 1e-12."""
+    from oracle import oracle as O
+    if subprocess.run([TOOL, "h5support"], capture_output=True, text=True).stdout.strip() != "1":
+        pytest.skip("built without HDF5")
+    N = 10
+    rc, out, err, _ = run_with_pipe(["synth:tinysweep:%d" % N, "--save-h5", "--min-spot-size-3d", "3", "--threads", "2",
+                                     "--batch", "4"], tmp_path)
+    assert rc == 0 and not err, (out, err)
+    frames = tiny_frames(N, sweep=True)
+    mask = np.ones((200, 300), np.uint8)
+    exp = expected(frames, mask)
+    slices = [(cc.k, cc.intensity) for cc, _ in exp]
+    want = O.cc3d(slices, 300, 200, 3, 2.0)
+    sig = O.cc3d_signals(slices, 300, 200, 3, 2.0)
+    # the synthetic source's metadata (host/readers.cc): 0.3 m, 75 um pixels, beam centre at the middle
+    # (the driver holds them as float32, spotfinder.cc:484-587; the products below are taken in double)
+    f32 = lambda v: float(np.float32(v))
+    geom = O.Geometry(f32(0.3) * 1000.0, 150.0, 100.0, f32(0.75e-4) * 1000.0, f32(0.75e-4) * 1000.0, f32(0.976), 0.0,
+                      f32(0.1))
+    sb, sm, depth = O.kabsch_variances(slices, 300, sig, want.reflections, geom)
+    st = _h5stats(tmp_path / "results_ffs.h5")
+    n = len(want.reflections)
+    assert n > 5
+    xyz = np.stack([want.reflections[c].astype(np.float64) for c in ("com_x", "com_y", "com_z")], axis=1)
+    for name, col in (("xyzobs.px.value", xyz), ("sigma_b_variance", sb[:, None]), ("sigma_m_variance", sm[:, None]),
+                      ("spot_extent_z", depth[:, None].astype(float)), ("id", np.zeros((n, 1)))):
+        rows, v = st[name]
+        assert rows == n, name
+        ref = np.stack([col.min(0), col.max(0), col.mean(0)])
+        np.testing.assert_allclose(v, ref, rtol=1e-8, atol=1e-300, err_msg=name)
+    assert (sb > 0).all() and (sm[depth > 1] > 0).all()
+    txt = strip_ansi(out)
+    m = re.search(r"Estimated sigma_b \(degrees\): ([0-9.]+)", txt)
+    assert m and abs(float(m.group(1)) - np.degrees(np.sqrt(sb.mean()))) < 1e-6
+    deep = depth >= 5
+    if deep.any():
+        m = re.search(r"Estimated sigma_m \(degrees\): ([0-9.]+), calculated on (\d+) spots", txt)
+        assert m and int(m.group(2)) == int(deep.sum())
+        assert abs(float(m.group(1)) - np.degrees(np.sqrt(sm[deep].mean()))) < 1e-6
+    assert "Successfully wrote 3D reflections to HDF5 file" in txt
+
+
+def test_save_h5_stills(tmp_path):
+    """2D: per-image centroids with one experiment id per image (spotfinder.cc:1265-1306)."""
+    if subprocess.run([TOOL, "h5support"], capture_output=True, text=True).stdout.strip() != "1":
+        pytest.skip("built without HDF5")
+    N = 4
+    rc, out, err, _ = run_with_pipe(["synth:tiny:%d" % N, "--save-h5", "--threads", "2"], tmp_path)
+    assert rc == 0 and not err, (out, err)
+    exp = expected(tiny_frames(N), np.ones((200, 300), np.uint8))
+    xyz = np.concatenate([np.stack([r.reflections[c].astype(np.float64) for c in ("com_x", "com_y", "com_z")], axis=1)
+                          for _, r in exp])
+    ids = np.concatenate([np.full(len(r.reflections), i) for i, (_, r) in enumerate(exp)])
+    st = _h5stats(tmp_path / "results_ffs.h5")
+    rows, v = st["xyzobs.px.value"]
+    assert rows == len(xyz) > 10
+    np.testing.assert_allclose(v, np.stack([xyz.min(0), xyz.max(0), xyz.mean(0)]), rtol=1e-9)
+    rows, v = st["id"]
+    assert rows == len(ids) and v[1, 0] == N - 1 and abs(v[2, 0] - ids.mean()) < 1e-9
+    assert "Successfully wrote %d 2D reflections to HDF5 file" % len(ids) in strip_ansi(out)
+    assert "sigma_b_variance" not in st
+
+
 def test_extended_algorithm_flag(tmp_path):
     """`-a dispersion_extended` (spotfinder.cc:338-342): per-frame counts from the oracle's extended mask."""
     from oracle import oracle as O

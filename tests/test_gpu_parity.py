@@ -194,3 +194,13 @@ def test_stack3d_matches_oracle(ffs):
     from util import assert_reflections_equal
     assert_reflections_equal(refl, want.reflections)
     assert len(refl) > 5 and (refl["z_max"] > refl["z_min"]).any()
+    # per-signal view (Reflection3D::signals_ order) against the oracle's membership
+    sig = stack.signals()
+    want_sig = O.cc3d_signals(slices, W, H, 4, 2.0)
+    assert np.array_equal(sig["reflection"], want_sig) and (want_sig >= 0).any() and (want_sig < 0).any()
+    k_all = np.concatenate([k for k, _ in slices]).astype(np.int64)
+    assert np.array_equal(sig["x"], k_all % W) and np.array_equal(sig["y"], k_all // W)
+    assert np.array_equal(sig["z"], np.concatenate([np.full(len(k), z) for z, (k, _) in enumerate(slices)]))
+    assert np.array_equal(sig["intensity"], np.concatenate([i for _, i in slices]))
+    counts = np.bincount(sig["reflection"][sig["reflection"] >= 0], minlength=len(refl))
+    assert np.array_equal(counts, refl["num_pixels"])
