@@ -53,25 +53,14 @@ struct RowRegsU16 {
 
 __device__ __forceinline__ void unpack_u16(const RowRegsU16& r, uint32_t (&A)[8]) {
     const uint32_t w[4] = {r.raw.x, r.raw.y, r.raw.z, r.raw.w};
-    // Most wave-rows lie inside a detector module: all 512 pixels valid.  Then the word is just
-    // p | 2^22 (one op per pixel: v_and_or / v_alignbit) -- a wave-uniform shortcut, VALU only, so
-    // it does not disturb the counted s_waitcnt of the loads in flight.
-    if (__ballot(r.mb != 0xFFu) == 0ull) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            A[2 * q] = (w[q] & 0xFFFFu) | kFlag;
-            A[2 * q + 1] = __builtin_amdgcn_alignbit(kFlag >> 16, w[q], 16);  // (w >> 16) | 2^22
-        }
-        return;
-    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const uint32_t lo = (w[q] & 0xFFFFu) | kFlag;
-        const uint32_t hi = (w[q] >> 16) | kFlag;
-        const uint32_t vlo = (uint32_t)__builtin_amdgcn_sbfe((int)r.mb, 2 * q, 1);  // 0 / ~0
-        const uint32_t vhi = (uint32_t)__builtin_amdgcn_sbfe((int)r.mb, 2 * q + 1, 1);
-        A[2 * q] = lo & vlo;
-        A[2 * q + 1] = hi & vhi;
+        A[2 * q] = (w[q] & 0xFFFFu) | kFlag;
+        A[2 * q + 1] = __builtin_amdgcn_alignbit(kFlag >> 16, w[q], 16);  // (w >> 16) | 2^22
+    }
+    if (__ballot(r.mb != 0xFFu) != 0ull) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) A[j] &= (uint32_t)__builtin_amdgcn_sbfe((int)r.mb, j, 1);  // 0 / ~0
     }
 }
 
@@ -134,7 +123,7 @@ __device__ __forceinline__ uint32_t group_tests8(const uint32_t (*q)[kQCap], int
         const float mf = (float)m, xf = (float)x, yf = (float)wq;
         const float t0 = mf * yf;
         const float af = (t0 - xf * xf) - xf * (mf - 1.0f);
-        const float cf = xf * (kB * __builtin_sqrtf(2.0f * (mf - 1.0f)));
+        const float cf = xf * (kB * __builtin_amdgcn_sqrtf(2.0f * (mf - 1.0f)));  // raw v_sqrt_f32: 1 ulp, inside the 2^-20 allowances
         const bool disp = (af + t0 * 9.5367431640625e-07f >= cf) || x >= 8192u;
         cb |= (sig && disp) ? (1u << j) : 0u;
         wq = wq - q[16 + j][e] + q[23 + j][e];  // j = 7 reads the tag word; that sum is not used
@@ -248,7 +237,7 @@ __global__ __launch_bounds__(64, 4) void k_candidates_u16(const ThresholdArgs a)
         qn = 0;
     };
 
-    constexpr int kAhead = SCREEN ? 3 : 4;  // rows of loads in flight per wave  // rows of loads in flight per wave
+    constexpr int kAhead = SCREEN ? 2 : 4;  // rows of loads in flight per wave (measured: 1, 2, 3 within 2 %)
 #pragma unroll
     for (int s = 0; s < kAhead; ++s) fetch(pre[s], s);
 
@@ -316,8 +305,9 @@ __global__ __launch_bounds__(64, 4) void k_candidates_u16(const ThresholdArgs a)
                     // no candidate.  Groups with unequal counts (next to masked pixels) always pass.
                     const uint32_t wmin = min(min(min(Wn[0], Wn[1]), min(Wn[2], Wn[3])),
                                               min(min(Wn[4], Wn[5]), min(Wn[6], Wn[7])));
-                    const uint32_t wmax = max(max(max(Wn[0], Wn[1]), max(Wn[2], Wn[3])),
-                                              max(max(Wn[4], Wn[5]), max(Wn[6], Wn[7])));
+                    auto window_max = [&]() {
+                        return max(max(max(Wn[0], Wn[1]), max(Wn[2], Wn[3])), max(max(Wn[4], Wn[5]), max(Wn[6], Wn[7])));
+                    };
                     const uint32_t x = wmin & kXMask, m = wmin >> 22;
                     bool pass;
                     uint32_t QL5 = 0, QL6 = 0, QL7 = 0, QR0 = 0, QR1 = 0, QR2 = 0;
@@ -342,7 +332,8 @@ __global__ __launch_bounds__(64, 4) void k_candidates_u16(const ThresholdArgs a)
                         const float mf = (float)m, xf = (float)x, yf = (float)ymax;
                         const float t0 = mf * yf;
                         const float af = (t0 - xf * xf) - xf * (mf - 1.0f);
-                        const float cf = xf * (kB * __builtin_sqrtf(2.0f * (mf - 1.0f)));
+                        const float cf = xf * (kB * __builtin_amdgcn_sqrtf(2.0f * (mf - 1.0f)));  // raw v_sqrt_f32: 1 ulp, inside the 2^-20 allowances
+                        const uint32_t wmax = window_max();
                         pass = (af + t0 * 9.5367431640625e-07f >= cf) || (wmax & kXMask) >= 4096u
                                || ((wmin ^ wmax) >> 22) != 0;
                     } else {
@@ -351,7 +342,12 @@ __global__ __launch_bounds__(64, 4) void k_candidates_u16(const ThresholdArgs a)
                         const uint32_t pv = amax & kXMask;
                         const int32_t b = (int32_t)(m * pv) - (int32_t)x;
                         const float bf = (float)b, tf = (float)(x * m);
-                        pass = (bf * __builtin_fabsf(bf) > kS * tf) || ((wmin ^ wmax) >> 22) != 0;
+                        // a smallest count of 49 means all eight windows are full: counts can differ only
+                        // where some lane's minimum is below 49 (wave-uniform test; inside a detector
+                        // module the window maximum is never computed)
+                        bool unequal = false;
+                        if (__ballot(m != 49u) != 0ull) unequal = ((wmin ^ window_max()) >> 22) != 0;
+                        pass = (bf * __builtin_fabsf(bf) > kS * tf) || unequal;
                     }
                     const bool flag = owned && pass;
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, so_bytes, 0);

@@ -11,7 +11,8 @@ _PKG = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 
 
 def lib_path() -> str:
-    return os.path.join(_PKG, "libffs_hip.so")
+    # FFS_HIP_LIB: an alternative build of the same library (A/B experiments); there is no fallback
+    return os.environ.get("FFS_HIP_LIB") or os.path.join(_PKG, "libffs_hip.so")
 
 
 class FfsError(RuntimeError):
