@@ -206,14 +206,14 @@ def main():
                 s = streams[step % len(streams)]
                 if len(inflight) == len(streams):
                     done = inflight.pop(0)
-                    res = done.wait()
+                    res = done.wait(copy=False)
                     gather(res, done)
                     spots += sum(len(r.boxes) for r in res)
                 s.submit_device(ptr, pitch, fstride, B, first_frame_id=(rank * k + step) * B)
                 inflight.append(s)
             elif inflight:
                 done = inflight.pop(0)
-                res = done.wait()
+                res = done.wait(copy=False)
                 gather(res, done)
                 spots += sum(len(r.boxes) for r in res)
         flush_gather()                   # every frame's spots are gathered before the clock stops

@@ -307,7 +307,9 @@ class Stream:
         self.ctx._check(self._lib.ffs_submit_device(self._h, C.c_void_p(dev_ptr), pitch_bytes,
                                                     frame_stride_bytes, n_frames, first_frame_id))
 
-    def wait(self) -> list[FrameResult]:
+    def wait(self, copy: bool = True) -> list[FrameResult]:
+        """copy=False: the box / reflection arrays are views of the library's buffers, valid until the
+        next wait() on this stream (what a C caller gets); copy=True detaches them."""
         res = C.POINTER(_FrameResult)()
         n = C.c_uint32()
         self.ctx._check(self._lib.ffs_wait(self._h, C.byref(res), C.byref(n)))
@@ -316,10 +318,13 @@ class Stream:
         nb, nr = C.c_uint32(), C.c_uint32()
         self.ctx._check(self._lib.ffs_stream_batch_arrays(self._h, C.byref(bp), C.byref(nb),
                                                           C.byref(rp), C.byref(nr)))
-        boxes = (np.frombuffer(C.string_at(bp, nb.value * BOX_DT.itemsize), BOX_DT)
-                 if nb.value else np.zeros(0, BOX_DT))
-        refls = (np.frombuffer(C.string_at(rp, nr.value * REFL_DT.itemsize), REFL_DT)
-                 if nr.value else np.zeros(0, REFL_DT))
+        def arr(ptr, count, dt):
+            if not count:
+                return np.zeros(0, dt)
+            buf = (C.c_uint8 * (count * dt.itemsize)).from_address(ptr.value)
+            a = np.frombuffer(buf, dt)
+            return a.copy() if copy else a
+        boxes, refls = arr(bp, nb.value, BOX_DT), arr(rp, nr.value, REFL_DT)
         self.last_batch_boxes, self.last_batch_reflections = boxes, refls   # whole-batch arrays
         want_refl = bool(self.ctx.params.want_reflections)
         want_list = bool(self.ctx.params.want_strong_list)
