@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--workload", default="eiger16m")
     ap.add_argument("--variants", default="1", help="comma list of FFS_K1_VARIANT values to A/B")
     ap.add_argument("--rounds", type=int, default=1)
+    ap.add_argument("--algorithm", default="dispersion", choices=["dispersion", "dispersion_extended"])
+    ap.add_argument("--decode", action="store_true", help="also run the bitshuffle-LZ4 decode kernel on the batch")
     args = ap.parse_args()
     import torch
     import ffs_amd
@@ -32,6 +34,7 @@ def main():
     B = args.batch
     ctx = ffs_amd.Context(W, H, dt, max_batch=B)
     ctx.set_mask(mask)
+    ctx.set_params(algorithm=1 if args.algorithm == "dispersion_extended" else 0)
     pitch, fstride = ctx.device_layout()
     host = np.zeros((B, H, pitch // np.dtype(dt).itemsize), dt)
     for i in range(B):
@@ -40,6 +43,14 @@ def main():
     st = ctx.stream()
     alg = float(W) * H * bpp * B
     variants = [int(v) for v in args.variants.split(",")]
+    if args.decode:
+        from ffs_amd import bslz4
+        uniq = [np.frombuffer(bslz4.compress(f), np.uint8) for f in frames]
+        chunks = [uniq[i % len(uniq)] for i in range(B)]
+        ms, _ = st.decode_only(chunks, iters=args.iters, want_frames=False)
+        raw = float(W) * H * np.dtype(dt).itemsize * B
+        print(f"decode: {ms*1e3:.1f} us/launch, {raw/ms/1e6:.0f} GB/s of pixels written, "
+              f"{sum(c.size for c in chunks)/ms/1e6:.0f} GB/s of chunks read, batch {B}", flush=True)
     for rnd in range(args.rounds):          # interleaved A/B rounds in one process
         for v in variants:
             os.environ["FFS_K1_VARIANT"] = str(v)
