@@ -34,6 +34,11 @@ class Reader {
     virtual std::optional<std::array<float, 2>> get_beam_center() const = 0;  // (y, x) px
     virtual std::optional<float> get_detector_distance() const = 0;           // m
     virtual std::array<float, 2> get_oscillation() const = 0;                 // (start, width) deg
+    // Addition to the reference's interface: true when is_image_available / get_raw_chunk may be called
+    // from several worker threads at once (one file per frame, no shared state).  The driver then skips
+    // the reader mutex the reference takes around every call (spotfinder.cc:763-765), which otherwise
+    // caps the whole pipeline at the speed of one thread copying chunks.
+    virtual bool reentrant() const { return false; }
 };
 
 // spotfinder <file>: directory -> SHMRead, *.cbf -> CBFRead, "synth:..." -> SynthRead,

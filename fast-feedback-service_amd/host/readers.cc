@@ -5,6 +5,8 @@
 // H5Read (NXmx/VDS, h5read/src/h5read.c) needs HDF5 and is a "next" row.
 #include <cstdio>
 #include <cstring>
+#include <fcntl.h>
+#include <unistd.h>
 #include <filesystem>
 #include <fstream>
 #include <sstream>
@@ -221,10 +223,18 @@ class SHMRead : public Reader {
     }
     bool is_image_available(size_t index) override { return fs::exists(image_path(index)); }
     std::span<uint8_t> get_raw_chunk(size_t index, std::span<uint8_t> dst) override {
-        std::ifstream f(image_path(index), std::ios::binary);
-        f.read(reinterpret_cast<char*>(dst.data()), (std::streamsize)dst.size());
-        return {dst.data(), (size_t)f.gcount()};
+        const int fd = ::open(image_path(index).c_str(), O_RDONLY);
+        if (fd < 0) return {dst.data(), 0};
+        size_t got = 0;
+        while (got < dst.size()) {
+            const ssize_t r = ::read(fd, dst.data() + got, dst.size() - got);
+            if (r <= 0) break;
+            got += (size_t)r;
+        }
+        ::close(fd);
+        return {dst.data(), got};
     }
+    bool reentrant() const override { return true; }  // one file per frame
     ChunkCompression get_raw_chunk_compression() override { return BITSHUFFLE_LZ4; }
     PixelDType get_dtype() const override { return dtype_; }
     size_t get_number_of_images() const override { return n_images_; }

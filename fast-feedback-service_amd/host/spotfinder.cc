@@ -465,7 +465,7 @@ int main(int argc, char** argv) {
     const auto all_start = std::chrono::steady_clock::now();
     std::atomic<uint32_t> next_image{0};
     std::atomic<uint32_t> completed{0};
-    double time_waiting = 0.0;
+    std::atomic<double> time_waiting_acc{0.0};
     std::atomic<int> failed{0};
     std::map<uint32_t, std::vector<float>> reflection_centers_2d;  // spotfinder.cc:706-708
     std::mutex reflection_centers_2d_mutex;
@@ -501,7 +501,9 @@ int main(int argc, char** argv) {
                 const uint32_t offset_image_num = image_num + args.start_index;  // :756
                 std::span<uint8_t> chunk;
                 {
-                    std::scoped_lock lock(reader_mutex);  // readers are not thread-safe (:763-765)
+                    // readers are not thread-safe in general (:763-765); those that say they are skip the lock
+                    std::unique_lock<std::mutex> lock(reader_mutex, std::defer_lock);
+                    if (!reader.reentrant()) lock.lock();
                     const auto w0 = std::chrono::steady_clock::now();
                     while (!reader.is_image_available(offset_image_num) && !g_stop.load()) {
                         const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - last_received).count();
@@ -514,7 +516,7 @@ int main(int argc, char** argv) {
                     }
                     if (g_stop.load()) break;
                     last_received = std::chrono::steady_clock::now();
-                    time_waiting += std::chrono::duration<double>(last_received - w0).count();
+                    time_waiting_acc.fetch_add(std::chrono::duration<double>(last_received - w0).count());
                     for (;;) {  // zero-length reads on /dev/shm: retry (:805-821)
                         chunk = gpu_decode ? reader.get_raw_chunk(offset_image_num, {host + cursor, host_bytes - cursor})
                                            : reader.get_raw_chunk(offset_image_num, raw);
@@ -730,6 +732,7 @@ int main(int argc, char** argv) {
     const uint32_t done = completed.load();
     std::printf("\n%d images in %.2f s (\033[1;34m%.2f GBps\033[0m) (\033[1;34m%.1f fps\033[0m)\n", (int)done, total,
                 (double)width * height * bytes_per_pixel * done / total / 1e9, done / total);
+    const double time_waiting = time_waiting_acc.load();
     if (time_waiting < 10) std::printf("Total time waiting for images to appear: %.0f ms\n", time_waiting * 1000);
     else std::printf("Total time waiting for images to appear: %.2f s\n", time_waiting);
     pipe.reset();
