@@ -197,10 +197,13 @@ def main():
         if pending == G:
             flush_gather()
 
+    strong_px = 0
+
     def run_steps(k):
         """k steps, `streams` batches in flight"""
         inflight = []
         spots = 0
+        nonlocal strong_px
         for step in range(k + len(streams)):
             if step < k:
                 s = streams[step % len(streams)]
@@ -209,6 +212,7 @@ def main():
                     res = done.wait(copy=False)
                     gather(res, done)
                     spots += sum(len(r.boxes) for r in res)
+                    strong_px += sum(r.num_strong_pixels for r in res)
                 s.submit_device(ptr, pitch, fstride, B, first_frame_id=(rank * k + step) * B)
                 inflight.append(s)
             elif inflight:
@@ -216,6 +220,7 @@ def main():
                 res = done.wait(copy=False)
                 gather(res, done)
                 spots += sum(len(r.boxes) for r in res)
+                strong_px += sum(r.num_strong_pixels for r in res)
         flush_gather()                   # every frame's spots are gathered before the clock stops
         return spots
 
@@ -226,6 +231,7 @@ def main():
 
     run_steps(args.warmup)
     barrier()
+    strong_px = 0
     t0 = time.perf_counter()
     spots = run_steps(args.steps)
     barrier()
@@ -324,7 +330,8 @@ def main():
                                    f"{B} frames/step/GPU resident in HBM, spots+centroids returned to host",
                        "frames_per_step_per_gpu": B, "streams": len(streams),
                        "spot_gather": (f"RCCL all_gather every {G} batches" if use_dist else "none (single GPU)"),
-                       "spots_per_frame": round(spots / max(1, args.steps * B), 1)},
+                       "spots_per_frame": round(spots / max(1, args.steps * B), 1),
+                       "strong_pixels_per_frame": round(strong_px / max(1, args.steps * B), 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,

@@ -632,6 +632,9 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     ca.cap = c->cap;
     ca.max_comp = c->max_comp;
     ca.pixel_bytes = c->pixel_bytes;
+    // (Measured and dropped: one workgroup per frame with the union-find forest, the entries' columns and
+    // the row offsets in LDS instead of k_union + k_label -- correct, but 64 us against 50 + 24 us: a
+    // frame's ~18 k entries are compute-bound on a single CU.)
     // (Measured and dropped: writing the list from the exact stage itself, each tile getting its list
     // offset by a decoupled look-back over the tiles before it -- 263 us against 87 + 4 + 63 us for
     // the three kernels: tiles that wait for a predecessor's count hold their CU slots.)
