@@ -28,6 +28,20 @@ static_assert(offsetof(ReflOut, sum_intensity) == offsetof(ffs_reflection, sum_i
 
 static thread_local std::string g_create_error;
 
+// Error text is kept per calling thread (several worker threads drive their own streams of one
+// context; a shared std::string would be a data race exactly when things go wrong).  `ctx->err = ...`
+// and `ctx->err.c_str()` keep reading naturally at the call sites.
+struct ThreadError {
+    static std::string& text() {
+        static thread_local std::string t;
+        return t;
+    }
+    const ThreadError& operator=(const std::string& m) const { text() = m; return *this; }
+    const ThreadError& operator=(const char* m) const { text() = m; return *this; }
+    const char* c_str() const { return text().c_str(); }
+    operator std::string() const { return text(); }
+};
+
 struct ffs_ctx {
     int device = 0;
     Layout L{};
@@ -38,7 +52,7 @@ struct ffs_ctx {
     int n_tiles = 0, n_strips = 0;
     ffs_params params{};
     uint8_t* d_maskbits = nullptr;
-    mutable std::string err;
+    ThreadError err;  // the calling thread's most recent error on any context
 };
 
 #define HIP_TRY(ctx, expr)                                                              \
@@ -153,7 +167,7 @@ extern "C" int ffs_device_total_mem(int device, uint64_t* bytes) {
 }
 
 extern "C" const char* ffs_last_error(const ffs_ctx* ctx) {
-    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();  // both are per-thread texts
 }
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }

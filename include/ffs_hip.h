@@ -120,7 +120,9 @@ int ffs_device_total_mem(int device, uint64_t *bytes);
 int ffs_ctx_create(int device, uint32_t width, uint32_t height, int pixel_bytes,
                    uint32_t max_batch, uint32_t max_strong_per_frame, ffs_ctx **out);
 void ffs_ctx_destroy(ffs_ctx *ctx);
-const char *ffs_last_error(const ffs_ctx *ctx); /* ctx may be NULL: last error of ffs_ctx_create */
+/* Text of the calling thread's most recent error (kept per thread: worker threads drive their own
+ * streams of one context).  ctx may be NULL: last error of ffs_ctx_create. */
+const char *ffs_last_error(const ffs_ctx *ctx);
 
 /* upload_mask(), spotfinder/spotfinder.cc:61-108: host_mask = W*H bytes, nonzero = valid,
  * or NULL for "all valid" (the reference's cudaMemset(1) branch). */
