@@ -1,0 +1,78 @@
+"""GPU: randomised parity sweep -- frame sizes around the kernels' strip / tile / block boundaries,
+both pixel widths, random masks, background levels from empty to bright, saturated pixels, random
+algorithm parameters, both algorithms and flavours, batches, raw and compressed input.  Everything the
+C ABI returns is compared with the oracle, bit for bit.  Seeds are fixed: a failure names its case."""
+import numpy as np
+import pytest
+
+from ffs_amd import bslz4
+from oracle import oracle as O
+from util import assert_frame_matches_oracle
+
+pytestmark = pytest.mark.gpu
+
+# widths around 496-px strips (u16), 240-px strips (u32), 56-px strips (extended first pass), 128-px pitch
+WIDTHS = [8, 31, 55, 56, 57, 127, 128, 129, 239, 241, 495, 496, 497, 512, 991, 993, 1030]
+HEIGHTS = [1, 2, 6, 7, 8, 9, 15, 17, 33, 64, 101]
+
+
+def random_case(seed):
+    rng = np.random.default_rng(seed)
+    W = int(rng.choice(WIDTHS))
+    H = int(rng.choice(HEIGHTS))
+    dtype = np.uint16 if rng.random() < 0.7 else np.uint32
+    lam = float(rng.choice([0.0, 0.05, 0.5, 2.0, 20.0, 300.0]))
+    n = int(rng.integers(1, 4))
+    frames = rng.poisson(lam, (n, H, W)).astype(np.int64)
+    for f in frames:                                     # spots, some saturated, some on the borders
+        for _ in range(int(rng.integers(0, max(2, W * H // 400)))):
+            cy, cx = int(rng.integers(0, H)), int(rng.integers(0, W))
+            s = rng.uniform(0.5, 2.0)
+            pk = rng.choice([20, 200, 5000, 70000 if dtype == np.uint16 else 3e6])
+            y0, y1, x0, x1 = max(cy - 5, 0), min(cy + 6, H), max(cx - 5, 0), min(cx + 6, W)
+            yy, xx = np.mgrid[y0:y1, x0:x1]
+            f[y0:y1, x0:x1] += rng.poisson(pk * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s)))
+    top = np.iinfo(np.uint16).max if dtype == np.uint16 else (1 << 26)   # u32: some pixels above 2^24
+    frames = np.minimum(frames, top).astype(dtype)
+    mask = np.ones((H, W), np.uint8)
+    kind = rng.integers(0, 4)
+    if kind == 1:
+        mask[rng.random((H, W)) < 0.03] = 0
+    elif kind == 2:
+        mask[:, W // 2:W // 2 + max(1, W // 20)] = 0
+        mask[H // 3:H // 3 + max(1, H // 10), :] = 0
+    elif kind == 3:
+        mask[rng.random((H, W)) < 0.5] = 0
+    params = dict(min_count=int(rng.choice([2, 2, 3, 5, 10])), nsig_b=float(rng.choice([6.0, 6.0, 3.0, 1.5])),
+                  nsig_s=float(rng.choice([3.0, 3.0, 2.0, 5.5])), threshold=float(rng.choice([0.0, 0.0, 4.0])),
+                  min_spot_size=int(rng.choice([3, 1, 0, 6])),
+                  max_peak_centroid_separation=float(rng.choice([2.0, 0.5, 10.0])))
+    algo = int(rng.integers(0, 2))
+    flavour = int(rng.integers(0, 2)) if algo else 0
+    max_valid = int(rng.choice([-1, -1, 1000]))
+    return W, H, dtype, frames, mask, params, algo, flavour, max_valid, bool(rng.random() < 0.4)
+
+
+@pytest.mark.parametrize("seed", range(240))
+def test_random_case(ffs, seed):
+    W, H, dtype, frames, mask, prm, algo, flavour, max_valid, compressed = random_case(seed)
+    ctx = ffs.Context(W, H, dtype, max_batch=len(frames))
+    ctx.set_mask(mask)
+    ctx.set_params(algorithm=algo, extended_flavour=flavour, max_valid=max_valid, want_strong_mask=1, want_strong_list=1,
+                   want_reflections=1, **prm)
+    st = ctx.stream()
+    res = (st.process_compressed([bslz4.compress(f) for f in frames], first_frame_id=5) if compressed
+           else st.process(frames, first_frame_id=5))
+    p = O.DispParams()
+    O.lib().ffs_oracle_default_disp_params(O.C.byref(p))
+    p.min_count, p.nsig_b, p.nsig_s, p.threshold = prm["min_count"], prm["nsig_b"], prm["nsig_s"], prm["threshold"]
+    for i, (fr, img) in enumerate(zip(res, frames)):
+        assert fr.frame_id == 5 + i
+        if algo:
+            strong = O.dispersion_extended(img, mask, p, flavour=flavour, max_valid=float(max_valid))
+        else:
+            strong = O.dispersion(img, mask, p)
+            if max_valid >= 0:
+                strong = strong & (img <= max_valid)          # thresholding.cu:208-215
+        assert_frame_matches_oracle(fr, img, mask, min_spot_size=prm["min_spot_size"],
+                                    max_sep=prm["max_peak_centroid_separation"], strong=strong)
