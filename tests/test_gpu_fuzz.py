@@ -76,3 +76,76 @@ def test_random_case(ffs, seed):
                 strong = strong & (img <= max_valid)          # thresholding.cu:208-215
         assert_frame_matches_oracle(fr, img, mask, min_spot_size=prm["min_spot_size"],
                                     max_sep=prm["max_peak_centroid_separation"], strong=strong)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_stack3d(ffs, seed):
+    """Random sweeps: blobs that persist over a random number of frames, gaps in the frame numbering,
+    slices added out of order; 3D components, their reflections and the per-signal view against the oracle."""
+    from util import assert_reflections_equal
+    rng = np.random.default_rng(1000 + seed)
+    W, H = int(rng.choice([64, 130, 300])), int(rng.choice([40, 90, 200]))
+    NZ = int(rng.integers(2, 9))
+    vol = rng.poisson(float(rng.choice([0.2, 2.0])), (NZ, H, W)).astype(np.int64)
+    for _ in range(int(rng.integers(3, 40))):
+        cz, cy, cx = rng.integers(0, NZ), rng.integers(0, H), rng.integers(0, W)
+        sz, s, pk = rng.uniform(0.3, 2.5), rng.uniform(0.6, 1.8), rng.choice([30, 300, 4000])
+        zz, yy, xx = np.mgrid[0:NZ, max(cy - 5, 0):min(cy + 6, H), max(cx - 5, 0):min(cx + 6, W)]
+        vol[:, max(cy - 5, 0):min(cy + 6, H), max(cx - 5, 0):min(cx + 6, W)] += rng.poisson(
+            pk * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s) - (zz - cz) ** 2 / (2 * sz * sz)))
+    frames = np.minimum(vol, 65535).astype(np.uint16)
+    mask = np.ones((H, W), np.uint8)
+    if rng.random() < 0.5:
+        mask[rng.random((H, W)) < 0.02] = 0
+    min3d, sep = int(rng.choice([1, 3, 5])), float(rng.choice([2.0, 1.0, 50.0]))
+    ctx = ffs.Context(W, H, np.uint16, max_batch=3)
+    ctx.set_mask(mask)
+    ctx.set_params(want_strong_list=1, min_spot_size_3d=min3d, max_peak_centroid_separation=sep)
+    st = ctx.stream()
+    stack = ffs.Stack3D(ctx)
+    ids = np.sort(rng.choice(np.arange(100, 100 + 3 * NZ), NZ, replace=False))     # gaps in the numbering
+    lists = {}
+    for z0 in range(0, NZ, 3):
+        res = st.process(frames[z0:z0 + 3])
+        for j, r in enumerate(res):
+            lists[int(ids[z0 + j])] = (r.strong_k.copy(), r.strong_intensity.copy())
+    for fid in rng.permutation(list(lists)):                                        # out of order
+        stack.add_slice(int(fid), *lists[int(fid)])
+    refl, n_calc, fs, fp = stack.finish()
+    slices = [lists[int(f)] for f in ids]
+    want = O.cc3d(slices, W, H, min3d, sep)
+    assert (n_calc, fs, fp) == (want.n_calculated, want.n_filtered_size, want.n_filtered_sep)
+    assert_reflections_equal(refl, want.reflections)
+    assert np.array_equal(stack.signals()["reflection"], O.cc3d_signals(slices, W, H, min3d, sep))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_chunks_decode(ffs, seed):
+    """Decoder against data with very different LZ4 structure: sparse bit planes (many short sequences),
+    ramps and periodic patterns (overlapping matches of every small offset), noise, constant frames."""
+    if bslz4.liblz4() is None:
+        pytest.skip("no liblz4")
+    rng = np.random.default_rng(2000 + seed)
+    W, H = int(rng.choice([64, 97, 333, 1030])), int(rng.choice([17, 64, 129]))
+    dtype = np.uint16 if seed % 3 else np.uint32
+    kind = seed % 8
+    if kind == 0:
+        img = (rng.random((H, W)) < 0.01) * rng.integers(1, 4, (H, W))
+    elif kind == 1:
+        img = np.arange(W * H).reshape(H, W) % int(rng.integers(2, 40))
+    elif kind == 2:
+        img = np.repeat(rng.integers(0, 1 << 12, (H, 1)), W, axis=1)
+    elif kind == 3:
+        img = rng.integers(0, np.iinfo(dtype).max, (H, W), endpoint=True)
+    elif kind == 4:
+        img = np.zeros((H, W)); img[H // 2, W // 2] = np.iinfo(dtype).max
+    elif kind == 5:
+        img = rng.poisson(0.05, (H, W))
+    elif kind == 6:
+        img = rng.poisson(40.0, (H, W))
+    else:
+        img = np.tile(rng.integers(0, 300, (1, int(rng.integers(1, 9)))), (H, W))[:H, :W]
+    img = np.ascontiguousarray(img).astype(dtype)
+    ctx = ffs.Context(W, H, dtype, max_batch=2)
+    _, got = ctx.stream().decode_only([bslz4.compress(img, "lz4"), bslz4.compress(img[::-1].copy(), "lz4")])
+    assert np.array_equal(got[0], img) and np.array_equal(got[1], img[::-1])
