@@ -172,28 +172,41 @@ def main():
     use_dist = dist is not None
     G = max(1, args.gather_every)
     spot_cap = 2048 * B
+    # Two sets of buffers: a group's pinned block must not be overwritten while its H2D copy is in flight.
     if use_dist:
-        pack_host = torch.empty((G, spot_cap + 1, 4), dtype=torch.float32).pin_memory()
-        pack_dev = torch.empty((G, spot_cap + 1, 4), dtype=torch.float32, device=dev)
-        gather_buf = torch.empty((world * G, spot_cap + 1, 4), dtype=torch.float32, device=dev)
-    pending = 0
+        pack_host = [torch.empty((G, spot_cap + 1, 4), dtype=torch.float32).pin_memory() for _ in range(2)]
+        pack_dev = [torch.empty((G, spot_cap + 1, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+        gather_buf = [torch.empty((world * G, spot_cap + 1, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+        buf_free = [None, None]            # event after which pack_host[b] may be overwritten
+    cur, pending = 0, 0
+    gather_s = [0.0, 0.0]   # host seconds: packing, collectives
 
     def flush_gather():
-        nonlocal pending
+        nonlocal cur, pending
         if not use_dist or pending == 0:
             return
+        tg = time.perf_counter()
         for g in range(pending, G):      # unused slots of a partial group: zero spots
-            pack_host[g, spot_cap, 0] = 0
-        pack_dev.copy_(pack_host, non_blocking=True)
-        dist.all_gather_into_tensor(gather_buf.view(-1), pack_dev.view(-1))
-        pending = 0
+            pack_host[cur][g, spot_cap, 0] = 0
+        pack_dev[cur].copy_(pack_host[cur], non_blocking=True)
+        dist.all_gather_into_tensor(gather_buf[cur].view(-1), pack_dev[cur].view(-1))
+        ev = torch.cuda.Event()
+        ev.record()
+        buf_free[cur] = ev
+        cur, pending = cur ^ 1, 0
+        gather_s[1] += time.perf_counter() - tg
 
     def gather(results, stream):
         nonlocal pending
         if not use_dist:
             return
-        D.pack_spots_batch(results, stream.last_batch_reflections, spot_cap, pack_host[pending].numpy())
+        tg = time.perf_counter()
+        if pending == 0 and buf_free[cur] is not None:
+            buf_free[cur].synchronize()
+        # (frame_id, x, y, z) rows straight from the library's reflection records (C loop)
+        stream.pack_spot_centres(pack_host[cur][pending].numpy(), spot_cap)
         pending += 1
+        gather_s[0] += time.perf_counter() - tg
         if pending == G:
             flush_gather()
 
@@ -343,6 +356,9 @@ def main():
         # the whole threshold stage (candidate + exact kernels) against the same algorithmic bytes
         out["roofline"]["threshold_stage_frac"] = round(
             alg_bytes / ((ms_cand + ms_exact) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if use_dist:
+            out["config"]["gather_host_ms_per_step"] = {"pack": round(gather_s[0] / (args.steps + args.warmup) * 1e3, 4),
+                                                        "collective": round(gather_s[1] / (args.steps + args.warmup) * 1e3, 4)}
         if streamed is not None:
             out["streamed_frames_per_s"] = round(streamed * world, 1)
             out["streamed_compressed"] = {

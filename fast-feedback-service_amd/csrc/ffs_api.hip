@@ -1150,6 +1150,30 @@ extern "C" int ffs_stream_timings(ffs_stream* s, float ms[5]) {
     return FFS_OK;
 }
 
+extern "C" int ffs_stream_spot_centres(ffs_stream* s, float* rows4, uint32_t cap, uint32_t* n_written) {
+    if (!s || !rows4) return FFS_ERR_INVALID;
+    if (s->busy) {
+        s->ctx->err = "ffs_stream_spot_centres: a batch is in flight";
+        return FFS_ERR_INVALID;
+    }
+    uint32_t n = 0;
+    for (const ffs_frame_result& r : s->results) {
+        const float id = (float)r.frame_id;
+        for (uint32_t q = 0; q < r.n_reflections && n < cap; ++q, ++n) {
+            float* row = rows4 + (size_t)n * 4;
+            row[0] = id;
+            row[1] = r.reflections[q].com_x;
+            row[2] = r.reflections[q].com_y;
+            row[3] = r.reflections[q].com_z;
+        }
+    }
+    float* last = rows4 + (size_t)cap * 4;
+    last[0] = (float)n;
+    last[1] = last[2] = last[3] = 0.0f;
+    if (n_written) *n_written = n;
+    return FFS_OK;
+}
+
 extern "C" int ffs_stream_debug_planes(ffs_stream* s, const uint8_t** strong_bytes, size_t* mask_pitch,
                                        size_t* mask_fstride) {
     if (!s) return FFS_ERR_INVALID;

@@ -74,7 +74,7 @@ EXPORTS = [
     "ffs_ctx_apply_resolution_mask", "ffs_ctx_get_mask", "ffs_ctx_set_params",
     "ffs_stream_create", "ffs_stream_destroy", "ffs_stream_host_buffer", "ffs_submit",
     "ffs_submit_device", "ffs_ctx_device_layout", "ffs_wait", "ffs_stream_batch_arrays", "ffs_stream_timings",
-    "ffs_submit_compressed", "ffs_decode_only", "ffs_bench_threshold", "ffs_stream_debug_planes", "ffs_stream_debug_bitplane", "ffs_selftest_sqrt", "ffs_stack3d_create",
+    "ffs_submit_compressed", "ffs_decode_only", "ffs_stream_spot_centres", "ffs_bench_threshold", "ffs_stream_debug_planes", "ffs_stream_debug_bitplane", "ffs_selftest_sqrt", "ffs_stack3d_create",
     "ffs_stack3d_destroy", "ffs_stack3d_add_batch", "ffs_stack3d_add_slice", "ffs_stack3d_finish", "ffs_stack3d_signals",
 ]
 
@@ -113,6 +113,7 @@ def load_library():
                                           C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.ffs_stream_debug_planes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                               C.POINTER(C.c_size_t)]
+        L.ffs_stream_spot_centres.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.ffs_submit_compressed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64]
         L.ffs_decode_only.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                       C.POINTER(C.c_float), C.c_void_p]
@@ -371,6 +372,14 @@ class Stream:
                                                       frame_stride_bytes, n_frames, iters,
                                                       C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def pack_spot_centres(self, out: np.ndarray, cap: int) -> int:
+        """Rows (frame_id, x, y, z) of the last batch's reflections into `out` ((cap + 1, 4) float32,
+        last row = count); the layout dist.pack_spots produces."""
+        assert out.dtype == np.float32 and out.flags.c_contiguous and out.size >= (cap + 1) * 4
+        n = C.c_uint32()
+        self.ctx._check(self._lib.ffs_stream_spot_centres(self._h, out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return n.value
 
     def debug_bitplane(self, frame_in_batch: int, which: int) -> np.ndarray:
         """0 = strong plane, 1 = extended first pass, 2 = extended eroded signal region (H x W uint8)."""

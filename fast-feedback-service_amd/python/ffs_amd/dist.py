@@ -45,9 +45,16 @@ def pack_spots_batch(results, refl_all: np.ndarray, cap: int, out: np.ndarray | 
     ids = np.fromiter((r.frame_id for r in results), np.float32, len(results))
     n = int(min(counts.sum(), cap))
     out[:n, 0] = np.repeat(ids, counts)[:n]
-    out[:n, 1] = refl_all["com_x"][:n]
-    out[:n, 2] = refl_all["com_y"][:n]
-    out[:n, 3] = refl_all["com_z"][:n]
+    # com_x, com_y, com_z are three consecutive float32 fields of the record: one strided copy
+    off = refl_all.dtype.fields["com_x"][1]
+    if (refl_all.dtype.itemsize % 4 == 0 and off % 4 == 0 and refl_all.dtype.fields["com_y"][1] == off + 4
+            and refl_all.dtype.fields["com_z"][1] == off + 8 and refl_all.flags.c_contiguous):
+        v = refl_all.view(np.float32).reshape(-1, refl_all.dtype.itemsize // 4)
+        out[:n, 1:4] = v[:n, off // 4:off // 4 + 3]
+    else:
+        out[:n, 1] = refl_all["com_x"][:n]
+        out[:n, 2] = refl_all["com_y"][:n]
+        out[:n, 3] = refl_all["com_z"][:n]
     out[cap] = (n, 0, 0, 0)
     return out
 

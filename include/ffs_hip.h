@@ -194,6 +194,13 @@ int ffs_stream_batch_arrays(ffs_stream *s, const ffs_box **boxes, uint32_t *n_bo
  * [3] D2H, [4] total.  (The reference prints Copy/Kernel/Post Copy/Post, spotfinder.cc:1056-1076.) */
 int ffs_stream_timings(ffs_stream *s, float ms[5]);
 
+/* Centres of mass of the last batch's reflections as rows (frame_id, x, y, z) of float32 -- the
+ * payload of `--output-for-index` (spot_centers, spotfinder.cc:919-933,1004-1006), in frame order;
+ * used to feed a multi-GPU gather without a per-frame loop on the caller's side.  Writes at most
+ * `cap` rows, then one more row (n_written, 0, 0, 0): rows4 must hold (cap + 1) * 4 floats.
+ * Needs want_reflections. */
+int ffs_stream_spot_centres(ffs_stream *s, float *rows4, uint32_t cap, uint32_t *n_written);
+
 /* ---- kernel-only entry points (bench.py roofline leg, kernel parity tests) ------------------ */
 /* Runs only the two threshold kernels on device-resident frames, `iters` times back to back
  * on the stream, and returns the average duration of ONE launch of the dominant

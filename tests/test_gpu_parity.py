@@ -204,3 +204,22 @@ def test_stack3d_matches_oracle(ffs):
     assert np.array_equal(sig["intensity"], np.concatenate([i for _, i in slices]))
     counts = np.bincount(sig["reflection"][sig["reflection"] >= 0], minlength=len(refl))
     assert np.array_equal(counts, refl["num_pixels"])
+
+
+def test_spot_centres_rows(ffs):
+    """ffs_stream_spot_centres: the (frame_id, x, y, z) rows fed to the multi-GPU gather equal what
+    dist.pack_spots builds from the per-frame results."""
+    from ffs_amd import dist as D
+    rng = np.random.default_rng(3)
+    H, W = 120, 200
+    ctx = ffs.Context(W, H, np.uint16, max_batch=3)
+    st = ctx.stream()
+    frames = np.stack([_spotty(rng, H, W, 1.0, 25) for _ in range(3)])
+    res = st.process(frames, first_frame_id=40)
+    want = D.pack_spots(res, 500)
+    got = np.full((501, 4), -1, np.float32)
+    n = st.pack_spot_centres(got, 500)
+    assert n == int(want[500, 0]) > 5 and np.array_equal(got[:n], want[:n]) and np.array_equal(got[500], want[500])
+    assert (got[n:500] == -1).all()                      # rows beyond the count are left alone
+    small = np.zeros((4, 4), np.float32)                 # capacity smaller than the batch: truncated, count says so
+    assert st.pack_spot_centres(small, 3) == 3 and np.array_equal(small[:3], want[:3]) and small[3, 0] == 3
