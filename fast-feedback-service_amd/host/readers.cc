@@ -80,6 +80,7 @@ class SynthRead : public Reader {
         ffs_synth_frame(&p_, (uint32_t)index, dst.data());
         return {dst.data(), bytes};
     }
+    bool reentrant() const override { return true; }  // frames are a pure function of (parameters, index)
     ChunkCompression get_raw_chunk_compression() override { return NONE; }
     size_t get_number_of_images() const override { return n_images_; }
     PixelDType get_dtype() const override { return p_.pixel_bytes == 2 ? PixelDType::UINT16 : PixelDType::UINT32; }
