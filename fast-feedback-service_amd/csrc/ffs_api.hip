@@ -472,12 +472,19 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
     a.bytes_frame_stride = L.bytes_frame_stride;
     a.n_strips = c->n_strips;
     a.n_tiles = c->n_tiles;
-    // enough waves to fill 256 CUs several times over, bands no shorter than 24 rows
-    const long long target_waves = 8192;
-    long long rows = ((long long)L.H * c->n_strips * n_frames + target_waves - 1) / target_waves;
-    rows = std::max<long long>(24, std::min<long long>(rows, 512));
-    a.band_rows = (int)rows;
-    a.n_bands = (L.H + a.band_rows - 1) / a.band_rows;
+    // Bands: enough waves to fill the 256 CUs several times over, bands no shorter than 24 rows -- and a
+    // whole number of bands per XCD.  The candidate kernels deal the bands round-robin to the 8 XCDs
+    // (band = xcd + 8 k, so that neighbouring strips share an L2); with 29 bands three XCDs had a band
+    // less to do than the others and the launch waited for the busy five: 511 us per 32 Eiger frames, against 430-440 us with 48 or 56.
+    long long target_waves = 16384;
+    if (const char* e = std::getenv("FFS_K1_TARGET_WAVES")) target_waves = std::max(1, std::atoi(e));
+    {
+        const long long per_band = std::max<long long>(1, (long long)c->n_strips * n_frames);
+        long long nb = std::max<long long>(1, std::min<long long>(target_waves / per_band, L.H / 24));
+        if (nb >= 8) nb = nb / 8 * 8;
+        a.band_rows = (int)std::min<long long>(512, (L.H + nb - 1) / nb);
+        a.n_bands = (L.H + a.band_rows - 1) / a.band_rows;
+    }
     a.kS = (float)(p.nsig_s * p.nsig_s * (1.0 - 1.0 / 65536.0));
     a.kB = (float)(p.nsig_b * (1.0 - 1.0 / 1048576.0));
     a.min_count = p.min_count;
@@ -499,7 +506,8 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
     }
     a.ext_strips = (L.pitch_px + kExtOwnedPx - 1) / kExtOwnedPx;
     {   // one pixel per lane: bands of 64..256 rows keep the 6-row warm-up below 10 %
-        long long er = ((long long)L.H * a.ext_strips * n_frames + 4 * target_waves - 1) / (4 * target_waves);
+        const long long ext_target = 8192;
+        long long er = ((long long)L.H * a.ext_strips * n_frames + 4 * ext_target - 1) / (4 * ext_target);
         er = std::max<long long>(64, std::min<long long>(er, 256));
         a.ext_band_rows = (int)er;
         a.ext_bands = (L.H + a.ext_band_rows - 1) / a.ext_band_rows;
