@@ -480,7 +480,8 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
     if (const char* e = std::getenv("FFS_K1_TARGET_WAVES")) target_waves = std::max(1, std::atoi(e));
     {
         const long long per_band = std::max<long long>(1, (long long)c->n_strips * n_frames);
-        long long nb = std::max<long long>(1, std::min<long long>(target_waves / per_band, L.H / 24));
+        // (bands of at least 72 rows keep the 6-row warm-up of every band below 8 %)
+        long long nb = std::max<long long>(1, std::min<long long>(target_waves / per_band, L.H / 72));
         if (nb >= 8) nb = nb / 8 * 8;
         a.band_rows = (int)std::min<long long>(512, (L.H + nb - 1) / nb);
         a.n_bands = (L.H + a.band_rows - 1) / a.band_rows;
