@@ -94,6 +94,8 @@ struct ffs_stream {
     size_t h_img_bytes = 0;
     uint32_t* h_counts = nullptr;  // [max_batch] num_strong | [max_batch] n_comp | [max_batch*8] summary | [1] overflow
     ReflOut* h_recs = nullptr;
+    ReflOut* h_recs_dev = nullptr;  // device-side address of h_recs when the records are written straight to the host
+    bool direct_recs = false;
     uint32_t *h_list_k = nullptr, *h_list_i = nullptr;
     uint8_t* h_mask = nullptr;
     // state of the batch in flight
@@ -436,6 +438,14 @@ extern "C" int ffs_stream_create(ffs_ctx* c, ffs_stream** out) {
     STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), (B * 10 + 1) * 4, hipHostMallocDefault));
     STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_recs), B * (size_t)c->max_comp * sizeof(ReflOut),
                              hipHostMallocDefault));
+    // k_finalize can write the (few MB of) records straight into this pinned, device-visible buffer:
+    // no copy kernel after it.  FFS_DIRECT_RECS=0 keeps the device buffer + copy (A/B).
+    s->direct_recs = !(std::getenv("FFS_DIRECT_RECS") && std::atoi(std::getenv("FFS_DIRECT_RECS")) == 0);
+    if (s->direct_recs
+        && hipHostGetDevicePointer(reinterpret_cast<void**>(&s->h_recs_dev), s->h_recs, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        s->direct_recs = false;
+    }
     STREAM_TRY(hipMemsetAsync(s->d_overflow, 0, 4, s->st));
     STREAM_TRY(hipStreamSynchronize(s->st));
 #undef STREAM_TRY
@@ -685,7 +695,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     sa.n_slices = 1;
     sa.min_spot_size = p.min_spot_size;
     sa.max_sep = p.max_peak_centroid_separation;
-    sa.recs = s->d_recs;
+    sa.recs = s->direct_recs ? s->h_recs_dev : s->d_recs;
     sa.summary = s->d_summary;
     int gx = 32;
     if (const char* e = std::getenv("FFS_CCL_GRID")) gx = std::max(1, std::atoi(e));
@@ -700,8 +710,12 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     // small counts first; ffs_wait() sizes the record copy from them
     const size_t B = c->max_batch;
     HIP_TRY(c, hipMemcpyAsync(s->h_counts, s->d_num_strong, (B * 10 + 1) * 4, hipMemcpyDeviceToHost, s->st2));
-    s->spec_recs_copied = std::min<uint64_t>((uint64_t)s->spec_recs_per_frame * n, (uint64_t)B * c->max_comp);
-    HIP_TRY(c, hipMemcpyAsync(s->h_recs, s->d_recs, s->spec_recs_copied * sizeof(ReflOut), hipMemcpyDeviceToHost, s->st2));
+    if (s->direct_recs) {
+        s->spec_recs_copied = (uint64_t)B * c->max_comp;  // everything is on the host already
+    } else {
+        s->spec_recs_copied = std::min<uint64_t>((uint64_t)s->spec_recs_per_frame * n, (uint64_t)B * c->max_comp);
+        HIP_TRY(c, hipMemcpyAsync(s->h_recs, s->d_recs, s->spec_recs_copied * sizeof(ReflOut), hipMemcpyDeviceToHost, s->st2));
+    }
     HIP_TRY(c, hipEventRecord(s->ev[4], s->st2));
     s->busy = true;
     s->n_frames = n;
