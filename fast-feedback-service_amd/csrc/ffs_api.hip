@@ -84,7 +84,7 @@ struct ffs_stream {
     std::thread job;          // ffs_submit_compressed's helper (block index + launches); joined by ffs_wait
     int job_rc = 0;
     std::string job_err;
-    uint32_t *d_tile_counts = nullptr, *d_tile_offsets = nullptr, *d_num_strong = nullptr, *d_row_off = nullptr;
+    uint32_t *d_tile_counts = nullptr, *d_num_strong = nullptr, *d_row_off = nullptr;
     uint32_t *d_list_k = nullptr, *d_list_i = nullptr, *d_parent = nullptr, *d_comp_id = nullptr;
     uint32_t *d_n_comp = nullptr, *d_overflow = nullptr, *d_summary = nullptr;
     CompAcc* d_acc = nullptr;
@@ -353,7 +353,7 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     if (s->st) (void)hipStreamSynchronize(s->st);
     if (s->st2 && s->st2 != s->st) { (void)hipStreamSynchronize(s->st2); (void)hipStreamDestroy(s->st2); }
     // (d_n_comp, d_summary and d_overflow live inside the d_num_strong allocation)
-    void* dev[] = {s->d_comp, s->d_tab, s->d_dplane, s->d_eplane, s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_tile_offsets, s->d_num_strong,
+    void* dev[] = {s->d_comp, s->d_tab, s->d_dplane, s->d_eplane, s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_num_strong,
                    s->d_list_k, s->d_list_i, s->d_parent, s->d_comp_id, s->d_acc, s->d_recs};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -417,7 +417,6 @@ extern "C" int ffs_stream_create(ffs_ctx* c, ffs_stream** out) {
     STREAM_TRY(dmalloc(&s->d_bits, B * L.plane_frame_stride));
     STREAM_TRY(dmalloc(&s->d_sbytes, B * L.bytes_frame_stride));
     STREAM_TRY(dmalloc(&s->d_tile_counts, B * c->n_tiles * 4));
-    STREAM_TRY(dmalloc(&s->d_tile_offsets, B * c->n_tiles * 4));
 
     // per-frame counters in the layout of h_counts, so that one copy brings them all back:
     // [B] strong pixels | [B] components | [B][8] summary | [1] overflow / error flag
@@ -647,7 +646,6 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     ca.pitch = (uint32_t)pitch;
     ca.bits = s->d_bits;
     ca.tile_counts = s->d_tile_counts;
-    ca.tile_offsets = s->d_tile_offsets;
     ca.num_strong = s->d_num_strong;
     ca.row_off = s->d_row_off;
     ca.list_k = s->d_list_k;
@@ -670,8 +668,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     // frame's ~18 k entries are compute-bound on a single CU.)
     // (Measured and dropped: writing the list from the exact stage itself, each tile getting its list
     // offset by a decoupled look-back over the tiles before it -- 263 us against 87 + 4 + 63 us for
-    // the three kernels: tiles that wait for a predecessor's count hold their CU slots.)
-    hipLaunchKernelGGL(k_scan_tiles, dim3(n), dim3(256), 0, s->st2, ca);
+    // the then three kernels: tiles that wait for a predecessor's count hold their CU slots.)
     if (c->pixel_bytes == 2)
         hipLaunchKernelGGL(k_emit_list<uint16_t>, dim3(c->n_tiles, n), dim3(256), 0, s->st2, ca);
     else

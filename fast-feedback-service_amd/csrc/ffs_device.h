@@ -70,7 +70,6 @@ struct CclArgs {
     uint32_t pitch;
     const uint8_t* bits;       // strong bit planes
     const uint32_t* tile_counts;
-    uint32_t* tile_offsets;    // [n][n_tiles]
     uint32_t* num_strong;      // [n]
     uint32_t* row_off;         // [n][H+1] list offset of the first strong pixel of each image row
     uint32_t* list_k;          // [n][cap] ascending linear index y*W + x

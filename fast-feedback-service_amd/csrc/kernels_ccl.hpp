@@ -3,7 +3,7 @@
 // Replaces the reference's host stage (spotfinder/connected_components/connected_components.cc):
 // a std::map of strong pixels, a Boost adjacency_list with edges to k+1 and k+width, and
 // boost::connected_components (DFS => components numbered by their minimum vertex).  Here:
-//   k_scan_tiles / k_emit_list : strong bit plane -> per-frame list sorted by linear index
+//   k_emit_list                : strong bit plane -> per-frame list sorted by linear index
 //                                (popcount + wave/block prefix sums; no sort needed)
 //   k_union                    : lock-free union-find, union-by-minimum-index (atomicMin hooks),
 //                                neighbours found by binary search in the sorted list
@@ -43,40 +43,41 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
 
 // ---- compaction ------------------------------------------------------------------------------------
 
-// One block per frame: exclusive scan of the exact stage's per-tile strong counts.
-__global__ __launch_bounds__(256) void k_scan_tiles(const CclArgs a) {
-    __shared__ uint32_t s_wave[4];
-    const int frame = blockIdx.x;
-    const uint32_t* cnt = a.tile_counts + (uint64_t)frame * a.n_tiles;
-    uint32_t* off = a.tile_offsets + (uint64_t)frame * a.n_tiles;
-    uint32_t running = 0;
-    for (int t0 = 0; t0 < a.n_tiles; t0 += 256) {
-        const int t = t0 + threadIdx.x;
-        const uint32_t v = t < a.n_tiles ? cnt[t] : 0u;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan<256>(v, s_wave, total);
-        if (t < a.n_tiles) off[t] = running + ex;
-        running += total;
-    }
-    if (threadIdx.x == 0) {
-        a.num_strong[frame] = running;
-        a.row_off[(uint64_t)frame * (a.H + 1) + a.H] = min(running, a.cap);
-        if (running > a.cap) atomicOr(a.overflow, 1u);
-    }
-}
-
 // One block per (tile, frame): bits -> (k, intensity) in raster order; parent[i] = i.
+// The tile's offset in the frame's list is the sum of the counts of the tiles before it: every block
+// adds them up itself (at most a few hundred words from L2) instead of waiting for a scan kernel.
 template <typename PixelT>
 __global__ __launch_bounds__(256) void k_emit_list(const CclArgs a) {
     __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_base;
     const int tile = blockIdx.x, frame = blockIdx.y;
-    const uint32_t count = a.tile_counts[(uint64_t)frame * a.n_tiles + tile];
+    const uint32_t* counts = a.tile_counts + (uint64_t)frame * a.n_tiles;
+    const uint32_t count = counts[tile];
     const int y0 = tile * kTileRows;
     const int rows = min(kTileRows, a.H - y0);
     uint32_t* row_off = a.row_off + (uint64_t)frame * (a.H + 1);
+    {
+        uint32_t part = 0;
+        for (int t = threadIdx.x; t < tile; t += 256) part += counts[t];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+        if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t base = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            s_base = base;
+            if (tile == a.n_tiles - 1) {  // the last tile knows the frame's total
+                const uint32_t total = base + count;
+                a.num_strong[frame] = total;
+                row_off[a.H] = min(total, a.cap);
+                if (total > a.cap) atomicOr(a.overflow, 1u);
+            }
+        }
+        __syncthreads();
+    }
+    const uint32_t tile_base = s_base;
     if (count == 0) {  // block-uniform: empty rows all start where the tile starts
-        if ((int)threadIdx.x < rows)
-            row_off[y0 + threadIdx.x] = min(a.tile_offsets[(uint64_t)frame * a.n_tiles + tile], a.cap);
+        if ((int)threadIdx.x < rows) row_off[y0 + threadIdx.x] = min(tile_base, a.cap);
         return;
     }
     const int dpr = a.mpitch >> 2;
@@ -88,7 +89,6 @@ __global__ __launch_bounds__(256) void k_emit_list(const CclArgs a) {
     uint32_t* li = a.list_i + (uint64_t)frame * a.cap;
     uint32_t* par = a.parent + (uint64_t)frame * a.cap;
     // each thread owns a contiguous run of words, so ONE block scan gives raster order
-    const uint32_t tile_base = a.tile_offsets[(uint64_t)frame * a.n_tiles + tile];
     const int per = (ndw + 255) / 256;
     const int g0 = min((int)threadIdx.x * per, ndw), g1 = min(g0 + per, ndw);
     uint32_t mine = 0;
