@@ -80,3 +80,37 @@ def test_bad_arguments_are_rejected(ffs):
     with pytest.raises(ffs.FfsError):
         st.submit(np.zeros((64, 64), np.uint16))             # batch already in flight
     assert st.wait()[0].num_strong_pixels == 0
+
+
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_many_components_per_frame_both_record_paths(ffs, direct, monkeypatch):
+    """Thousands of components per frame: more than the 256 per frame the copy path brings back
+    speculatively (so its top-up copy runs) and enough to exercise the direct-to-host path too."""
+    from util import assert_frame_matches_oracle
+    monkeypatch.setenv("FFS_DIRECT_RECS", direct)
+    rng = np.random.default_rng(8)
+    H, W = 300, 400
+    frames = rng.poisson(0.05, (2, H, W)).astype(np.uint16)          # lonely photons: thousands of tiny components
+    frames[rng.random((2, H, W)) < 0.01] += 9
+    mask = np.ones((H, W), np.uint8)
+    ctx = ffs.Context(W, H, np.uint16, max_batch=2)
+    ctx.set_params(min_spot_size=1, want_strong_list=1, max_peak_centroid_separation=50.0)
+    st = ctx.stream()                                                   # (the env var is read here)
+    for rep in range(2):                                                # 2nd pass: speculative size has grown
+        res = st.process(frames)
+        for fr, img in zip(res, frames):
+            assert_frame_matches_oracle(fr, img, mask, min_spot_size=1, max_sep=50.0)
+        assert min(fr.n_components for fr in res) > 600
+
+
+def test_stream_closed_with_a_compressed_batch_in_flight(ffs):
+    """Destroying a stream joins the helper thread of ffs_submit_compressed and drains the GPU work."""
+    from ffs_amd import bslz4
+    from util import make_frame
+    img, _ = make_frame(W=300, H=200, seed=2, n_spots=30)
+    ctx = ffs.Context(300, 200, np.uint16, max_batch=2)
+    st = ctx.stream()
+    st.submit_compressed([bslz4.compress(img), bslz4.compress(img)])
+    st.close()                                                          # no wait()
+    st2 = ctx.stream()
+    assert st2.process(img)[0].num_strong_pixels > 0                    # the context is still usable
