@@ -116,8 +116,8 @@ def cpu_baseline(frames, mask, ext=False, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="frames per step and per GPU")
     ap.add_argument("--workload", default="eiger16m", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=2, help="batches in flight per GPU")
