@@ -582,7 +582,11 @@ static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_
         else
             hipLaunchKernelGGL(k_candidates_u16<true>, grid, block, 0, s->st, a);
     }
-    else
+    else if (a.variant >= 1) {
+        // the queue variant ORs its few candidate nibbles into a zeroed plane (a lane pair shares a byte)
+        (void)hipMemsetAsync(a.bits, 0, (size_t)n_frames * a.plane_frame_stride, s->st);
+        hipLaunchKernelGGL(k_candidates_u32_q, grid, block, 0, s->st, a);
+    } else
         hipLaunchKernelGGL(k_candidates_u32, grid, block, 0, s->st, a);
 }
 
@@ -592,6 +596,8 @@ static void launch_exact(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frame
         hipLaunchKernelGGL(k_exact_w64<uint16_t>, grid, dim3(64), 0, s->st, a);
     else if (s->ctx->pixel_bytes == 2)
         hipLaunchKernelGGL(k_exact<uint16_t>, grid, block, 0, s->st, a);
+    else if (a.variant >= 1)
+        hipLaunchKernelGGL(k_exact_w64<uint32_t>, grid, dim3(64), 0, s->st, a);
     else
         hipLaunchKernelGGL(k_exact<uint32_t>, grid, block, 0, s->st, a);
 }

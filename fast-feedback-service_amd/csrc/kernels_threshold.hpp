@@ -556,6 +556,221 @@ __global__ __launch_bounds__(64) void k_candidates_u32(const ThresholdArgs a) {
     }
 }
 
+// ---- 32-bit pixels with the group screen and the LDS queue (variant 1) ------------------------------
+// k_candidates_u32 above tests every pixel for signal only, and ~0.5 % of all pixels reach the exact
+// kernel, which then gathers seven rows for each of them (260 us per 32 Jungfrau frames).  This variant
+// is the 16-bit kernel's scheme on the 4-pixel lane groups: running column sums of p^2 (pixels clamped
+// to 8191 first -- a window that holds a larger pixel has sum p >= 8192 and skips the dispersion test
+// anyway --, so the differences fit a 24-bit multiply and the 32-bit sums are exact whenever they are
+// used), a group screen (largest centre pixel against smallest window sum), and per-pixel signal AND
+// dispersion tests on queued groups.  A lane pair shares one byte of the candidate plane, so the plane
+// is zeroed before the launch and the drain ORs the few non-zero nibbles in with atomics.
+constexpr int kQWords32 = 24;  // 0-3 WX, 4-7 WM, 8-11 centre X, 12 centre flags, 13-22 column sums of p^2, 23 tag
+
+__device__ __forceinline__ uint32_t group_tests4(const uint32_t (*q)[kQCap], int e, float kS, float kB) {
+    uint32_t wq = 0;  // window j sums cq[j .. j+6] of L1 L2 L3 c0 c1 c2 c3 R0 R1 R2
+#pragma nounroll
+    for (int t = 0; t < 7; ++t) wq += q[13 + t][e];
+    const uint32_t fc = q[12][e];
+    uint32_t cb = 0;
+#pragma unroll 2
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t x = q[j][e], m = q[4 + j][e], p = q[8 + j][e];
+        const float xf = (float)x, mf = (float)m, pf = (float)p;
+        // signal, as in k_candidates_u32: b = m p - x in float32 with the error bound 2^-22 (m p + x) added
+        const float sp = __builtin_fmaf(mf, pf, xf);
+        const float bf = __builtin_fmaf(mf, pf, -xf);
+        const float u = __builtin_fmaf(sp, 2.384185791015625e-07f, bf);
+        const bool sig = u * __builtin_fabsf(u) > kS * (xf * mf);
+        // dispersion, as in group_tests8 (exact sums while x < 8192)
+        const float yf = (float)wq;
+        const float t0 = mf * yf;
+        const float af = (t0 - xf * xf) - xf * (mf - 1.0f);
+        const float cf = xf * (kB * __builtin_amdgcn_sqrtf(2.0f * (mf - 1.0f)));
+        const bool disp = (af + t0 * 9.5367431640625e-07f >= cf) || x >= 8192u;
+        const uint32_t big = ((fc >> (4 + j)) & ~(fc >> j)) & 1u;  // valid centre >= 2^24: the exact kernel decides
+        cb |= ((sig && disp) || big) ? (1u << j) : 0u;
+        wq = wq - q[13 + j][e] + q[20 + j][e];  // j = 3 reads the tag word; that sum is not used
+    }
+    return cb;
+}
+
+__global__ __launch_bounds__(64) void k_candidates_u32_q(const ThresholdArgs a) {
+    __shared__ uint32_t s_q[kQWords32][kQCap];
+    const int lane = threadIdx.x;
+    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int strip = qb % a.n_strips;
+    const int band = xcd + 8 * (qb / a.n_strips);
+    if (band >= a.n_bands) return;
+    const int frame = blockIdx.y;
+    const int yb0 = band * a.band_rows;
+    const int yb1 = min(yb0 + a.band_rows, a.H);
+    const int lx0 = strip * kStripOwnedPx32 + kStripStartOffset32 + lane * kLanePx32;
+    const bool active = lx0 >= 0 && lx0 + kLanePx32 <= a.pitch_px;
+    const bool owned = active && lane >= 2 && lane <= 61;
+    const int cx = active ? lx0 : 0;
+
+    const rsrc_t r_img = make_rsrc((const uint8_t*)a.image + (uint64_t)frame * a.frame_stride, (uint32_t)a.H * a.pitch);
+    const rsrc_t r_mask = make_rsrc(a.maskbits, (uint32_t)a.H * a.mpitch);
+    const rsrc_t r_sb = make_rsrc(a.strong_bytes + (uint64_t)frame * a.bytes_frame_stride, (uint32_t)a.H * a.bpitch);
+    uint32_t* const plane = reinterpret_cast<uint32_t*>(a.bits + (uint64_t)frame * a.plane_frame_stride);  // zeroed by the host
+    constexpr uint32_t kOob = 0x80000000u;
+    const uint32_t off_px = (uint32_t)cx * 4u;
+    const uint32_t off_bit = active ? ((uint32_t)cx >> 3) : kOob;
+    const uint32_t zcol = (uint32_t)strip * 256u + (uint32_t)lane * 4u;
+    const uint32_t off_byte_st = zcol < (uint32_t)a.bpitch ? zcol : kOob;
+    const uint32_t nib = (uint32_t)cx & 4u;
+    const int sx0 = strip * kStripOwnedPx32 + kStripStartOffset32;
+
+    const int total = (yb1 - yb0) + 6;
+    const float kS = a.kS, kB = a.kB;
+
+    uint32_t ringX[7][4], ringF[7];
+    uint32_t colX[4], colM[4], colQ[4];
+    RowRegsU32 pre[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        ringF[s] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ringX[s][j] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { colX[j] = 0; colM[j] = 0; colQ[j] = 0; }
+
+    auto fetch = [&](RowRegsU32& dst, int i) {
+        const int yin = yb0 - 3 + i;
+        const bool ok = (i < total) & (yin >= 0) & (yin < a.H);
+        const uint32_t kill = ok ? 0u : kOob;
+        const uint32_t row = ok ? (uint32_t)yin : 0u;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_img, off_px | kill, row * a.pitch, 0);
+        dst.raw = make_uint4(v[0], v[1], v[2], v[3]);
+        const uint32_t mb = __builtin_amdgcn_raw_buffer_load_b8(r_mask, off_bit | kill, row * a.mpitch, 0);
+        dst.mb = (mb >> nib) & 0xFu;
+    };
+    auto push = [&](int s, const RowRegsU32& r) {
+        const uint32_t p[4] = {r.raw.x, r.raw.y, r.raw.z, r.raw.w};
+        uint32_t fl = r.mb << 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool sm = ((r.mb >> j) & 1u) && p[j] < (1u << 24);  // mm, standalone.cc:90
+            const uint32_t X = sm ? p[j] : 0u;
+            const uint32_t Mn = sm ? 1u : 0u;
+            const uint32_t Mo = (ringF[s] >> j) & 1u;
+            const int32_t cn = (int32_t)min(X, 8191u), co = (int32_t)min(ringX[s][j], 8191u);
+            colQ[j] += (uint32_t)((cn - co) * (cn + co));
+            colX[j] += X - ringX[s][j];
+            colM[j] += Mn - Mo;
+            ringX[s][j] = X;
+            fl |= Mn << j;
+        }
+        ringF[s] = fl;
+    };
+
+    int qn = 0;
+    auto drain = [&]() {
+        if (lane < qn) {
+            const uint32_t cb = group_tests4(s_q, lane, kS, kB);
+            if (cb) {
+                const uint32_t tag = s_q[23][lane], row = tag >> 6, ln = tag & 63u;
+                const uint32_t x0 = (uint32_t)(sx0 + (int)ln * kLanePx32);  // first pixel of the group (multiple of 4)
+                atomicOr(plane + (uint64_t)row * (a.mpitch >> 2) + (x0 >> 5), cb << (x0 & 31u));
+            }
+        }
+        qn = 0;
+    };
+
+    constexpr int kAhead = 2;
+#pragma unroll
+    for (int s = 0; s < kAhead; ++s) fetch(pre[s], s);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const RowRegsU32 r = pre[s];
+        fetch(pre[(s + kAhead) % 7], s + kAhead);
+        push(s, r);
+    }
+
+    for (int base = 6;; base += 7) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const int s = (6 + t) % 7;
+            const int sc = (s + 4) % 7;
+            const int i = base + t;
+            if (i >= total) goto rows_done;
+            {
+                const RowRegsU32 r = pre[s];
+                fetch(pre[(s + kAhead) % 7], i + kAhead);
+                push(s, r);
+
+                uint32_t WX[4], WM[4];
+                {
+                    const uint32_t L1 = from_left(colX[1]), L2 = from_left(colX[2]), L3 = from_left(colX[3]);
+                    const uint32_t R0 = from_right(colX[0]), R1 = from_right(colX[1]), R2 = from_right(colX[2]);
+                    WX[0] = (L1 + L2 + L3) + (colX[0] + colX[1] + colX[2]) + colX[3];
+                    WX[1] = WX[0] - L1 + R0;
+                    WX[2] = WX[1] - L2 + R1;
+                    WX[3] = WX[2] - L3 + R2;
+                }
+                {
+                    const uint32_t L1 = from_left(colM[1]), L2 = from_left(colM[2]), L3 = from_left(colM[3]);
+                    const uint32_t R0 = from_right(colM[0]), R1 = from_right(colM[1]), R2 = from_right(colM[2]);
+                    WM[0] = (L1 + L2 + L3) + (colM[0] + colM[1] + colM[2]) + colM[3];
+                    WM[1] = WM[0] - L1 + R0;
+                    WM[2] = WM[1] - L2 + R1;
+                    WM[3] = WM[2] - L3 + R2;
+                }
+                const int yout = __builtin_amdgcn_readfirstlane(yb0 + (i - 6));
+                __builtin_amdgcn_raw_buffer_store_b32(0u, r_sb, off_byte_st, (uint32_t)yout * a.bpitch, 0);
+
+                // group screen: b_j <= m pmax - xmin for all four pixels when their windows hold the same
+                // count; same float32 form and error bound as the per-pixel test
+                const uint32_t fc = ringF[sc];
+                const uint32_t xmin = min(min(WX[0], WX[1]), min(WX[2], WX[3]));
+                const uint32_t mmin = min(min(WM[0], WM[1]), min(WM[2], WM[3]));
+                const uint32_t mmax = max(max(WM[0], WM[1]), max(WM[2], WM[3]));
+                const uint32_t pmax = max(max(ringX[sc][0], ringX[sc][1]), max(ringX[sc][2], ringX[sc][3]));
+                const float xf = (float)xmin, mf = (float)mmin, pf = (float)pmax;
+                const float sp = __builtin_fmaf(mf, pf, xf);
+                const float bf = __builtin_fmaf(mf, pf, -xf);
+                const float u = __builtin_fmaf(sp, 2.384185791015625e-07f, bf);
+                const bool any_big = (((fc >> 4) & ~fc) & 0xFu) != 0u;
+                const bool pass = (u * __builtin_fabsf(u) > kS * (xf * mf)) || mmin != mmax || any_big;
+                const bool flag = owned && pass;
+                const unsigned long long fm = __ballot(flag);
+                if (fm) {  // wave-uniform
+                    const int nf = __popcll(fm);
+                    if (qn + nf > kQCap) drain();
+                    const uint32_t QL1 = from_left(colQ[1]), QL2 = from_left(colQ[2]), QL3 = from_left(colQ[3]);
+                    const uint32_t QR0 = from_right(colQ[0]), QR1 = from_right(colQ[1]), QR2 = from_right(colQ[2]);
+                    if (flag) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                        const int e = qn + (int)rank;
+                        if (e >= kQCap) {
+                            // queue full: the exact kernel takes the whole group
+                            const uint32_t x0 = (uint32_t)cx;
+                            atomicOr(plane + (uint64_t)yout * (a.mpitch >> 2) + (x0 >> 5), 0xFu << (x0 & 31u));
+                        } else {
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) {
+                                s_q[w][e] = WX[w];
+                                s_q[4 + w][e] = WM[w];
+                                s_q[8 + w][e] = ringX[sc][w];
+                                s_q[16 + w][e] = colQ[w];
+                            }
+                            s_q[12][e] = fc;
+                            s_q[13][e] = QL1; s_q[14][e] = QL2; s_q[15][e] = QL3;
+                            s_q[20][e] = QR0; s_q[21][e] = QR1; s_q[22][e] = QR2;
+                            s_q[23][e] = ((uint32_t)yout << 6) | (uint32_t)lane;
+                        }
+                    }
+                    qn = min(qn + nf, kQCap);
+                }
+            }
+        }
+    }
+rows_done:
+    if (qn > 0) drain();
+}
+
 // ================================================================================================
 // K2: exact predicate on candidates
 // ================================================================================================
@@ -762,6 +977,7 @@ __global__ __launch_bounds__(64) void k_exact_w64(const ThresholdArgs a) { exact
 template __global__ void k_exact<uint16_t>(const ThresholdArgs);
 template __global__ void k_exact<uint32_t>(const ThresholdArgs);
 template __global__ void k_exact_w64<uint16_t>(const ThresholdArgs);
+template __global__ void k_exact_w64<uint32_t>(const ThresholdArgs);
 // extended first pass, exact stage (many more candidates per tile than the standard path)
 template <typename PixelT>
 __global__ __launch_bounds__(256) void k_exact_disp(const ThresholdArgs a) { exact_tile<PixelT, 256, kExactListCap, 2>(a); }
