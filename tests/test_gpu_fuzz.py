@@ -149,3 +149,12 @@ def test_random_chunks_decode(ffs, seed):
     ctx = ffs.Context(W, H, dtype, max_batch=2)
     _, got = ctx.stream().decode_only([bslz4.compress(img, "lz4"), bslz4.compress(img[::-1].copy(), "lz4")])
     assert np.array_equal(got[0], img) and np.array_equal(got[1], img[::-1])
+
+
+@pytest.mark.parametrize("seed", range(0, 240, 6))
+def test_random_case_alternative_kernels(ffs, seed, monkeypatch):
+    """The same sweep through the A/B variants that are not the default: per-pixel-signal candidate
+    kernels (both pixel widths) and the one-pixel-per-lane extended first pass."""
+    monkeypatch.setenv("FFS_K1_VARIANT", "0")
+    monkeypatch.setenv("FFS_EXT_VARIANT", "0")
+    test_random_case(ffs, seed)
