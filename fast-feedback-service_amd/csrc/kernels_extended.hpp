@@ -188,22 +188,52 @@ __device__ bool ext_final_strong(const ThresholdArgs& a, const uint8_t* img, con
     const uint32_t colmask = (1u << ncol) - 1u;
     uint32_t m2 = 0;
     unsigned long long x2 = 0;
-    for (int yy = max(y - 5, 0); yy <= min(y + 5, H - 1); ++yy) {
-        const uint32_t* mrow = reinterpret_cast<const uint32_t*>(a.maskbits) + (uint64_t)yy * dpr;
-        const uint32_t* erow = reinterpret_cast<const uint32_t*>(eplane) + (uint64_t)yy * dpr;
-        const bool two = w0 + 1 < dpr;
-        const unsigned long long mw = (unsigned long long)mrow[w0] | (two ? (unsigned long long)mrow[w0 + 1] << 32 : 0ull);
-        const unsigned long long ew = (unsigned long long)erow[w0] | (two ? (unsigned long long)erow[w0 + 1] << 32 : 0ull);
-        // background for the second SAT: valid and not in the signal region (:552-571, :755)
-        uint32_t inc = (uint32_t)((mw & ~ew) >> sh) & colmask;
-        const PixelT* prow = reinterpret_cast<const PixelT*>(img + (uint64_t)yy * a.pitch) + xs;
-        while (inc) {
-            const int q = __ffs(inc) - 1;
-            inc &= inc - 1;
-            const uint32_t p = prow[q];
-            if (sizeof(PixelT) == 2 || p < (1u << 24)) {  // compute_sat's BIG, :379,391
-                m2 += 1;
-                x2 += p;
+    if constexpr (sizeof(PixelT) == 2) {
+        // 12 pixels from an even column cover the (<= 11 wide) window row: six aligned dword loads per row,
+        // no data-dependent loop, four rows of loads in flight
+        const int bx = min(xs & ~1, a.pitch_px - 12);
+        const int wb = bx >> 5, shb = bx & 31;
+        const uint32_t cm = (colmask << (xs - bx)) & 0xFFFu;
+        const bool two = wb + 1 < dpr;
+#pragma unroll 4
+        for (int r = 0; r < 11; ++r) {
+            const int yy = y - 5 + r;
+            const bool ok = yy >= 0 && yy < H;
+            const int yc = ok ? yy : y;
+            const uint32_t* mrow = reinterpret_cast<const uint32_t*>(a.maskbits) + (uint64_t)yc * dpr;
+            const uint32_t* erow = reinterpret_cast<const uint32_t*>(eplane) + (uint64_t)yc * dpr;
+            const unsigned long long mw = (unsigned long long)mrow[wb] | (two ? (unsigned long long)mrow[wb + 1] << 32 : 0ull);
+            const unsigned long long ew = (unsigned long long)erow[wb] | (two ? (unsigned long long)erow[wb + 1] << 32 : 0ull);
+            const uint32_t* prow = reinterpret_cast<const uint32_t*>(img + (uint64_t)yc * a.pitch + (uint64_t)bx * 2u);
+            uint32_t pw[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) pw[q] = prow[q];
+            // background for the second SAT: valid and not in the signal region (:552-571, :755)
+            const uint32_t inc = ok ? ((uint32_t)((mw & ~ew) >> shb) & cm) : 0u;
+            m2 += __popc(inc);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                x2 += ((inc >> (2 * q)) & 1u) ? (pw[q] & 0xFFFFu) : 0u;
+                x2 += ((inc >> (2 * q + 1)) & 1u) ? (pw[q] >> 16) : 0u;
+            }
+        }
+    } else {
+        for (int yy = max(y - 5, 0); yy <= min(y + 5, H - 1); ++yy) {
+            const uint32_t* mrow = reinterpret_cast<const uint32_t*>(a.maskbits) + (uint64_t)yy * dpr;
+            const uint32_t* erow = reinterpret_cast<const uint32_t*>(eplane) + (uint64_t)yy * dpr;
+            const bool two = w0 + 1 < dpr;
+            const unsigned long long mw = (unsigned long long)mrow[w0] | (two ? (unsigned long long)mrow[w0 + 1] << 32 : 0ull);
+            const unsigned long long ew = (unsigned long long)erow[w0] | (two ? (unsigned long long)erow[w0 + 1] << 32 : 0ull);
+            uint32_t inc = (uint32_t)((mw & ~ew) >> sh) & colmask;
+            const PixelT* prow = reinterpret_cast<const PixelT*>(img + (uint64_t)yy * a.pitch) + xs;
+            while (inc) {
+                const int q = __ffs(inc) - 1;
+                inc &= inc - 1;
+                const uint32_t p = prow[q];
+                if (p < (1u << 24)) {  // compute_sat's BIG, :379,391
+                    m2 += 1;
+                    x2 += p;
+                }
             }
         }
     }
