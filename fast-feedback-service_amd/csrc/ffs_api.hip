@@ -703,6 +703,9 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     int gx = 32;
     if (const char* e = std::getenv("FFS_CCL_GRID")) gx = std::max(1, std::atoi(e));
     const dim3 gseg((unsigned)gx, n), b256(256);
+    static const int link_runs = std::getenv("FFS_LINK_RUNS") ? std::atoi(std::getenv("FFS_LINK_RUNS")) : 1;
+    sa.runs_linked = link_runs;
+    if (link_runs) hipLaunchKernelGGL(k_link_runs, gseg, b256, 0, s->st2, sa);
     hipLaunchKernelGGL(k_union<false>, gseg, b256, 0, s->st2, sa);
     hipLaunchKernelGGL(k_label, dim3(n), dim3(1024), 0, s->st2, sa);
     hipLaunchKernelGGL(k_reduce<false>, gseg, b256, 0, s->st2, sa);

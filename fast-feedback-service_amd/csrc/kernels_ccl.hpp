@@ -152,6 +152,24 @@ __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t 
     }
 }
 
+// 2D pre-pass: entries whose left neighbour in the list is k - 1 belong to the same horizontal run (the
+// reference's k + 1 edge, row wrap included).  Hook each of them to an earlier member of its run with
+// a plain store -- no atomics, no contention -- so that k_union only has the vertical edges left, and
+// of those only one per pair of overlapping runs.  (The backward walk is capped: pointing at any
+// earlier member of the run keeps the forest valid, parents always being smaller indices.)
+__global__ __launch_bounds__(256) void k_link_runs(const SegArgs a) {
+    const int seg = blockIdx.y;
+    const uint32_t n = min(a.seg_n[seg], (uint32_t)a.seg_stride);
+    const uint32_t* k = a.list_k + (uint64_t)seg * a.seg_stride;
+    uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        if (i == 0 || k[i - 1] + 1 != k[i]) continue;  // a run start keeps parent[i] = i
+        uint32_t j = i - 1;
+        for (int steps = 0; steps < 16 && j > 0 && k[j - 1] + 1 == k[j]; ++steps) --j;
+        parent[i] = j;
+    }
+}
+
 template <bool IS3D>
 __global__ __launch_bounds__(256) void k_union(const SegArgs a) {
     const int seg = blockIdx.y;
@@ -169,7 +187,8 @@ __global__ __launch_bounds__(256) void k_union(const SegArgs a) {
         }
         const uint32_t ki = k[i];
         // right neighbour: k + 1, with NO row-end check (connected_components.cc:62-70)
-        if (i + 1 < s_end && k[i + 1] == ki + 1) uf_union(parent, i, i + 1);
+        const bool runs_linked = !IS3D && a.runs_linked;  // k_link_runs did these edges already
+        if (!runs_linked && i + 1 < s_end && k[i + 1] == ki + 1) uf_union(parent, i, i + 1);
         // neighbour below: k + width (:63, :73-78); it lives in the next image row, whose
         // list range is known from the compaction (row_off), so the search is a few steps
         {
@@ -184,7 +203,13 @@ __global__ __launch_bounds__(256) void k_union(const SegArgs a) {
                 const uint32_t mid = lo + ((hi - lo) >> 1);
                 if (k[mid] < key) lo = mid + 1; else hi = mid;
             }
-            if (lo < s_end && k[lo] == key) uf_union(parent, i, lo);
+            if (lo < s_end && k[lo] == key) {
+                // with the runs linked, one edge per pair of overlapping runs is enough: the leftmost
+                // overlapping pair has a run start on one side (if neither pixel starts its run, the
+                // pair one column to the left is adjacent too)
+                const bool needed = !runs_linked || i == 0 || k[i - 1] + 1 != ki || lo == 0 || k[lo - 1] + 1 != key;
+                if (needed) uf_union(parent, i, lo);
+            }
         }
         if (IS3D && nb < ne) {  // same pixel in the next slice (:352-370)
             uint32_t lo = nb, hi = ne;
