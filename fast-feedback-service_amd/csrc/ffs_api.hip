@@ -87,6 +87,7 @@ struct ffs_stream {
     uint32_t *d_tile_counts = nullptr, *d_num_strong = nullptr, *d_row_off = nullptr;
     uint32_t *d_list_k = nullptr, *d_list_i = nullptr, *d_parent = nullptr, *d_comp_id = nullptr;
     uint32_t *d_n_comp = nullptr, *d_overflow = nullptr, *d_summary = nullptr;
+    uint32_t* d_part_roots = nullptr;
     CompAcc* d_acc = nullptr;
     ReflOut* d_recs = nullptr;
     // pinned host
@@ -354,7 +355,7 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     if (s->st2 && s->st2 != s->st) { (void)hipStreamSynchronize(s->st2); (void)hipStreamDestroy(s->st2); }
     // (d_n_comp, d_summary and d_overflow live inside the d_num_strong allocation)
     void* dev[] = {s->d_comp, s->d_tab, s->d_dplane, s->d_eplane, s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_num_strong,
-                   s->d_list_k, s->d_list_i, s->d_parent, s->d_comp_id, s->d_acc, s->d_recs};
+                   s->d_list_k, s->d_list_i, s->d_parent, s->d_comp_id, s->d_part_roots, s->d_acc, s->d_recs};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     void* host[] = {s->h_tab, s->h_img, s->h_counts, s->h_recs, s->h_list_k, s->h_list_i, s->h_mask};
@@ -429,6 +430,7 @@ extern "C" int ffs_stream_create(ffs_ctx* c, ffs_stream** out) {
     STREAM_TRY(dmalloc(&s->d_list_i, B * (size_t)c->cap * 4));
     STREAM_TRY(dmalloc(&s->d_parent, B * (size_t)c->cap * 4));
     STREAM_TRY(dmalloc(&s->d_comp_id, B * (size_t)c->cap * 4));
+    STREAM_TRY(dmalloc(&s->d_part_roots, B * (size_t)kLabelParts * 4));
     STREAM_TRY(dmalloc(&s->d_acc, B * (size_t)c->max_comp * sizeof(CompAcc)));
     STREAM_TRY(dmalloc(&s->d_recs, B * (size_t)c->max_comp * sizeof(ReflOut)));
     // raw frames, or bitshuffle-LZ4 chunks (which can exceed the raw size by < 1 % when incompressible)
@@ -707,7 +709,9 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     sa.runs_linked = link_runs;
     if (link_runs) hipLaunchKernelGGL(k_link_runs, gseg, b256, 0, s->st2, sa);
     hipLaunchKernelGGL(k_union<false>, gseg, b256, 0, s->st2, sa);
-    hipLaunchKernelGGL(k_label, dim3(n), dim3(1024), 0, s->st2, sa);
+    sa.part_roots = s->d_part_roots;
+    hipLaunchKernelGGL(k_count_roots, dim3(kLabelParts, n), b256, 0, s->st2, sa);
+    hipLaunchKernelGGL(k_label_parts, dim3(kLabelParts, n), b256, 0, s->st2, sa);
     hipLaunchKernelGGL(k_reduce<false>, gseg, b256, 0, s->st2, sa);
     hipLaunchKernelGGL(k_finalize<false>, dim3(8, n), b256, 0, s->st2, sa);
     HIP_TRY(c, hipGetLastError());

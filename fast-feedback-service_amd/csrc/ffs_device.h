@@ -116,6 +116,7 @@ struct SegArgs {
     uint32_t* overflow;
     uint32_t W, H;
     const uint32_t* row_off;  // 2D only: [n_seg][H+1] per-row list offsets (may be null)
+    uint32_t* part_roots;     // 2D only: [n_seg][kLabelParts] roots per part of the list (k_count_roots)
     int runs_linked;          // 2D only: k_link_runs ran, k_union does the vertical edges only
     // 3D only
     const uint32_t* slice_begin;  // [n_slices + 1] entry offsets of each slice inside the segment

@@ -272,6 +272,75 @@ __global__ __launch_bounds__(1024) void k_label(const SegArgs a) {
     }
 }
 
+// The same numbering with several workgroups per segment (2D batches: a frame's list can hold 10^5
+// entries, and one workgroup walking it was 24-85 us): kLabelParts parts per segment, k_count_roots
+// counts the roots of every part, k_label_parts adds up the counts of the parts before its own and
+// numbers its roots.  Output identical to k_label.
+constexpr int kLabelParts = 32;
+
+__global__ __launch_bounds__(256) void k_count_roots(const SegArgs a) {
+    __shared__ uint32_t s_wave[4];
+    const int seg = blockIdx.y, part = blockIdx.x;
+    const uint32_t n = min(a.seg_n[seg], (uint32_t)a.seg_stride);
+    const uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
+    const uint32_t per = (n + kLabelParts - 1) / kLabelParts;
+    const uint32_t p0 = min((uint32_t)part * per, n), p1 = min(p0 + per, n);
+    uint32_t mine = 0;
+    for (uint32_t i = p0 + threadIdx.x; i < p1; i += 256) mine += parent[i] == i ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) a.part_roots[(uint64_t)seg * kLabelParts + part] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+}
+
+__global__ __launch_bounds__(256) void k_label_parts(const SegArgs a) {
+    __shared__ uint32_t s_wave[4];
+    const int seg = blockIdx.y, part = blockIdx.x;
+    const uint32_t n = min(a.seg_n[seg], (uint32_t)a.seg_stride);
+    const uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
+    uint32_t* comp_id = a.comp_id + (uint64_t)seg * a.seg_stride;
+    CompAcc* acc = a.acc + (uint64_t)seg * a.max_comp;
+    const uint32_t* counts = a.part_roots + (uint64_t)seg * kLabelParts;
+    uint32_t before = 0, total = 0;
+    for (int q = 0; q < kLabelParts; ++q) {  // 32 words, the same for every thread
+        const uint32_t v = counts[q];
+        if (q < part) before += v;
+        total += v;
+    }
+    const uint32_t per = (n + kLabelParts - 1) / kLabelParts;
+    const uint32_t p0 = min((uint32_t)part * per, n), p1 = min(p0 + per, n);
+    // each thread owns a contiguous run of the part, so one block scan numbers the roots in list order
+    const uint32_t tper = (p1 - p0 + 255u) / 256u;
+    const uint32_t b0 = min(p0 + threadIdx.x * tper, p1), b1 = min(b0 + tper, p1);
+    uint32_t mine = 0;
+    for (uint32_t i = b0; i < b1; ++i) mine += parent[i] == i ? 1u : 0u;
+    uint32_t running;
+    uint32_t c = before + block_exclusive_scan<256>(mine, s_wave, running);
+    for (uint32_t i = b0; i < b1; ++i) {
+        if (parent[i] != i) continue;
+        comp_id[i] = c;
+        if (c < a.max_comp) {
+            CompAcc z;
+            z.sum_i = z.sum_xi = z.sum_yi = z.sum_zi = 0ull;
+            z.peak = 0ull;
+            z.x_min = 0xFFFFFFFFu; z.x_max = 0u;
+            z.y_min = 0xFFFFFFFFu; z.y_max = 0u;
+            z.z_min = 0x7FFFFFFF; z.z_max = (int32_t)0x80000000;
+            z.num_pixels = 0u;
+            z.root = i;
+            acc[c] = z;
+        }
+        ++c;
+    }
+    if (part == 0 && threadIdx.x == 0) {
+        a.n_comp[seg] = total;
+        if (total > a.max_comp) atomicOr(a.overflow, 2u);
+        uint32_t* sm = a.summary + (uint64_t)seg * 8;
+        for (int q = 0; q < 8; ++q) sm[q] = 0;
+    }
+}
+
 // Per-component sums.  Entries of one component sit close together in the sorted list, so each
 // block first reduces a chunk of 512 consecutive entries into LDS accumulators (components whose
 // root lies inside the chunk have consecutive numbers) and then issues ONE set of global atomics
