@@ -371,13 +371,23 @@ __global__ __launch_bounds__(256) void k_reduce(const SegArgs a) {
     for (uint32_t base = blockIdx.x * kReduceChunk; base < n; base += gridDim.x * kReduceChunk) {
         if (tid == 0) { s_cmin = 0xFFFFFFFFu; s_cmax = 0u; }
         __syncthreads();
-        uint32_t ci[2], ri[2];
+        // 2D: consecutive-k entries form a horizontal run = one component.  The thread of a run's first
+        // entry (runs are also cut every 32 entries and at the chunk start) owns the whole segment: one
+        // root chase and one set of atomics per segment instead of per pixel; the other threads idle.
+        uint32_t ci[2], ri[2], seg_end[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const uint32_t i = base + tid + 256 * q;
+            const uint32_t e = (uint32_t)tid + 256u * q;
+            const uint32_t i = base + e;
             ci[q] = 0xFFFFFFFFu;
             ri[q] = 0;
-            if (i < n) {
+            seg_end[q] = i;
+            const bool owner = i < n && (IS3D || (e & 31u) == 0u || k[i - 1] + 1 != k[i]);
+            if (owner) {
+                uint32_t j = i + 1;
+                if (!IS3D)
+                    while (j < n && (j - base) < (uint32_t)kReduceChunk && ((j - base) & 31u) != 0u && k[j] == k[j - 1] + 1) ++j;
+                seg_end[q] = j;
                 ri[q] = uf_find(parent, i);  // no separate flatten pass: chase to the root here
                 ci[q] = comp_id[ri[q]];
                 if (ri[q] >= base && ci[q] < a.max_comp) {  // root inside this chunk
@@ -400,49 +410,63 @@ __global__ __launch_bounds__(256) void k_reduce(const SegArgs a) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const uint32_t i = base + tid + 256 * q;
+            const uint32_t i0 = base + tid + 256 * q;
             const uint32_t c = ci[q];
-            if (i >= n || c >= a.max_comp) continue;
-            const uint32_t ki = k[i];
-            const uint32_t y = ki / a.W, x = ki - y * a.W;
-            const unsigned long long I = inten[i];
-            uint32_t z = 0;
-            if (IS3D) {
-                int lo = 0, hi = a.n_slices;  // slice containing entry i
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (a.slice_begin[mid] <= i) lo = mid; else hi = mid;
+            if (seg_end[q] == i0 || c >= a.max_comp) continue;  // not a segment owner (or overflowing label)
+            // the segment's sums in registers
+            uint32_t x_min = 0xFFFFFFFFu, x_max = 0u, y_min = 0xFFFFFFFFu, y_max = 0u, npx = 0u;
+            int32_t z_min = 0x7FFFFFFF, z_max = (int32_t)0x80000000;
+            unsigned long long s_i = 0, s_xi = 0, s_yi = 0, s_zi = 0, pk = 0;
+            for (uint32_t i = i0; i < seg_end[q]; ++i) {
+                const uint32_t ki = k[i];
+                const uint32_t y = ki / a.W, x = ki - y * a.W;
+                const unsigned long long I = inten[i];
+                uint32_t z = 0;
+                if (IS3D) {
+                    int lo = 0, hi = a.n_slices;  // slice containing entry i
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (a.slice_begin[mid] <= i) lo = mid; else hi = mid;
+                    }
+                    z = (uint32_t)lo;
                 }
-                z = (uint32_t)lo;
+                x_min = min(x_min, x); x_max = max(x_max, x);
+                y_min = min(y_min, y); y_max = max(y_max, y);
+                z_min = min(z_min, (int32_t)z); z_max = max(z_max, (int32_t)z);
+                ++npx;
+                s_i += I;
+                s_xi += (2ull * x + 1ull) * I;
+                s_yi += (2ull * y + 1ull) * I;
+                s_zi += (2ull * z + 1ull) * I;
+                // highest intensity, ties -> smallest (z, y, x) = smallest list index
+                // (connected_components.hpp:125-170, connected_components.cc:143-157)
+                pk = max(pk, (I << 32) | (unsigned long long)(0xFFFFFFFFu - i));
             }
-            // highest intensity, ties -> smallest (z, y, x) = smallest list index
-            // (connected_components.hpp:125-170, connected_components.cc:143-157)
-            const unsigned long long pk = (I << 32) | (unsigned long long)(0xFFFFFFFFu - i);
             if (ri[q] >= base) {
                 LdsAcc* r = &s_acc[c - cmin];
-                atomicMin(&r->x_min, x); atomicMax(&r->x_max, x);
-                atomicMin(&r->y_min, y); atomicMax(&r->y_max, y);
+                atomicMin(&r->x_min, x_min); atomicMax(&r->x_max, x_max);
+                atomicMin(&r->y_min, y_min); atomicMax(&r->y_max, y_max);
                 if (IS3D) {
-                    atomicMin(&r->z_min, (int32_t)z); atomicMax(&r->z_max, (int32_t)z);
-                    atomicAdd(&r->sum_zi, (2ull * z + 1ull) * I);
+                    atomicMin(&r->z_min, z_min); atomicMax(&r->z_max, z_max);
+                    atomicAdd(&r->sum_zi, s_zi);
                 }
-                atomicAdd(&r->num_pixels, 1u);
-                atomicAdd(&r->sum_i, I);
-                atomicAdd(&r->sum_xi, (2ull * x + 1ull) * I);
-                atomicAdd(&r->sum_yi, (2ull * y + 1ull) * I);
+                atomicAdd(&r->num_pixels, npx);
+                atomicAdd(&r->sum_i, s_i);
+                atomicAdd(&r->sum_xi, s_xi);
+                atomicAdd(&r->sum_yi, s_yi);
                 atomicMax(&r->peak, pk);
             } else {
                 CompAcc* r = acc + c;
-                atomicMin(&r->x_min, x); atomicMax(&r->x_max, x);
-                atomicMin(&r->y_min, y); atomicMax(&r->y_max, y);
+                atomicMin(&r->x_min, x_min); atomicMax(&r->x_max, x_max);
+                atomicMin(&r->y_min, y_min); atomicMax(&r->y_max, y_max);
                 if (IS3D) {
-                    atomicMin(&r->z_min, (int32_t)z); atomicMax(&r->z_max, (int32_t)z);
-                    atomicAdd(&r->sum_zi, (2ull * z + 1ull) * I);
+                    atomicMin(&r->z_min, z_min); atomicMax(&r->z_max, z_max);
+                    atomicAdd(&r->sum_zi, s_zi);
                 }
-                atomicAdd(&r->num_pixels, 1u);
-                atomicAdd(&r->sum_i, I);
-                atomicAdd(&r->sum_xi, (2ull * x + 1ull) * I);
-                atomicAdd(&r->sum_yi, (2ull * y + 1ull) * I);
+                atomicAdd(&r->num_pixels, npx);
+                atomicAdd(&r->sum_i, s_i);
+                atomicAdd(&r->sum_xi, s_xi);
+                atomicAdd(&r->sum_yi, s_yi);
                 atomicMax(&r->peak, pk);
             }
         }
