@@ -537,6 +537,8 @@ static bool ext_fast_first(const ffs_stream* s, const ThresholdArgs& a) {
 }
 static void launch_ext_first(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
     if (ext_fast_first(s, a)) {
+        // a.bits collects the positives the streaming kernel could not settle: zero it, the drain fills it
+        (void)hipMemsetAsync(a.bits, 0, (size_t)n_frames * a.plane_frame_stride, s->st);
         const int bands8 = (a.n_bands + 7) / 8 * 8;
         hipLaunchKernelGGL((k_candidates_u16<true, true>), dim3((unsigned)(a.n_strips * bands8), n_frames), dim3(64), 0,
                            s->st, a);

@@ -107,9 +107,15 @@ constexpr int kQWords = 32;
 // Deliberately a rolled loop reading LDS word by word: the drain runs once per ~20 rows, and
 // keeping its live registers to a handful is what lets the streaming loop keep 4 waves per SIMD.
 // EXT (extended algorithm's first pass): the dispersion test alone decides.
+// EXT also classifies its positives: bit j of `sure` is set when pixel j passes the dispersion test with
+// room to spare (a - 2^-20 m y > c (1 + 2^-18): float32 rounding and the shaved nsig_b cannot turn that
+// around), its centre is valid, the window holds at least min_count pixels and the 32-bit sum of p^2 is
+// exact (x < 8192).  Those pixels need no second opinion from the exact kernel.
 template <bool EXT>
-__device__ __forceinline__ uint32_t group_tests8(const uint32_t (*q)[kQCap], int e, float kS, float kB) {
+__device__ __forceinline__ uint32_t group_tests8(const uint32_t (*q)[kQCap], int e, float kS, float kB,
+                                                 uint32_t min_count = 2, uint32_t* sure = nullptr) {
     uint32_t wq = 0;  // window j sums cq[j .. j+6]
+    uint32_t sb = 0;
 #pragma nounroll
     for (int t = 0; t < 7; ++t) wq += q[16 + t][e];
     uint32_t cb = 0;
@@ -126,8 +132,14 @@ __device__ __forceinline__ uint32_t group_tests8(const uint32_t (*q)[kQCap], int
         const float cf = xf * (kB * __builtin_amdgcn_sqrtf(2.0f * (mf - 1.0f)));  // raw v_sqrt_f32: 1 ulp, inside the 2^-20 allowances
         const bool disp = (af + t0 * 9.5367431640625e-07f >= cf) || x >= 8192u;
         cb |= (sig && disp) ? (1u << j) : 0u;
+        if constexpr (EXT) {
+            const bool certain = (af - t0 * 9.5367431640625e-07f > cf * (1.0f + 3.814697265625e-06f)) && x < 8192u
+                                 && m >= min_count && (A >> 22) != 0u;
+            sb |= certain ? (1u << j) : 0u;
+        }
         wq = wq - q[16 + j][e] + q[23 + j][e];  // j = 7 reads the tag word; that sum is not used
     }
+    if (sure) *sure = sb;
     return cb;
 }
 
@@ -175,6 +187,8 @@ __global__ __launch_bounds__(64, 4) void k_candidates_u16(const ThresholdArgs a)
                                   (uint32_t)a.H * a.bpitch);
     const rsrc_t r_cb = make_rsrc((EXT ? a.dplane : a.bits) + (uint64_t)frame * a.plane_frame_stride,
                                   (uint32_t)a.H * a.mpitch);
+    // EXT: a.bits receives the positives that still need the exact kernel ("uncertain"); a.dplane all of them
+    const rsrc_t r_ub = make_rsrc(a.bits + (uint64_t)frame * a.plane_frame_stride, (uint32_t)a.H * a.mpitch);
     // Offsets with bit 31 set are out of range for every resource: such loads return 0 and such
     // stores are dropped.  Used instead of branches (inactive / not-owned lanes, rows outside the
     // image) so that the loop body is straight-line code and the compiler can keep several rows of
@@ -230,9 +244,15 @@ __global__ __launch_bounds__(64, 4) void k_candidates_u16(const ThresholdArgs a)
     int qn = 0;  // queued lane-groups (wave-uniform)
     auto drain = [&]() {
         if constexpr (SCREEN) if (lane < qn) {
-            const uint32_t cb = group_tests8<EXT>(s_q, lane, kS, kB);
+            uint32_t sure = 0;
+            const uint32_t cb = group_tests8<EXT>(s_q, lane, kS, kB, (uint32_t)a.min_count, &sure);
             const uint32_t tag = s_q[30][lane], row = tag >> 6, ln = tag & 63u;
             __builtin_amdgcn_raw_buffer_store_b8((uint8_t)cb, r_cb, row * a.mpitch + (uint32_t)(sx0 >> 3) + ln, 0, 0);
+            if constexpr (EXT) {
+                const uint32_t uncertain = a.max_valid >= 0 ? cb : (cb & ~sure);  // a trusted-range test needs the pixel
+                if (uncertain)
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)uncertain, r_ub, row * a.mpitch + (uint32_t)(sx0 >> 3) + ln, 0, 0);
+            }
         }
         qn = 0;
     };
@@ -353,6 +373,8 @@ __global__ __launch_bounds__(64, 4) void k_candidates_u16(const ThresholdArgs a)
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, so_bytes, 0);
                     // queued groups get their byte from drain(); everybody else stores 0 now
                     __builtin_amdgcn_raw_buffer_store_b8((uint8_t)0, r_cb, flag ? kOob : off_bit_st, so_bits, 0);
+                    // (EXT: the plane of uncertain positives is zeroed by the host before the launch; only the
+                    // drain writes into it)
                     const unsigned long long fm = __ballot(flag);
                     if (fm) {  // wave-uniform
                         const int nf = __popcll(fm);
@@ -370,6 +392,8 @@ __global__ __launch_bounds__(64, 4) void k_candidates_u16(const ThresholdArgs a)
                                 // queue full (a burst of flagged groups): hand the whole group to
                                 // the exact kernel instead -- still a superset, never a miss
                                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)0xFF, r_cb, off_bit_st, so_bits, 0);
+                                if constexpr (EXT)
+                                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)0xFF, r_ub, off_bit_st, so_bits, 0);
                             } else {
 #pragma unroll
                             for (int w = 0; w < 8; ++w) {
@@ -861,13 +885,15 @@ __device__ bool ext_final_strong(const ThresholdArgs& a, const uint8_t* img, con
 // MODE 0: candidates come from (and strong pixels go back to) a.bits, predicate exact_strong.
 // MODE 1: extended algorithm -- candidates are the signal-region plane a.eplane (read-only: other
 //         tiles read it for their 11x11 windows), predicate ext_final_strong, result in a.bits.
-// MODE 2: extended algorithm's first pass after k_candidates_u16<true, true>: a.dplane filtered in
-//         place by the exact dispersion test; no byte mask.
+// MODE 2: extended algorithm's first pass after k_candidates_u16<true, true>: the pixels marked in
+//         a.bits (positives the streaming kernel could not settle) take the exact dispersion test, the
+//         failures are cleared in a.dplane; tiles without such pixels are left alone; no byte mask.
 template <typename PixelT, int NT, int LISTCAP, int MODE = 0>
 __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
     // The stage is latency-bound (sparse gathers).  Measured dead ends: a smaller LDS footprint
     // (more tiles resident) and one-wave workgroups both made it slower.
     __shared__ uint32_t s_words[kTileRows * 320];  // tile bit-plane words (pitch_px <= 10240)
+    __shared__ uint32_t s_plane[MODE == 2 ? kTileRows * 320 : 1];  // MODE 2: the dplane tile being edited
     __shared__ uint32_t s_list[LISTCAP];
     __shared__ uint32_t s_cnt, s_total, s_strong;
 
@@ -881,7 +907,10 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
     uint32_t* gwords = reinterpret_cast<uint32_t*>((MODE == 2 ? a.dplane : a.bits) + (uint64_t)frame * a.plane_frame_stride
                                                    + (uint64_t)y0 * a.mpitch);
     const uint8_t* eframe = MODE == 1 ? a.eplane + (uint64_t)frame * a.plane_frame_stride : nullptr;
-    const uint32_t* gin = MODE == 1 ? reinterpret_cast<const uint32_t*>(eframe + (uint64_t)y0 * a.mpitch) : gwords;
+    const uint32_t* gin = MODE == 1 ? reinterpret_cast<const uint32_t*>(eframe + (uint64_t)y0 * a.mpitch)
+                        : MODE == 2 ? reinterpret_cast<const uint32_t*>(a.bits + (uint64_t)frame * a.plane_frame_stride
+                                                                        + (uint64_t)y0 * a.mpitch)
+                                    : gwords;
     uint8_t* sbytes = a.strong_bytes + (uint64_t)frame * a.bytes_frame_stride;
 
     if (tid == 0) { s_cnt = 0; s_total = 0; s_strong = 0; }
@@ -900,6 +929,11 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
         if constexpr (MODE == 1)
             for (int g = tid; g < ndw; g += NT) gwords[g] = 0;
         return;
+    }
+
+    if constexpr (MODE == 2) {
+        for (int g = tid; g < ndw; g += NT) s_plane[g] = gwords[g];
+        __syncthreads();
     }
 
     auto append = [&](int g, uint32_t w, uint32_t at) {
@@ -924,7 +958,7 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
             if (strong) {
                 if constexpr (MODE != 2) sbytes[(uint64_t)y * a.bpitch + x] = 1;
             } else {
-                atomicAnd(&s_words[g], ~(1u << bit));
+                atomicAnd(MODE == 2 ? &s_plane[g] : &s_words[g], ~(1u << bit));
             }
         }
     };
@@ -958,7 +992,7 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
 
     uint32_t cnt = 0;
     for (int g = tid; g < ndw; g += NT) {
-        const uint32_t w = s_words[g];
+        const uint32_t w = MODE == 2 ? s_plane[g] : s_words[g];
         gwords[g] = w;
         cnt += __popc(w);
     }
