@@ -19,6 +19,7 @@
 #include "kernels_ccl.hpp"
 #include "kernels_threshold.hpp"
 #include "kernels_extended.hpp"
+#include "kernels_stream.hpp"
 #include "kernels_decode.hpp"
 
 using namespace ffsamd;
@@ -52,6 +53,8 @@ struct ffs_ctx {
     int n_tiles = 0, n_strips = 0;
     ffs_params params{};
     uint8_t* d_maskbits = nullptr;
+    uint8_t* d_ginfo = nullptr;  // per-group mask bits + window-count bounds (kernels_stream.hpp)
+    uint8_t* d_mmap = nullptr;   // per-pixel window counts
     ThreadError err;  // the calling thread's most recent error on any context
 };
 
@@ -63,6 +66,8 @@ struct ffs_ctx {
             return e_ == hipErrorOutOfMemory ? FFS_ERR_NOMEM : FFS_ERR_DEVICE;          \
         }                                                                               \
     } while (0)
+
+constexpr uint32_t kBrightCap = 1u << 20;  // entries of the bright-window list per batch (8 MB)
 
 struct ffs_stream {
     ffs_ctx* ctx = nullptr;
@@ -85,6 +90,7 @@ struct ffs_stream {
     int job_rc = 0;
     std::string job_err;
     uint32_t *d_tile_counts = nullptr, *d_num_strong = nullptr, *d_row_off = nullptr;
+    uint2* d_bright = nullptr;  // pixels k_stream_u16 hands to k_bright_fix; their count sits behind the tile counts
     uint32_t *d_list_k = nullptr, *d_list_i = nullptr, *d_parent = nullptr, *d_comp_id = nullptr;
     uint32_t *d_n_comp = nullptr, *d_overflow = nullptr, *d_summary = nullptr;
     uint32_t* d_part_roots = nullptr;
@@ -97,6 +103,8 @@ struct ffs_stream {
     ReflOut* h_recs = nullptr;
     ReflOut* h_recs_dev = nullptr;  // device-side address of h_recs when the records are written straight to the host
     bool direct_recs = false;
+    bool bits_cleared = false;  // the last batch's compaction zeroed the strong plane again (k_stream_u16's invariant)
+    bool bits_dirty = false;    // the strong plane may hold bits: k_stream_u16 needs it zeroed first
     uint32_t *h_list_k = nullptr, *h_list_i = nullptr;
     uint8_t* h_mask = nullptr;
     // state of the batch in flight
@@ -227,9 +235,11 @@ extern "C" int ffs_ctx_create(int device, uint32_t width, uint32_t height, int p
         return FFS_ERR_DEVICE;
     }
     hipError_t e = hipMalloc(&c->d_maskbits, L.plane_frame_stride + 256);
+    if (e == hipSuccess) e = hipMalloc(&c->d_ginfo, (size_t)(L.H + kInfoExtraRows) * (L.pitch_px / 2) + 256);
+    if (e == hipSuccess) e = hipMalloc(&c->d_mmap, (size_t)L.H * L.pitch_px + 256);
     if (e != hipSuccess) {
         g_create_error = std::string("hipMalloc(mask): ") + hipGetErrorString(e);
-        delete c;
+        ffs_ctx_destroy(c);
         return FFS_ERR_NOMEM;
     }
     *out = c;
@@ -247,7 +257,23 @@ extern "C" void ffs_ctx_destroy(ffs_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->d_maskbits) (void)hipFree(c->d_maskbits);
+    if (c->d_ginfo) (void)hipFree(c->d_ginfo);
+    if (c->d_mmap) (void)hipFree(c->d_mmap);
     delete c;
+}
+
+// The tables of the one-kernel threshold path depend on the mask alone: rebuilt whenever it changes.
+static int rebuild_mask_tables(ffs_ctx* c) {
+    const Layout& L = c->L;
+    const uint32_t gpitch = (uint32_t)L.pitch_px / 2;
+    HIP_TRY(c, hipMemset(c->d_ginfo, 0, (size_t)(L.H + kInfoExtraRows) * gpitch));
+    const int groups = L.pitch_px / 8;
+    (void)hipGetLastError();  // drop any stale error state: the check below is for this launch
+    hipLaunchKernelGGL(k_build_maps, dim3((groups + 255) / 256, L.H), dim3(256), 0, 0, c->d_maskbits, L.mpitch, L.W, L.H,
+                       L.pitch_px, c->d_mmap, c->d_ginfo, gpitch);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipDeviceSynchronize());
+    return FFS_OK;
 }
 
 extern "C" int ffs_ctx_set_mask(ffs_ctx* c, const uint8_t* host_mask) {
@@ -266,7 +292,7 @@ extern "C" int ffs_ctx_set_mask(ffs_ctx* c, const uint8_t* host_mask) {
     }
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpy(c->d_maskbits, bits.data(), bits.size(), hipMemcpyHostToDevice));
-    return FFS_OK;
+    return rebuild_mask_tables(c);
 }
 
 extern "C" int ffs_ctx_get_mask(ffs_ctx* c, uint8_t* host_mask) {
@@ -315,7 +341,7 @@ extern "C" int ffs_ctx_apply_resolution_mask(ffs_ctx* c, float wavelength, float
                        wavelength, distance_m, bcx, bcy, psx, psy, dmin, dmax);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipDeviceSynchronize());
-    return FFS_OK;
+    return rebuild_mask_tables(c);
 }
 
 extern "C" int ffs_ctx_set_params(ffs_ctx* c, const ffs_params* p) {
@@ -354,7 +380,7 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     if (s->st) (void)hipStreamSynchronize(s->st);
     if (s->st2 && s->st2 != s->st) { (void)hipStreamSynchronize(s->st2); (void)hipStreamDestroy(s->st2); }
     // (d_n_comp, d_summary and d_overflow live inside the d_num_strong allocation)
-    void* dev[] = {s->d_comp, s->d_tab, s->d_dplane, s->d_eplane, s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_num_strong,
+    void* dev[] = {s->d_bright, s->d_comp, s->d_tab, s->d_dplane, s->d_eplane, s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_num_strong,
                    s->d_list_k, s->d_list_i, s->d_parent, s->d_comp_id, s->d_part_roots, s->d_acc, s->d_recs};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -417,7 +443,8 @@ extern "C" int ffs_stream_create(ffs_ctx* c, ffs_stream** out) {
     STREAM_TRY(dmalloc(&s->d_img, B * L.frame_stride));
     STREAM_TRY(dmalloc(&s->d_bits, B * L.plane_frame_stride));
     STREAM_TRY(dmalloc(&s->d_sbytes, B * L.bytes_frame_stride));
-    STREAM_TRY(dmalloc(&s->d_tile_counts, B * c->n_tiles * 4));
+    STREAM_TRY(dmalloc(&s->d_tile_counts, (B * c->n_tiles + 1) * 4));
+    STREAM_TRY(dmalloc(&s->d_bright, (size_t)kBrightCap * sizeof(uint2)));
 
     // per-frame counters in the layout of h_counts, so that one copy brings them all back:
     // [B] strong pixels | [B] components | [B][8] summary | [1] overflow / error flag
@@ -448,6 +475,8 @@ extern "C" int ffs_stream_create(ffs_ctx* c, ffs_stream** out) {
         s->direct_recs = false;
     }
     STREAM_TRY(hipMemsetAsync(s->d_overflow, 0, 4, s->st));
+    // bits beyond the image width (x >= W up to the row pitch) are never written by the threshold kernels and must read 0
+    STREAM_TRY(hipMemsetAsync(s->d_bits, 0, B * L.plane_frame_stride, s->st));
     STREAM_TRY(hipStreamSynchronize(s->st));
 #undef STREAM_TRY
     *out = s;
@@ -502,12 +531,41 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
     a.min_count = p.min_count;
     a.nsig_b = p.nsig_b;
     a.nsig_s = p.nsig_s;
+    a.nsig_b2 = p.nsig_b * p.nsig_b;
+    a.nsig_s2 = p.nsig_s * p.nsig_s;
     a.threshold = p.threshold;
     a.max_valid = p.max_valid;
-    {   // FFS_K1_VARIANT=0 selects the signal-test-only candidate kernel (A/B testing); default 1 =
-        // signal + dispersion screen in the candidate kernel
+    {   // FFS_K1_VARIANT (A/B testing): 0 = signal-test-only candidate kernel + exact kernel, 1 = signal +
+        // dispersion screen in the candidate kernel + exact kernel; default 2 (16-bit pixels) = the whole
+        // threshold in one streaming kernel (kernels_stream.hpp)
         const char* v = std::getenv("FFS_K1_VARIANT");
-        a.variant = v ? std::atoi(v) : 1;
+        a.variant = v ? std::atoi(v) : 2;
+        if (c->pixel_bytes != 2 && a.variant > 1) a.variant = 1;
+    }
+    a.bright_n = s->d_tile_counts + (size_t)c->max_batch * c->n_tiles;
+    a.bright_list = s->d_bright;
+    a.bright_cap = kBrightCap;
+    a.dbg = std::getenv("FFS_K1_DEBUG") ? std::atoi(std::getenv("FFS_K1_DEBUG")) : 0;
+    a.ginfo = c->d_ginfo;
+    a.mmap = c->d_mmap;
+    a.gpitch = (uint32_t)L.pitch_px / 2;
+    a.gpf = (L.W + 7) / 8;
+    a.n_frames = (int)n_frames;
+    {   // frames side by side in one super row, as many as keep every buffer of the group below 2 GiB
+        const uint64_t per_frame = std::max<uint64_t>(fstride, L.bytes_frame_stride);
+        a.group_frames = (int)std::max<uint64_t>(1, std::min<uint64_t>(n_frames, ((1ull << 31) - 1) / per_frame));
+        if (const char* e = std::getenv("FFS_K1_GROUP")) a.group_frames = std::max(1, std::min(a.group_frames, std::atoi(e)));
+        const int n_groups = ((int)n_frames + a.group_frames - 1) / a.group_frames;
+        const long long lanes = (long long)a.group_frames * (a.gpf + 1);
+        const long long lines = (long long)a.group_frames * (L.bpitch / 128);  // byte-mask lines to zero per row
+        a.s_strips = (int)std::max<long long>((lanes + kSOwned - 1) / kSOwned, (lines + 3) / 4);
+        long long tw = 16384;
+        if (const char* e = std::getenv("FFS_K1_TARGET_WAVES")) tw = std::max(1, std::atoi(e));
+        const long long per_band = std::max<long long>(1, (long long)a.s_strips * n_groups);
+        long long nb = std::max<long long>(1, std::min<long long>(tw / per_band, L.H / 72));
+        if (nb >= 8) nb = nb / 8 * 8;
+        a.s_band_rows = (int)std::min<long long>(1024, (L.H + nb - 1) / nb);
+        a.s_bands = (L.H + a.s_band_rows - 1) / a.s_band_rows;
     }
     a.dplane = s->d_dplane;
     a.eplane = s->d_eplane;
@@ -578,6 +636,23 @@ static int ensure_extended_buffers(ffs_stream* s) {
 }
 
 static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
+    if (s->ctx->pixel_bytes == 2 && a.variant >= 2) {
+        // the whole threshold in one kernel: final strong plane + per-tile counts (atomics into zeroed counters)
+        ThresholdArgs b = a;
+        b.n_strips = a.s_strips;
+        b.band_rows = a.s_band_rows;
+        b.n_bands = a.s_bands;
+        (void)hipMemsetAsync(a.tile_counts, 0, ((size_t)s->ctx->max_batch * a.n_tiles + 1) * 4, s->st);  // + the bright-list count
+        const int bands8s = (b.n_bands + 7) / 8 * 8;
+        const unsigned n_groups = (n_frames + (unsigned)a.group_frames - 1) / (unsigned)a.group_frames;
+        const int ahead = std::getenv("FFS_K1_AHEAD") ? std::atoi(std::getenv("FFS_K1_AHEAD")) : 2;
+        if (ahead >= 3)
+            hipLaunchKernelGGL(k_stream_u16<3>, dim3((unsigned)(b.n_strips * bands8s), n_groups), dim3(64), 0, s->st, b);
+        else
+            hipLaunchKernelGGL(k_stream_u16<2>, dim3((unsigned)(b.n_strips * bands8s), n_groups), dim3(64), 0, s->st, b);
+        hipLaunchKernelGGL(k_bright_fix, dim3(32), dim3(256), 0, s->st, b);
+        return;
+    }
     const int bands8 = (a.n_bands + 7) / 8 * 8;  // XCD-aware mapping wants a multiple of 8 bands
     dim3 grid((unsigned)(a.n_strips * bands8), n_frames), block(64);
     if (s->ctx->pixel_bytes == 2) {
@@ -595,6 +670,7 @@ static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_
 }
 
 static void launch_exact(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
+    if (s->ctx->pixel_bytes == 2 && a.variant >= 2) return;  // k_stream_u16 left the final plane and the counts
     dim3 grid((unsigned)a.n_tiles, n_frames), block(256);
     if (s->ctx->pixel_bytes == 2 && a.variant == 1)  // few candidates per tile: one wave per tile
         hipLaunchKernelGGL(k_exact_w64<uint16_t>, grid, dim3(64), 0, s->st, a);
@@ -641,6 +717,10 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     // stream's sparse stage runs under the other's dense kernel -- a small kernel queued behind a
     // 9000-workgroup dispatch of another queue gets no CUs until that dispatch drains; 35.3 k vs
     // 37.2 k frames/s.  CU masks for the two stages: no gain either.)
+    const bool one_kernel = c->pixel_bytes == 2 && ta.variant >= 2 && p.algorithm != FFS_ALGO_DISPERSION_EXTENDED;
+    if (one_kernel && s->bits_dirty)  // (another algorithm / variant or a failed batch left bits behind)
+        HIP_TRY(c, hipMemsetAsync(s->d_bits, 0, (size_t)c->max_batch * L.plane_frame_stride, s->st));
+    s->bits_dirty = !one_kernel;
     if (p.algorithm == FFS_ALGO_DISPERSION_EXTENDED) {
         launch_extended(s, ta, n);
     } else {
@@ -655,6 +735,8 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     ca.frame_stride = fstride;
     ca.pitch = (uint32_t)pitch;
     ca.bits = s->d_bits;
+    ca.clear_bits = (c->pixel_bytes == 2 && ta.variant >= 2 && p.algorithm != FFS_ALGO_DISPERSION_EXTENDED) ? 1 : 0;
+    s->bits_cleared = ca.clear_bits != 0;
     ca.tile_counts = s->d_tile_counts;
     ca.num_strong = s->d_num_strong;
     ca.row_off = s->d_row_off;
@@ -673,6 +755,9 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     ca.cap = c->cap;
     ca.max_comp = c->max_comp;
     ca.pixel_bytes = c->pixel_bytes;
+    ca.strong_bytes = s->d_sbytes;
+    ca.bpitch = L.bpitch;
+    ca.bytes_frame_stride = L.bytes_frame_stride;
     // (Measured and dropped: one workgroup per frame with the union-find forest, the entries' columns and
     // the row offsets in LDS instead of k_union + k_label -- correct, but 64 us against 50 + 24 us: a
     // frame's ~18 k entries are compute-bound on a single CU.)
@@ -1070,6 +1155,7 @@ extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_
     const uint32_t overflow = s->h_counts[10 * B];
     s->busy = false;
     if (overflow) {
+        s->bits_dirty = true;
         (void)hipMemsetAsync(s->d_overflow, 0, 4, s->st2);
         (void)hipStreamSynchronize(s->st2);
         if (overflow & 4u) {
@@ -1232,6 +1318,12 @@ extern "C" int ffs_stream_debug_bitplane(ffs_stream* s, uint32_t frame, int whic
         return FFS_ERR_INVALID;
     }
     HIP_TRY(c, hipSetDevice(c->device));
+    if (which == 0 && s->bits_cleared) {
+        // the compaction consumed (and cleared) the plane; the byte mask holds the same pixels
+        HIP_TRY(c, hipMemcpy2D(host_out, L.W, s->d_sbytes + (size_t)frame * L.bytes_frame_stride, L.bpitch, L.W, L.H,
+                               hipMemcpyDeviceToHost));
+        return FFS_OK;
+    }
     std::vector<uint8_t> packed(L.plane_frame_stride);
     HIP_TRY(c, hipMemcpy(packed.data(), src + (size_t)frame * L.plane_frame_stride, packed.size(), hipMemcpyDeviceToHost));
     for (int y = 0; y < L.H; ++y)
@@ -1281,6 +1373,7 @@ extern "C" int ffs_bench_threshold(ffs_stream* s, const void* device_pixels, siz
     HIP_TRY(c, hipEventElapsedTime(&t2, s->ev[1], s->ev[2]));
     if (ms_candidate) *ms_candidate = t1 / iters;
     if (ms_exact) *ms_exact = std::max(0.0f, (t2 - t1) / iters);
+    s->bits_dirty = true;  // no compaction ran: the strong plane still holds this batch's bits
     return FFS_OK;
 }
 

@@ -53,6 +53,7 @@ struct ThresholdArgs {
     float kB;                  // nsig_b (1 - 2^-20): conservative dispersion pre-filter
     int min_count;
     double nsig_b, nsig_s, threshold;
+    double nsig_b2, nsig_s2;   // squares (float64), for the square-root-free form of the predicate
     long long max_valid;       // < 0: no test
     int variant;               // candidate kernel variant: 0 = per-pixel test, 1 = group screen + LDS queue
     // extended dispersion (kernels_extended.hpp)
@@ -61,6 +62,18 @@ struct ThresholdArgs {
     int ext_strips, ext_band_rows, ext_bands;
     int ext_flavour;           // 0 = baseline.cpp rules, 1 = device-kernel rules
     int ext_variant;           // first pass, 16-bit pixels: 1 = candidate kernel + exact stage, 0 = k_ext_first
+    // one-kernel threshold for 16-bit pixels (kernels_stream.hpp)
+    const uint8_t* ginfo;      // [H + 3][gpitch] one dword per 8-pixel group: mask bits | min count << 8 | max count << 16
+    const uint8_t* mmap;       // [H][pitch_px] 7x7 window count of every pixel
+    uint32_t gpitch;           // bytes per ginfo row = pitch_px / 2
+    int gpf;                   // lane groups per frame row = ceil(W / 8)
+    int n_frames;              // frames of this launch
+    int group_frames;          // frames laid side by side in one super row (group bytes < 2 GiB)
+    int s_strips, s_band_rows, s_bands;
+    uint32_t* bright_n;        // [1] pixels handed to k_bright_fix (window sum >= 65536)
+    uint2* bright_list;        // [bright_cap] (frame << 16 | x, y)
+    uint32_t bright_cap;
+    int dbg;                   // FFS_K1_DEBUG: timing experiments only (results are wrong when set)
 };
 
 // ---- strong-pixel lists and connected components -------------------------------------------------
@@ -68,7 +81,8 @@ struct CclArgs {
     const void* image;
     uint64_t frame_stride;
     uint32_t pitch;
-    const uint8_t* bits;       // strong bit planes
+    uint8_t* bits;             // strong bit planes
+    int clear_bits;            // clear every plane word after reading it (k_stream_u16 needs an all-zero plane)
     const uint32_t* tile_counts;
     uint32_t* num_strong;      // [n]
     uint32_t* row_off;         // [n][H+1] list offset of the first strong pixel of each image row
@@ -85,6 +99,9 @@ struct CclArgs {
     uint32_t cap;              // list capacity per frame
     uint32_t max_comp;         // record capacity per frame
     int pixel_bytes;
+    uint8_t* strong_bytes;     // byte masks [n][H][bpitch]: the compaction sets the 1s (the threshold kernels zero-fill)
+    uint32_t bpitch;
+    uint64_t bytes_frame_stride;
 };
 
 // Per-component accumulator (device) -- reduced with 64-bit integer atomics so the result

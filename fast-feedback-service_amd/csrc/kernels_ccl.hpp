@@ -82,12 +82,13 @@ __global__ __launch_bounds__(256) void k_emit_list(const CclArgs a) {
     }
     const int dpr = a.mpitch >> 2;
     const int ndw = rows * dpr;
-    const uint32_t* words = reinterpret_cast<const uint32_t*>(
+    uint32_t* words = reinterpret_cast<uint32_t*>(
         a.bits + (uint64_t)frame * a.plane_frame_stride + (uint64_t)y0 * a.mpitch);
     const uint8_t* img = (const uint8_t*)a.image + (uint64_t)frame * a.frame_stride;
     uint32_t* lk = a.list_k + (uint64_t)frame * a.cap;
     uint32_t* li = a.list_i + (uint64_t)frame * a.cap;
     uint32_t* par = a.parent + (uint64_t)frame * a.cap;
+    uint8_t* sbytes = a.strong_bytes + (uint64_t)frame * a.bytes_frame_stride;
     // each thread owns a contiguous run of words, so ONE block scan gives raster order
     const int per = (ndw + 255) / 256;
     const int g0 = min((int)threadIdx.x * per, ndw), g1 = min(g0 + per, ndw);
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256) void k_emit_list(const CclArgs a) {
     uint32_t at = tile_base + block_exclusive_scan<256>(mine, s_wave, total);
     for (int g = g0; g < g1; ++g) {
         uint32_t w = words[g];
+        if (w && a.clear_bits) words[g] = 0;
         const int row = g / dpr;
         if (g - row * dpr == 0) row_off[y0 + row] = min(at, a.cap);  // first word of an image row
         const int xb = (g - row * dpr) * 32;
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(256) void k_emit_list(const CclArgs a) {
                                                            + (uint64_t)x * sizeof(PixelT));
                 par[at] = at;
             }
+            sbytes[(uint64_t)y * a.bpitch + (uint32_t)x] = 1;  // the reference kernel's result_strong byte
             ++at;
         }
     }

@@ -1,0 +1,414 @@
+// kernels_stream.hpp (included by ffs_api.hip) -- the whole dispersion threshold in ONE streaming kernel
+// for 16-bit pixels on gfx950 (CDNA4): `k_stream_u16`.
+//
+// What the reference does: one 7x7 masked window sum per pixel from a shared-memory tile and a float32
+// test (spotfinder/kernels/thresholding.cu:60-125, :145-234).  What "bit-exact" is judged against: the
+// float64 summed-area-table predicate of baseline/spotfinder/standalone.cc:113-174.
+//
+// Design (round 2; replaces k_candidates_u16<true> + k_exact_w64 on the standard path):
+//  * The valid-pixel mask never changes between frames, so everything that depends on it alone is a
+//    table built once per mask (k_build_maps): the 7x7 window count m of every pixel (`mmap`, 1 B/px,
+//    read only for the few queued groups) and, per 8-pixel lane group, one dword `ginfo` = the group's
+//    8 mask bits | smallest m << 8 | largest m << 16 over its valid pixels.  The streaming loop then
+//    carries pure pixel sums: no count field to drag through every add, no per-row mask expansion
+//    (the four pair masks of a lane change only where the mask byte differs from the row above).
+//  * Cost model (tools/ubench/valu_rate.hip, measured on MI355X): VOP2 add/sub/and/or/shift and
+//    v_mul_f32/v_add_f32 issue at ~1.0 ns per wave per SIMD, everything else (VOP3, SDWA, DPP, packed,
+//    24-bit multiplies, min/max, conversions, compares) at ~1.9 ns.  The row loop is written against
+//    that: pixels are unpacked with one AND / one shift, the vertical sums are add/sub plus ONE
+//    multiply-add per pixel for the sum of squares, the horizontal 7-tap is built from pair sums so
+//    that every cross-lane operand rides on an add (v_add_u32_dpp) instead of a separate move.
+//  * All frames of a batch lie side by side in one "super row": lane groups are numbered across
+//    frames with one empty separator group between frames (it supplies the zeros outside the image),
+//    so only the last strip of the whole batch is partly filled -- not the last strip of every frame
+//    (Eiger-16M: 8.4 instead of 9 waves per row and frame).
+//  * Group screen per lane and row: largest centre pixel against smallest window sum, with the group's
+//    smallest / largest count from `ginfo` -- a proven superset of the oracle's signal test.  The few
+//    groups that pass (a few %) are queued in LDS with their window sums, centre pixels and the 14
+//    column sums of p^2; 64 queued groups at a time take, on dense lanes, the conservative float32
+//    signal + dispersion tests and then, for the pixels still standing, the oracle's float64 predicate
+//    itself, operation for operation (standalone.cc:165-170) on exact integer sums.  The plane
+//    written is therefore the final strong-pixel plane: no second kernel, no re-read of the frame.
+//    (Windows with sum p >= 65536 -- sum p^2 may exceed 32 bits -- fall back to exact_strong's gather.)
+//  * Output: the non-zero bytes of the strong bit plane (the plane is all zero when the kernel starts: the
+//    compaction kernel clears every word it has consumed), the zero-filled byte mask (whole 128-byte lines,
+//    non-temporal; the 1s are set by the compaction kernel from the list) and per-tile strong counts
+//    (atomics, about one per strong group).  Measured (tools/ubench/hbm_pattern.hip): byte-wise zero stores
+//    into the plane cost 45-55 us per 32 frames on their own, and the memory system moves this 2:1 read/write
+//    mix at 5.0 TB/s at best (352 us per 32 Eiger frames with no arithmetic at all).
+#pragma once
+#include "kernels_threshold.hpp"
+
+namespace ffsamd {
+
+constexpr int kSOwned = 62;          // lanes 1..62 own output; lanes 0 and 63 are halo
+constexpr int kSQWords = 32;         // queue entry: 0-7 window sums, 8-11 centre pixels (two per word), 16-29 column sums of p^2, 30 tag
+constexpr int kInfoExtraRows = 3;    // ginfo row y carries the mask bits of row y and the counts of row y - 3
+
+// ---- tables that depend on the mask alone -------------------------------------------------------------
+// One thread per (group, row).  mmap[y][x] = number of valid pixels in the 7x7 window clipped to the
+// image (the oracle's m, standalone.cc:126-141); ginfo[y][g] byte 0 = mask bits of row y,
+// ginfo[y + 3][g] bytes 1, 2 = min / max of m over the VALID pixels of group g in row y (max = 0: none).
+__global__ __launch_bounds__(256) void k_build_maps(const uint8_t* maskbits, uint32_t mpitch, int W, int H, int pitch_px,
+                                                    uint8_t* mmap, uint8_t* ginfo, uint32_t gpitch_bytes) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (g * 8 >= pitch_px) return;
+    // 24 mask bits per row: columns 8g-8 .. 8g+15
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int dy = -3; dy <= 3; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        const uint8_t* row = maskbits + (uint64_t)yy * mpitch;
+        uint32_t b = (uint32_t)row[g] << 8;
+        if (g > 0) b |= row[g - 1];
+        if ((uint32_t)(g + 1) < mpitch) b |= (uint32_t)row[g + 1] << 16;
+        for (int j = 0; j < 8; ++j) cnt[j] += __popc((b >> (j + 5)) & 0x7Fu);  // columns 8g+j-3 .. 8g+j+3
+    }
+    const uint32_t own = maskbits[(uint64_t)y * mpitch + g];
+    uint32_t mn = 255, mx = 0;
+    for (int j = 0; j < 8; ++j) {
+        mmap[(uint64_t)y * pitch_px + g * 8 + j] = (uint8_t)cnt[j];
+        if ((own >> j) & 1u) { mn = min(mn, cnt[j]); mx = max(mx, cnt[j]); }
+    }
+    if (mx == 0) mn = 0;
+    ginfo[(uint64_t)y * gpitch_bytes + g * 4] = (uint8_t)own;
+    ginfo[(uint64_t)(y + kInfoExtraRows) * gpitch_bytes + g * 4 + 1] = (uint8_t)mn;
+    ginfo[(uint64_t)(y + kInfoExtraRows) * gpitch_bytes + g * 4 + 2] = (uint8_t)mx;
+}
+
+// The oracle's predicate on exact integer window sums, standalone.cc:165-170 operation for operation
+// (the same lines as exact_strong, which gets its sums by gathering the window from memory).
+__device__ __forceinline__ bool exact_predicate(const ThresholdArgs& a, uint32_t m, unsigned long long sx,
+                                                unsigned long long sy, uint32_t pc) {
+    const double src = (double)pc;
+    if (!((int)m >= a.min_count && src > a.threshold)) return false;  // (an invalid centre has pc = 0 here)
+    if (a.max_valid >= 0 && (long long)pc > a.max_valid) return false;  // GPU reference only, thresholding.cu:208-215
+    const double md = (double)m, xd = (double)sx, yd = (double)sy;
+    const double t0 = md * yd;
+    const double t1 = xd * xd;
+    const double t2 = xd * (md - 1.0);
+    const double av = (t0 - t1) - t2;
+    const double bv = md * src - xd;
+    const double cv = (xd * a.nsig_b) * __builtin_sqrt(2.0 * (md - 1.0));
+    const double dv = a.nsig_s * __builtin_sqrt(xd * md);
+    return av > cv && bv > dv;
+}
+
+// The same decision without the two square roots, for sums below 2^32 (then a = m y - x^2 - x (m - 1) and
+// b = m p - x are exact integers in float64, as they are in the oracle).  The oracle compares a with
+// c = fl(fl(x nsig_b) fl(sqrt(2 (m-1)))) and b with d = fl(nsig_s fl(sqrt(x m))): each within 2^-51 of
+// the real number.  Comparing the squares instead, a^2 against nsig_b^2 x^2 2 (m-1) and b^2 against
+// nsig_s^2 x m (a few float64 roundings each), settles the comparison whenever the two sides differ by
+// more than 2^-40 relative -- which is always, unless they are equal as real numbers; `certain` says so,
+// and the caller falls back to exact_predicate (with its correctly rounded square roots) otherwise.
+__device__ __forceinline__ bool exact_predicate_nosqrt(const ThresholdArgs& a, uint32_t m, uint32_t sx, uint32_t sy,
+                                                       uint32_t pc, bool& certain) {
+    certain = true;
+    const double src = (double)pc;
+    if (!((int)m >= a.min_count && src > a.threshold)) return false;
+    if (a.max_valid >= 0 && (long long)pc > a.max_valid) return false;
+    const double md = (double)m, xd = (double)sx, yd = (double)sy;
+    const double av = (md * yd - xd * xd) - xd * (md - 1.0);
+    const double bv = md * src - xd;
+    if (!(av > 0.0 && bv > 0.0)) return false;  // c >= 0 and d >= 0
+    const double a2 = av * av, c2 = (a.nsig_b2 * (xd * xd)) * (2.0 * (md - 1.0));
+    const double b2 = bv * bv, d2 = a.nsig_s2 * (xd * md);
+    constexpr double kEps = 9.094947017729282e-13;  // 2^-40
+    const bool disp_yes = a2 > c2 + c2 * kEps, disp_no = a2 < c2 - c2 * kEps;
+    const bool sig_yes = b2 > d2 + d2 * kEps, sig_no = b2 < d2 - d2 * kEps;
+    certain = (disp_yes || disp_no) && (sig_yes || sig_no);
+    return disp_yes && sig_yes;
+}
+
+__device__ __forceinline__ uint32_t dpp_shr_add(uint32_t from_neighbour, uint32_t addend) {
+    // addend + (value of lane - 1); lane 0 adds 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)from_neighbour, 0x138, 0xf, 0xf, true) + addend;
+}
+__device__ __forceinline__ uint32_t dpp_shl_add(uint32_t from_neighbour, uint32_t addend) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)from_neighbour, 0x130, 0xf, 0xf, true) + addend;
+}
+
+struct RowRegsS {
+    uint4 raw;      // 8 pixels
+    uint32_t info;  // ginfo dword
+};
+
+template <int KAHEAD>
+__global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
+    __shared__ uint32_t s_q[kSQWords][kQCap];
+
+    const int lane = threadIdx.x;
+    // XCD-aware block map: all strips of a band carry the same blockIdx % 8 (see k_candidates_u16)
+    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int strip = qb % a.n_strips;
+    const int band = xcd + 8 * (qb / a.n_strips);
+    if (band >= a.n_bands) return;
+    const int f0 = blockIdx.y * a.group_frames;                   // first frame of this super row
+    const int nf = min(a.group_frames, a.n_frames - f0);
+    const int yb0 = band * a.band_rows;
+    const int yb1 = min(yb0 + a.band_rows, a.H);
+
+    // lane -> (frame, group) in the super row; group a.gpf of every frame is the empty separator
+    const int gsep = a.gpf + 1;
+    const int G = strip * kSOwned + lane - 1;
+    const int fl = G >= 0 ? G / gsep : 0;
+    const int g = G - fl * gsep;
+    const bool active = G >= 0 && fl < nf && g < a.gpf;
+    const bool owned = active && lane >= 1 && lane <= kSOwned;
+
+    const rsrc_t r_img = make_rsrc((const uint8_t*)a.image + (uint64_t)f0 * a.frame_stride,
+                                   (uint32_t)((uint64_t)(nf - 1) * a.frame_stride + (uint64_t)a.H * a.pitch));
+    const rsrc_t r_info = make_rsrc(a.ginfo, (uint32_t)(a.H + kInfoExtraRows) * a.gpitch);
+    const rsrc_t r_sb = make_rsrc(a.strong_bytes + (uint64_t)f0 * a.bytes_frame_stride,
+                                  (uint32_t)((uint64_t)nf * a.bytes_frame_stride));
+    const rsrc_t r_cb = make_rsrc(a.bits + (uint64_t)f0 * a.plane_frame_stride, (uint32_t)((uint64_t)nf * a.plane_frame_stride));
+    constexpr uint32_t kOob = 0x80000000u;  // offsets with bit 31 set are out of range for every resource (all < 2 GiB)
+    const uint32_t off_px = active ? (uint32_t)((uint64_t)fl * a.frame_stride) + (uint32_t)g * 16u : kOob;
+    const uint32_t off_info = active ? (uint32_t)g * 4u : kOob;
+    // The byte mask is zero-filled in whole 128-byte lines, independent of who owns which pixel: the rows
+    // of the nf frames hold nf * bpitch / 128 lines, wave `strip` clears lines 4 strip .. 4 strip + 3.
+    uint32_t off_byte_st;
+    {
+        const uint32_t lpf = a.bpitch >> 7;                       // lines per frame row
+        const uint32_t u = (uint32_t)strip * 4u + ((uint32_t)lane >> 4);
+        const uint32_t fz = u / lpf, cz = u - fz * lpf;
+        off_byte_st = fz < (uint32_t)nf ? (uint32_t)((uint64_t)fz * a.bytes_frame_stride) + cz * 128u + ((uint32_t)lane & 15u) * 8u : kOob;
+    }
+
+    const int total = (yb1 - yb0) + 6;  // incoming rows yb0-3 .. yb1+2
+    const float kS = a.kS, kB = a.kB;
+
+    uint32_t ring[7][4];   // masked pixels of the last seven rows, two per register as loaded
+    uint32_t col[8], colq[8];
+    uint32_t M[4] = {0, 0, 0, 0};  // pair masks of the current mask byte
+    uint32_t mprev = 0;
+    RowRegsS pre[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ring[s][q] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { col[j] = 0; colq[j] = 0; }
+
+    auto fetch = [&](RowRegsS& dst, int i) {
+        const int yin = yb0 - 3 + i;
+        const bool in_rows = (i < total) & (yin >= 0);            // wave-uniform (scalar ALU)
+        const bool ok_img = in_rows & (yin < a.H);
+        const bool ok_info = in_rows & (yin < a.H + kInfoExtraRows);
+        const uint32_t row = ok_info ? (uint32_t)yin : 0u;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_img, off_px | (ok_img ? 0u : kOob), (ok_img ? row : 0u) * a.pitch, 0);
+        dst.raw = make_uint4(v[0], v[1], v[2], v[3]);
+        dst.info = __builtin_amdgcn_raw_buffer_load_b32(r_info, off_info | (ok_info ? 0u : kOob), row * a.gpitch, 0);
+    };
+
+    // incoming row -> four registers of two masked pixels each
+    auto unpack = [&](const RowRegsS& r, uint32_t (&P)[4]) {
+        const uint32_t mb = r.info & 0xFFu;
+        if (__ballot(mb != mprev) != 0ull) {  // wave-uniform; rare (module edges, dead pixels)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                M[q] = ((uint32_t)__builtin_amdgcn_sbfe((int)mb, 2 * q, 1) & 0xFFFFu)
+                     | ((uint32_t)__builtin_amdgcn_sbfe((int)mb, 2 * q + 1, 1) & 0xFFFF0000u);
+            mprev = mb;
+        }
+        P[0] = r.raw.x & M[0]; P[1] = r.raw.y & M[1]; P[2] = r.raw.z & M[2]; P[3] = r.raw.w & M[3];
+        // keep the masked words opaque: otherwise the compiler merges `raw & M & 0xFFFF` into a three-operand
+        // v_bitop3 per pair instead of taking the low half as an SDWA select of the word it already has
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm("" : "+v"(P[q]));
+    };
+
+    // vertical running sums: add the incoming row, retire the row that left the 7-row window.  The
+    // half-word operands are meant to become SDWA selects (v_sub_u32_sdwa / v_add_u32_sdwa), the product a
+    // v_mad_i32_i24: four instructions per pixel, nothing to unpack.
+    auto push = [&](int s, const uint32_t (&P)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t wn = P[q], wo = ring[s][q];
+            {
+                const int32_t t = (int32_t)((wn & 0xFFFFu) - (wo & 0xFFFFu));
+                const int32_t u = (int32_t)((wn & 0xFFFFu) + (wo & 0xFFFFu));
+                col[2 * q] += (uint32_t)t;
+                colq[2 * q] += (uint32_t)__mul24(t, u);   // p_in^2 - p_out^2 (low 32 bits)
+            }
+            {
+                const int32_t t = (int32_t)((wn >> 16) - (wo >> 16));
+                const int32_t u = (int32_t)((wn >> 16) + (wo >> 16));
+                col[2 * q + 1] += (uint32_t)t;
+                colq[2 * q + 1] += (uint32_t)__mul24(t, u);
+            }
+            ring[s][q] = wn;
+        }
+    };
+
+    int qn = 0;  // queued lane groups (wave-uniform)
+    // 64 queued groups on dense lanes: the conservative float32 signal test on all eight pixels (a proven
+    // superset, see signal_test8), then for each pixel still standing the oracle's predicate on its exact
+    // window sums.
+    auto drain = [&]() {
+        if (lane < qn && !(a.dbg & 2)) {
+            const uint32_t tag = s_q[30][lane], row = tag >> 6, ln = tag & 63u;
+            const int Ge = strip * kSOwned + (int)ln - 1;
+            const uint32_t fe = (uint32_t)Ge / (uint32_t)gsep, ge = (uint32_t)Ge - fe * (uint32_t)gsep;
+            const uint2 mm = *reinterpret_cast<const uint2*>(a.mmap + (uint64_t)row * a.pitch_px + ge * 8u);
+            uint32_t todo = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t x = s_q[j][lane];
+                const uint32_t pw = s_q[8 + (j >> 1)][lane];
+                const uint32_t pv = (j & 1) ? pw >> 16 : pw & 0xFFFFu;
+                const uint32_t m = ((j < 4 ? mm.x : mm.y) >> (8 * (j & 3))) & 0xFFu;
+                //   oracle: b = m p - x > nsig_s sqrt(x m);  here: b |b| > nsig_s^2 (1 - 2^-16) x m in float32
+                const int32_t b = (int32_t)__umul24(m, pv) - (int32_t)x;
+                const float bf = (float)b, tf = (float)__umul24(x, m);
+                todo |= (bf * __builtin_fabsf(bf) > kS * tf) ? (1u << j) : 0u;
+            }
+            if (a.dbg & 4) todo = 0;
+            uint32_t cb = 0;
+            while (todo) {
+                const uint32_t j = (uint32_t)__ffs((int)todo) - 1u;
+                todo &= todo - 1u;
+                const uint32_t x = s_q[j][lane], pv = (s_q[8 + (j >> 1)][lane] >> (16 * (j & 1))) & 0xFFFFu;
+                const uint32_t m = ((j < 4 ? mm.x : mm.y) >> (8 * (j & 3))) & 0xFFu;
+                if (x < 65536u) {
+                    // sum p^2 mod 2^32 is the true sum while x < 65536 (y <= 65535 x < 2^32); window j = cq[j .. j+6]
+                    uint32_t y = 0;
+#pragma unroll
+                    for (uint32_t t = 0; t < 7; ++t) y += s_q[16 + j + t][lane];
+                    bool certain;
+                    bool strong = exact_predicate_nosqrt(a, m, x, y, pv, certain);
+                    if (!certain) strong = exact_predicate(a, m, x, y, pv);
+                    cb |= strong ? (1u << j) : 0u;
+                } else {
+                    // sum p^2 may not fit 32 bits: k_bright_fix gathers the window and decides (rare)
+                    const uint32_t at = atomicAdd(a.bright_n, 1u);
+                    if (at < a.bright_cap)
+                        a.bright_list[at] = make_uint2(((uint32_t)(f0 + (int)fe) << 16) | (ge * 8u + j), row);
+                }
+            }
+            if (cb) {  // the plane is all zero when the kernel starts (the compaction clears what it consumed)
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)cb, r_cb, (uint32_t)((uint64_t)fe * a.plane_frame_stride) + ge, row * a.mpitch, 0);
+                atomicAdd(a.tile_counts + (uint64_t)(f0 + (int)fe) * a.n_tiles + (row / (uint32_t)kTileRows), (uint32_t)__popc(cb));
+            }
+        }
+        qn = 0;
+    };
+
+#pragma unroll
+    for (int s = 0; s < KAHEAD; ++s) fetch(pre[s], s);
+
+    // warm-up: rows 0..5 of the band's input only fill the window
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        uint32_t P[4];
+        unpack(pre[s], P);
+        fetch(pre[(s + KAHEAD) % 7], s + KAHEAD);
+        push(s, P);
+    }
+
+    for (int base = 6;; base += 7) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const int s = (6 + t) % 7;   // slot of incoming row i (i % 7 == s)
+            const int sc = (s + 4) % 7;  // slot of the centre row i - 3
+            const int i = base + t;
+            if (i >= total) goto rows_done;
+            {
+                uint32_t P[4];
+                const uint32_t info = pre[s].info;   // carries the counts of the centre row
+                unpack(pre[s], P);
+                fetch(pre[(s + KAHEAD) % 7], i + KAHEAD);
+                push(s, P);
+
+                // horizontal 7-tap over the column sums c[-3..10] = L5 L6 L7 c0..c7 R0 R1 R2, from pair sums;
+                // every neighbour value rides on an add
+                const uint32_t s01 = col[0] + col[1], s23 = col[2] + col[3], s45 = col[4] + col[5], s67 = col[6] + col[7];
+                const uint32_t ua = s01 + s23, va = s45 + s67;
+                const uint32_t T0 = dpp_shr_add(s67, ua);      // L6 L7 c0..c3
+                const uint32_t T1 = ua + s45;                   // c0..c5
+                const uint32_t T2 = va + s23;                   // c2..c7
+                const uint32_t T3 = dpp_shl_add(s01, va);      // c4..c7 R0 R1
+                uint32_t Wn[8];
+                Wn[0] = dpp_shr_add(col[5], T0);
+                Wn[1] = T0 + col[4];
+                Wn[2] = dpp_shr_add(col[7], T1);
+                Wn[3] = T1 + col[6];
+                Wn[4] = T2 + col[1];
+                Wn[5] = dpp_shl_add(col[0], T2);
+                Wn[6] = T3 + col[3];
+                Wn[7] = dpp_shl_add(col[2], T3);
+
+                const int yout = __builtin_amdgcn_readfirstlane(yb0 + (i - 6));
+                const uint32_t so_bytes = (uint32_t)yout * a.bpitch;
+
+                // group screen: for every valid pixel j of the group  b_j = m_j p_j - x_j <= mmax pmax - xmin  and
+                // nsig_s sqrt(x_j m_j) >= nsig_s sqrt(xmin mmin): a group that fails  B |B| > kS xmin mmin  has no
+                // candidate (kS = nsig_s^2 (1 - 2^-16): float32 rounding cannot turn a true pass into a fail)
+                // (three-operand chains: four v_min3 / v_max3 class instructions each instead of five)
+                const uint32_t xmin = min(min(min(min(Wn[0], Wn[1]), Wn[2]), min(min(Wn[3], Wn[4]), Wn[5])), min(Wn[6], Wn[7]));
+                uint32_t pmax;
+                {
+                    typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+                    const u16x2 a01 = __builtin_bit_cast(u16x2, ring[sc][0]), a23 = __builtin_bit_cast(u16x2, ring[sc][1]);
+                    const u16x2 a45 = __builtin_bit_cast(u16x2, ring[sc][2]), a67 = __builtin_bit_cast(u16x2, ring[sc][3]);
+                    const u16x2 mx = __builtin_elementwise_max(__builtin_elementwise_max(a01, a23), __builtin_elementwise_max(a45, a67));  // v_pk_max_u16
+                    const uint32_t mw = __builtin_bit_cast(uint32_t, mx);
+                    pmax = max(mw & 0xFFFFu, mw >> 16);
+                }
+                const uint32_t mmin = (info >> 8) & 0xFFu, mmax = (info >> 16) & 0xFFu;
+                const int32_t B = (int32_t)__umul24(mmax, pmax) - (int32_t)xmin;
+                const float bf = (float)B, tf = (float)__umul24(xmin, mmin);
+                const bool pass = bf * __builtin_fabsf(bf) > kS * tf;
+                const bool flag = owned && pass && !(a.dbg & 1);
+                if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, so_bytes, 2 /* nt: written once, read much later */);
+                const unsigned long long fm = __builtin_amdgcn_ballot_w64(flag);
+                if (fm) {  // wave-uniform
+                    const int nfl = __popcll(fm);
+                    if (qn + nfl > kQCap) drain();
+                    // the group's 14 column sums of p^2 (own 8 + 3 from each neighbour lane)
+                    const uint32_t QL5 = from_left(colq[5]), QL6 = from_left(colq[6]), QL7 = from_left(colq[7]);
+                    const uint32_t QR0 = from_right(colq[0]), QR1 = from_right(colq[1]), QR2 = from_right(colq[2]);
+                    if (flag) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                        const int e = qn + (int)rank;   // < kQCap: after a drain qn = 0 and nfl <= 62
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) {
+                            s_q[w][e] = Wn[w];
+                            s_q[19 + w][e] = colq[w];
+                        }
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) s_q[8 + w][e] = ring[sc][w];
+                        s_q[16][e] = QL5; s_q[17][e] = QL6; s_q[18][e] = QL7;
+                        s_q[27][e] = QR0; s_q[28][e] = QR1; s_q[29][e] = QR2;
+                        s_q[30][e] = ((uint32_t)yout << 6) | (uint32_t)lane;
+                    }
+                    qn += nfl;
+                }
+            }
+        }
+    }
+rows_done:
+    if (qn > 0) drain();
+}
+// Pixels whose window holds sum p >= 65536 (k_stream_u16 cannot vouch for its 32-bit sum of p^2): exact
+// 64-bit sums gathered from memory, then the same predicate.  A handful per frame at most.
+__global__ __launch_bounds__(256) void k_bright_fix(const ThresholdArgs a) {
+    const uint32_t n = min(*a.bright_n, a.bright_cap);
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const uint2 r = a.bright_list[e];
+        const uint32_t frame = r.x >> 16, x = r.x & 0xFFFFu, y = r.y;
+        const uint8_t* img = (const uint8_t*)a.image + (uint64_t)frame * a.frame_stride;
+        if (exact_strong<uint16_t>(a, img, (int)x, (int)y)) {
+            uint8_t* plane = a.bits + (uint64_t)frame * a.plane_frame_stride + (uint64_t)y * a.mpitch;
+            atomicOr(reinterpret_cast<uint32_t*>(plane) + (x >> 5), 1u << (x & 31u));  // rows start on 4-byte boundaries
+            atomicAdd(a.tile_counts + (uint64_t)frame * a.n_tiles + y / (uint32_t)kTileRows, 1u);
+        }
+    }
+}
+
+template __global__ void k_stream_u16<2>(const ThresholdArgs);
+template __global__ void k_stream_u16<3>(const ThresholdArgs);
+
+}  // namespace ffsamd
