@@ -67,6 +67,10 @@ struct ffs_ctx {
         }                                                                               \
     } while (0)
 
+// per-tile strong counts of a batch + one word (the last) for the bright-list count; a multiple of 256 bytes so
+// that one fill kernel clears it
+static size_t tile_counts_bytes(const ffs_ctx* c) { return (((size_t)c->max_batch * c->n_tiles + 1) * 4 + 255) / 256 * 256; }
+
 constexpr uint32_t kBrightCap = 1u << 20;  // entries of the bright-window list per batch (8 MB)
 
 struct ffs_stream {
@@ -443,7 +447,7 @@ extern "C" int ffs_stream_create(ffs_ctx* c, ffs_stream** out) {
     STREAM_TRY(dmalloc(&s->d_img, B * L.frame_stride));
     STREAM_TRY(dmalloc(&s->d_bits, B * L.plane_frame_stride));
     STREAM_TRY(dmalloc(&s->d_sbytes, B * L.bytes_frame_stride));
-    STREAM_TRY(dmalloc(&s->d_tile_counts, (B * c->n_tiles + 1) * 4));
+    STREAM_TRY(dmalloc(&s->d_tile_counts, tile_counts_bytes(c)));
     STREAM_TRY(dmalloc(&s->d_bright, (size_t)kBrightCap * sizeof(uint2)));
 
     // per-frame counters in the layout of h_counts, so that one copy brings them all back:
@@ -542,7 +546,7 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
         a.variant = v ? std::atoi(v) : 2;
         if (c->pixel_bytes != 2 && a.variant > 1) a.variant = 1;
     }
-    a.bright_n = s->d_tile_counts + (size_t)c->max_batch * c->n_tiles;
+    a.bright_n = s->d_tile_counts + tile_counts_bytes(c) / 4 - 1;
     a.bright_list = s->d_bright;
     a.bright_cap = kBrightCap;
     a.dbg = std::getenv("FFS_K1_DEBUG") ? std::atoi(std::getenv("FFS_K1_DEBUG")) : 0;
@@ -642,7 +646,7 @@ static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_
         b.n_strips = a.s_strips;
         b.band_rows = a.s_band_rows;
         b.n_bands = a.s_bands;
-        (void)hipMemsetAsync(a.tile_counts, 0, ((size_t)s->ctx->max_batch * a.n_tiles + 1) * 4, s->st);  // + the bright-list count
+        (void)hipMemsetAsync(a.tile_counts, 0, tile_counts_bytes(s->ctx), s->st);  // + the bright-list count (last word)
         const int bands8s = (b.n_bands + 7) / 8 * 8;
         const unsigned n_groups = (n_frames + (unsigned)a.group_frames - 1) / (unsigned)a.group_frames;
         const int ahead = std::getenv("FFS_K1_AHEAD") ? std::atoi(std::getenv("FFS_K1_AHEAD")) : 2;
@@ -764,7 +768,14 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     // (Measured and dropped: writing the list from the exact stage itself, each tile getting its list
     // offset by a decoupled look-back over the tiles before it -- 263 us against 87 + 4 + 63 us for
     // the then three kernels: tiles that wait for a predecessor's count hold their CU slots.)
-    if (c->pixel_bytes == 2)
+    // FFS_EMIT (A/B): 1 (default) = one wave per tile, runs linked in the same pass; 0 = one workgroup per tile + k_link_runs
+    static const int emit_variant = std::getenv("FFS_EMIT") ? std::atoi(std::getenv("FFS_EMIT")) : 1;
+    if (emit_variant >= 1) {
+        if (c->pixel_bytes == 2)
+            hipLaunchKernelGGL(k_emit_list_w<uint16_t>, dim3(c->n_tiles, n), dim3(64), 0, s->st2, ca);
+        else
+            hipLaunchKernelGGL(k_emit_list_w<uint32_t>, dim3(c->n_tiles, n), dim3(64), 0, s->st2, ca);
+    } else if (c->pixel_bytes == 2)
         hipLaunchKernelGGL(k_emit_list<uint16_t>, dim3(c->n_tiles, n), dim3(256), 0, s->st2, ca);
     else
         hipLaunchKernelGGL(k_emit_list<uint32_t>, dim3(c->n_tiles, n), dim3(256), 0, s->st2, ca);
@@ -793,8 +804,8 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     if (const char* e = std::getenv("FFS_CCL_GRID")) gx = std::max(1, std::atoi(e));
     const dim3 gseg((unsigned)gx, n), b256(256);
     static const int link_runs = std::getenv("FFS_LINK_RUNS") ? std::atoi(std::getenv("FFS_LINK_RUNS")) : 1;
-    sa.runs_linked = link_runs;
-    if (link_runs) hipLaunchKernelGGL(k_link_runs, gseg, b256, 0, s->st2, sa);
+    sa.runs_linked = emit_variant >= 1 ? 2 : link_runs;
+    if (emit_variant < 1 && link_runs) hipLaunchKernelGGL(k_link_runs, gseg, b256, 0, s->st2, sa);
     hipLaunchKernelGGL(k_union<false>, gseg, b256, 0, s->st2, sa);
     sa.part_roots = s->d_part_roots;
     hipLaunchKernelGGL(k_count_roots, dim3(kLabelParts, n), b256, 0, s->st2, sa);

@@ -121,6 +121,150 @@ __global__ __launch_bounds__(256) void k_emit_list(const CclArgs a) {
 template __global__ void k_emit_list<uint16_t>(const CclArgs);
 template __global__ void k_emit_list<uint32_t>(const CclArgs);
 
+
+// The same compaction with ONE WAVE per (tile, frame).  The stage is a chain of dependent memory round
+// trips (tile counts, plane words -> pixels), so what matters is how many tiles are in flight and how short
+// the chain is: 32 waves per CU instead of 8 workgroups, both first loads issued together, and no
+// cross-lane scan per 64 words -- the few non-zero words of a tile (a few dozen of ~1000) are first packed
+// into an LDS list (ballot + mbcnt, no round trip), then one scan per 64 list entries places their pixels.
+// It also does what k_link_runs did: an entry whose left neighbour in the same row is strong points at it
+// (plain store; parents are always smaller indices), so that k_union is left with the vertical edges and
+// the reference's row-wrap edge ((W-1, y) -- (0, y+1), no row-end check, connected_components.cc:62-70).
+// Sets the 1s of the byte mask and, for k_stream_u16, clears every plane word it has consumed (that kernel
+// needs an all-zero plane).
+constexpr int kEmitListCap = 256;  // non-zero plane words staged per flush
+
+template <typename PixelT>
+__global__ __launch_bounds__(64) void k_emit_list_w(const CclArgs a) {
+    __shared__ uint32_t s_g[kEmitListCap], s_w[kEmitListCap];
+    __shared__ uint32_t s_rows[kTileRows];
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x, frame = blockIdx.y;
+    const uint32_t* counts = a.tile_counts + (uint64_t)frame * a.n_tiles;
+    const int y0 = tile * kTileRows;
+    const int rows = min(kTileRows, a.H - y0);
+    const int dpr = a.mpitch >> 2;
+    const int ndw = rows * dpr;
+    uint32_t* words = reinterpret_cast<uint32_t*>(a.bits + (uint64_t)frame * a.plane_frame_stride + (uint64_t)y0 * a.mpitch);
+    constexpr int kInFlight = 8;
+    // first round trip: this tile's count, the counts of the tiles before it, and the first plane words
+    const uint32_t count = counts[tile];
+    uint32_t part = 0;
+    for (int t = lane; t < tile; t += 64) part += counts[t];
+    uint32_t wv[kInFlight];
+#pragma unroll
+    for (int q = 0; q < kInFlight; ++q) {
+        const int g = q * 64 + lane;
+        wv[q] = g < ndw ? words[g] : 0u;
+    }
+    if (lane < kTileRows) s_rows[lane] = 0;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+    const uint32_t tile_base = part;
+    uint32_t* row_off = a.row_off + (uint64_t)frame * (a.H + 1);
+    if (tile == a.n_tiles - 1 && lane == 0) {  // the last tile knows the frame's total
+        const uint32_t total = tile_base + count;
+        a.num_strong[frame] = total;
+        row_off[a.H] = min(total, a.cap);
+        if (total > a.cap) atomicOr(a.overflow, 1u);
+    }
+    if (count == 0) {  // wave-uniform: empty rows all start where the tile starts
+        if (lane < rows) row_off[y0 + lane] = min(tile_base, a.cap);
+        return;
+    }
+    const uint8_t* img = (const uint8_t*)a.image + (uint64_t)frame * a.frame_stride;
+    uint32_t* lk = a.list_k + (uint64_t)frame * a.cap;
+    uint32_t* li = a.list_i + (uint64_t)frame * a.cap;
+    uint32_t* par = a.parent + (uint64_t)frame * a.cap;
+    uint8_t* sbytes = a.strong_bytes + (uint64_t)frame * a.bytes_frame_stride;
+
+    uint32_t run = tile_base;              // list position of the next strong pixel (wave-uniform)
+    int n_list = 0;                        // staged non-zero words (wave-uniform)
+    uint32_t last_g = 0xFFFFFFFFu, last_w = 0;  // the last word of the previous flush (for the link across flushes)
+    auto flush = [&]() {
+        for (int base = 0; base < n_list; base += 64) {
+            const int e = base + lane;
+            const bool valid = e < n_list;
+            const uint32_t g = valid ? s_g[e] : 0u;
+            uint32_t w = valid ? s_w[e] : 0u;
+            const uint32_t pg = e > 0 ? s_g[valid ? e - 1 : 0] : last_g, pw = e > 0 ? s_w[valid ? e - 1 : 0] : last_w;
+            const uint32_t pc = (uint32_t)__popc(w);
+            uint32_t inc = pc;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += t;
+            }
+            uint32_t at = run + inc - pc;
+            run += __shfl(inc, 63, 64);
+            if (valid) {
+                const int row = (int)g / dpr;
+                const int col = (int)g - row * dpr;
+                atomicAdd(&s_rows[row], pc);
+                const int xb = col * 32;
+                const int y = y0 + row;
+                // the pixel left of this word's bit 0: bit 31 of the word before it, same row
+                const bool left = col != 0 && pg + 1 == g && (pw >> 31) != 0u;
+                int prev = -2;  // bit index of this word's previous strong pixel
+                while (w) {
+                    const int bit = __ffs((int)w) - 1;
+                    w &= w - 1;
+                    const int x = xb + bit;
+                    const bool linked = bit == 0 ? left : prev == bit - 1;
+                    if (at < a.cap) {
+                        lk[at] = (uint32_t)y * (uint32_t)a.W + (uint32_t)x;
+                        li[at] = *reinterpret_cast<const PixelT*>(img + (uint64_t)y * a.pitch + (uint64_t)x * sizeof(PixelT));
+                        par[at] = linked ? at - 1 : at;
+                    }
+                    sbytes[(uint64_t)y * a.bpitch + (uint32_t)x] = 1;  // the reference kernel's result_strong byte
+                    ++at;
+                    prev = bit;
+                }
+            }
+        }
+        if (n_list > 0) {
+            last_g = s_g[n_list - 1];
+            last_w = s_w[n_list - 1];
+        }
+        n_list = 0;
+    };
+
+    for (int c0 = 0; c0 * 64 < ndw; c0 += kInFlight) {
+        if (c0 > 0) {
+#pragma unroll
+            for (int q = 0; q < kInFlight; ++q) {
+                const int g = (c0 + q) * 64 + lane;
+                wv[q] = g < ndw ? words[g] : 0u;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kInFlight; ++q) {
+            if ((c0 + q) * 64 >= ndw) break;  // wave-uniform
+            const uint32_t w = wv[q];
+            const unsigned long long nz = __builtin_amdgcn_ballot_w64(w != 0u);
+            if (nz == 0ull) continue;  // wave-uniform
+            if (n_list + 64 > kEmitListCap) flush();
+            if (w) {
+                const int g = (c0 + q) * 64 + lane;
+                if (a.clear_bits) words[g] = 0;
+                const int e = n_list + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
+                s_g[e] = (uint32_t)g;
+                s_w[e] = w;
+            }
+            n_list += __popcll(nz);
+        }
+    }
+    flush();
+    // list offset of the first strong pixel of every image row of the tile
+    if (lane < rows) {
+        uint32_t before = 0;
+        for (int r = 0; r < lane; ++r) before += s_rows[r];
+        row_off[y0 + lane] = min(tile_base + before, a.cap);
+    }
+}
+template __global__ void k_emit_list_w<uint16_t>(const CclArgs);
+template __global__ void k_emit_list_w<uint32_t>(const CclArgs);
+
 // ---- union-find --------------------------------------------------------------------------------------
 
 __device__ __forceinline__ uint32_t ld_parent(const uint32_t* p) {
@@ -192,6 +336,9 @@ __global__ __launch_bounds__(256) void k_union(const SegArgs a) {
         // right neighbour: k + 1, with NO row-end check (connected_components.cc:62-70)
         const bool runs_linked = !IS3D && a.runs_linked;  // k_link_runs did these edges already
         if (!runs_linked && i + 1 < s_end && k[i + 1] == ki + 1) uf_union(parent, i, i + 1);
+        // runs_linked == 2: k_emit_list_w linked the runs inside each image row; the edge from a row's last
+        // pixel to the next row's first (the reference's k + 1 without a row-end check) is left to do here
+        if (!IS3D && a.runs_linked == 2 && i > 0 && k[i - 1] + 1 == ki && ki % a.W == 0) uf_union(parent, i - 1, i);
         // neighbour below: k + width (:63, :73-78); it lives in the next image row, whose
         // list range is known from the compaction (row_off), so the search is a few steps
         {

@@ -42,7 +42,8 @@
 namespace ffsamd {
 
 constexpr int kSOwned = 62;          // lanes 1..62 own output; lanes 0 and 63 are halo
-constexpr int kSQWords = 32;         // queue entry: 0-7 window sums, 8-11 centre pixels (two per word), 16-29 column sums of p^2, 30 tag
+constexpr int kSQWords = 32;         // queue entry: 0-7 window sums, 8-11 centre pixels (two per word), 12-13 window counts,
+                                     // 14 result bits, 16-29 column sums of p^2, 30 tag
 constexpr int kInfoExtraRows = 3;    // ginfo row y carries the mask bits of row y and the counts of row y - 3
 
 // ---- tables that depend on the mask alone -------------------------------------------------------------
@@ -137,6 +138,7 @@ struct RowRegsS {
 template <int KAHEAD>
 __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     __shared__ uint32_t s_q[kSQWords][kQCap];
+    __shared__ uint16_t s_list[kQCap * 8];  // drain: (queue entry << 3 | pixel) of every candidate pixel
 
     const int lane = threadIdx.x;
     // XCD-aware block map: all strips of a band carry the same blockIdx % 8 (see k_candidates_u16)
@@ -244,16 +246,25 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     };
 
     int qn = 0;  // queued lane groups (wave-uniform)
-    // 64 queued groups on dense lanes: the conservative float32 signal test on all eight pixels (a proven
-    // superset, see signal_test8), then for each pixel still standing the oracle's predicate on its exact
-    // window sums.
+    // 64 queued groups at a time.  Phase 1, one group per lane: the conservative float32 signal test on its
+    // eight pixels (a proven superset, see signal_test8).  Phase 2: the pixels still standing (a few dozen)
+    // are dealt one per lane -- each lane's candidates numbered by ballot + mbcnt, bit plane by bit plane --
+    // and take the oracle's predicate on their exact window sums side by side instead of one after the
+    // other inside their group's lane (the drain is a latency chain, not a throughput problem).
+    // Phase 3: the group's lane collects its result byte.
     auto drain = [&]() {
-        if (lane < qn && !(a.dbg & 2)) {
-            const uint32_t tag = s_q[30][lane], row = tag >> 6, ln = tag & 63u;
+        const bool have = lane < qn && !(a.dbg & 2);
+        uint32_t todo = 0, row = 0, fe = 0, ge = 0;
+        if (have) {
+            const uint32_t tag = s_q[30][lane], ln = tag & 63u;
+            row = tag >> 6;
             const int Ge = strip * kSOwned + (int)ln - 1;
-            const uint32_t fe = (uint32_t)Ge / (uint32_t)gsep, ge = (uint32_t)Ge - fe * (uint32_t)gsep;
+            fe = (uint32_t)Ge / (uint32_t)gsep;
+            ge = (uint32_t)Ge - fe * (uint32_t)gsep;
             const uint2 mm = *reinterpret_cast<const uint2*>(a.mmap + (uint64_t)row * a.pitch_px + ge * 8u);
-            uint32_t todo = 0;
+            s_q[12][lane] = mm.x;
+            s_q[13][lane] = mm.y;
+            s_q[14][lane] = 0u;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const uint32_t x = s_q[j][lane];
@@ -266,28 +277,48 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                 todo |= (bf * __builtin_fabsf(bf) > kS * tf) ? (1u << j) : 0u;
             }
             if (a.dbg & 4) todo = 0;
-            uint32_t cb = 0;
-            while (todo) {
-                const uint32_t j = (uint32_t)__ffs((int)todo) - 1u;
-                todo &= todo - 1u;
-                const uint32_t x = s_q[j][lane], pv = (s_q[8 + (j >> 1)][lane] >> (16 * (j & 1))) & 0xFFFFu;
-                const uint32_t m = ((j < 4 ? mm.x : mm.y) >> (8 * (j & 3))) & 0xFFu;
+        }
+        int T = 0;  // candidates of the whole wave (wave-uniform)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool bit = (todo >> j) & 1u;
+            const unsigned long long bm = __builtin_amdgcn_ballot_w64(bit);
+            if (bit) {
+                const uint32_t pos = (uint32_t)T + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                s_list[pos] = (uint16_t)(((uint32_t)lane << 3) | (uint32_t)j);
+            }
+            T += __popcll(bm);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int base = 0; base < T; base += 64) {  // wave-uniform; one round unless the groups are full of bright pixels
+            const int idx = base + lane;
+            if (idx < T) {
+                const uint32_t ent = s_list[idx], e = ent >> 3, j = ent & 7u;
+                const uint32_t x = s_q[j][e], pv = (s_q[8 + (j >> 1)][e] >> (16 * (j & 1))) & 0xFFFFu;
+                const uint32_t m = (s_q[12 + (j >> 2)][e] >> (8 * (j & 3))) & 0xFFu;
                 if (x < 65536u) {
                     // sum p^2 mod 2^32 is the true sum while x < 65536 (y <= 65535 x < 2^32); window j = cq[j .. j+6]
                     uint32_t y = 0;
 #pragma unroll
-                    for (uint32_t t = 0; t < 7; ++t) y += s_q[16 + j + t][lane];
+                    for (uint32_t t = 0; t < 7; ++t) y += s_q[16 + j + t][e];
                     bool certain;
                     bool strong = exact_predicate_nosqrt(a, m, x, y, pv, certain);
                     if (!certain) strong = exact_predicate(a, m, x, y, pv);
-                    cb |= strong ? (1u << j) : 0u;
+                    if (strong) atomicOr(&s_q[14][e], 1u << j);
                 } else {
                     // sum p^2 may not fit 32 bits: k_bright_fix gathers the window and decides (rare)
+                    const uint32_t tg = s_q[30][e];
+                    const int Gc = strip * kSOwned + (int)(tg & 63u) - 1;
+                    const uint32_t fc = (uint32_t)Gc / (uint32_t)gsep, gc = (uint32_t)Gc - fc * (uint32_t)gsep;
                     const uint32_t at = atomicAdd(a.bright_n, 1u);
                     if (at < a.bright_cap)
-                        a.bright_list[at] = make_uint2(((uint32_t)(f0 + (int)fe) << 16) | (ge * 8u + j), row);
+                        a.bright_list[at] = make_uint2(((uint32_t)(f0 + (int)fc) << 16) | (gc * 8u + j), tg >> 6);
                 }
             }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (have) {
+            const uint32_t cb = s_q[14][lane];
             if (cb) {  // the plane is all zero when the kernel starts (the compaction clears what it consumed)
                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)cb, r_cb, (uint32_t)((uint64_t)fe * a.plane_frame_stride) + ge, row * a.mpitch, 0);
                 atomicAdd(a.tile_counts + (uint64_t)(f0 + (int)fe) * a.n_tiles + (row / (uint32_t)kTileRows), (uint32_t)__popc(cb));

@@ -1,11 +1,7 @@
 set -e
-mkdir -p gpurun_out/r2c
-rm -f gpurun_out/r2c/dbg5.log
-for cfg in "0 2" "1 2" "2 2" "4 2" "0 3" "8 2"; do
-  set -- $cfg
-  echo "== FFS_K1_DEBUG=$1 AHEAD=$2" >> gpurun_out/r2c/dbg5.log
-  FFS_K1_DEBUG=$1 FFS_K1_AHEAD=$2 python3 tools/prof_threshold.py --iters 10 --variants 2 2>&1 | grep round >> gpurun_out/r2c/dbg5.log
-done
-cat gpurun_out/r2c/dbg5.log
-python -m pytest tests -m gpu -q -x > gpurun_out/r2c/gputests.log 2>&1; tail -5 gpurun_out/r2c/gputests.log
-python bench.py --steps 50 --warmup 5 > gpurun_out/r2c/bench.json 2> gpurun_out/r2c/bench.err; cat gpurun_out/r2c/bench.json
+mkdir -p gpurun_out/r2f
+python -m pytest tests -m gpu -q -x > gpurun_out/r2f/gputests.log 2>&1 || true; tail -5 gpurun_out/r2f/gputests.log
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats -d gpurun_out/r2f/prof --output-format csv -- python3 bench.py --steps 20 --warmup 3 --streams 1 --no-cpu-baseline > gpurun_out/r2f/bench1.log 2>&1
+cat gpurun_out/r2f/prof/*/*kernel_stats.csv | cut -d, -f1-4 | head -16
+python bench.py --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/r2f/bench.json 2> gpurun_out/r2f/bench.err; cut -c1-300 gpurun_out/r2f/bench.json

@@ -70,6 +70,19 @@ __global__ __launch_bounds__(64) void k_march(const uint8_t* img, uint8_t* bytes
             pre[d] = __builtin_amdgcn_raw_buffer_load_b128(r_img, off_px, (uint32_t)min(y + d + D, H - 1) * PITCH, 0);
             acc += v[0] ^ v[1] ^ v[2] ^ v[3];
             const int yy = __builtin_amdgcn_readfirstlane(y + d);
+            if (PARTIAL == 2) {
+                if (WR && yy < y1) {
+                    const uint32_t zc2 = (uint32_t)strip * 512u + (uint32_t)lane * 16u;
+                    const uint32_t ob = (lane < 32 && zc2 < BPITCH) ? zc2 : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, r_sb, ob, (uint32_t)yy * BPITCH, NT ? 2 : 0);
+                }
+            } else if (PARTIAL == 3) {
+                if (WR && yy < y1 && (d & 1) == 0) {
+                    const uint32_t zc2 = (uint32_t)strip * 512u + (uint32_t)(lane & 31) * 16u;
+                    const uint32_t ob = zc2 < BPITCH ? zc2 + (uint32_t)(lane >> 5) * BPITCH : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, r_sb, ob, (uint32_t)yy * BPITCH, NT ? 2 : 0);
+                }
+            } else
             if (WR && yy < y1) {
                 if (NT) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_b, (uint32_t)yy * BPITCH, 2);
                 else __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_b, (uint32_t)yy * BPITCH, 0);
@@ -78,6 +91,16 @@ __global__ __launch_bounds__(64) void k_march(const uint8_t* img, uint8_t* bytes
         }
     }
     if (acc == 0x12345678u) sink[0] = acc;
+}
+
+template <int WIDTH, bool NT>
+__global__ __launch_bounds__(256) void k_fill(uint8_t* bytes, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n / WIDTH; i += stride) {
+        if (WIDTH == 16) { uint4* p = reinterpret_cast<uint4*>(bytes) + i; if (NT) { __builtin_nontemporal_store(0u, &p->x); __builtin_nontemporal_store(0u, &p->y); __builtin_nontemporal_store(0u, &p->z); __builtin_nontemporal_store(0u, &p->w);} else *p = make_uint4(0, 0, 0, 0); }
+        if (WIDTH == 8) { uint2* p = reinterpret_cast<uint2*>(bytes) + i; *p = make_uint2(0, 0); }
+        if (WIDTH == 4) { reinterpret_cast<uint32_t*>(bytes)[i] = 0; }
+    }
 }
 
 template <typename F>
@@ -118,7 +141,16 @@ int main() {
         snprintf(nm, sizeof nm, "linear read + write (8 B/lane), %d blocks", blocks);
         report(nm, time_it([&] { hipLaunchKernelGGL((k_linear<true, false>), dim3(blocks), dim3(256), 0, 0, img, bytes, sink, n16); }, 10), true);
     }
-    for (int band_rows : {78, 156, 312}) {
+    {
+        const uint64_t nb = BFSTRIDE * NF;
+        auto rep = [&](const char* name, float ms) { printf("%-44s %8.1f us   %6.2f TB/s written\n", name, ms * 1e3, (double)nb / ms / 1e9); fflush(stdout); };
+        rep("fill 16 B/lane", time_it([&] { hipLaunchKernelGGL((k_fill<16, false>), dim3(4096), dim3(256), 0, 0, bytes, nb); }, 10));
+        rep("fill 16 B/lane nt", time_it([&] { hipLaunchKernelGGL((k_fill<16, true>), dim3(4096), dim3(256), 0, 0, bytes, nb); }, 10));
+        rep("fill 8 B/lane", time_it([&] { hipLaunchKernelGGL((k_fill<8, false>), dim3(4096), dim3(256), 0, 0, bytes, nb); }, 10));
+        rep("fill 4 B/lane", time_it([&] { hipLaunchKernelGGL((k_fill<4, false>), dim3(4096), dim3(256), 0, 0, bytes, nb); }, 10));
+        rep("hipMemsetAsync", time_it([&] { (void)hipMemsetAsync(bytes, 0, nb, 0); }, 10));
+    }
+    for (int band_rows : {78}) {
         const int n_strips = 9, n_bands = (H + band_rows - 1) / band_rows, bands8 = (n_bands + 7) / 8 * 8;
         const dim3 grid(n_strips * bands8, NF);
         char nm[96];
@@ -133,6 +165,9 @@ int main() {
         RUN(8, true, false, 0, "read + zero-fill")
         RUN(4, true, true, 0, "read + zero-fill nt")
         RUN(4, true, false, 1, "read + zero-fill + byte-wise plane")
+        RUN(4, true, true, 2, "read + zero-fill nt b128 x 32 lanes")
+        RUN(4, true, true, 3, "read + zero-fill nt b128, two rows per store")
+        RUN(4, true, false, 3, "read + zero-fill b128, two rows per store")
 #undef RUN
     }
     return 0;
