@@ -99,6 +99,9 @@ struct ffs_stream {
     uint32_t *d_n_comp = nullptr, *d_overflow = nullptr, *d_summary = nullptr;
     uint32_t* d_part_roots = nullptr;
     CompAcc* d_acc = nullptr;
+    CompAcc2* d_acc2 = nullptr;          // accumulators at the root's list index (2D, k_reduce_roots)
+    uint32_t* d_chunk_roots = nullptr;
+    bool wire2 = false;                  // the batch in flight ships 40-byte WireRec2 records
     ReflOut* d_recs = nullptr;
     // pinned host
     uint8_t* h_img = nullptr;
@@ -384,7 +387,7 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     if (s->st) (void)hipStreamSynchronize(s->st);
     if (s->st2 && s->st2 != s->st) { (void)hipStreamSynchronize(s->st2); (void)hipStreamDestroy(s->st2); }
     // (d_n_comp, d_summary and d_overflow live inside the d_num_strong allocation)
-    void* dev[] = {s->d_bright, s->d_comp, s->d_tab, s->d_dplane, s->d_eplane, s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_num_strong,
+    void* dev[] = {s->d_acc2, s->d_chunk_roots, s->d_bright, s->d_comp, s->d_tab, s->d_dplane, s->d_eplane, s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_num_strong,
                    s->d_list_k, s->d_list_i, s->d_parent, s->d_comp_id, s->d_part_roots, s->d_acc, s->d_recs};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -463,6 +466,8 @@ extern "C" int ffs_stream_create(ffs_ctx* c, ffs_stream** out) {
     STREAM_TRY(dmalloc(&s->d_comp_id, B * (size_t)c->cap * 4));
     STREAM_TRY(dmalloc(&s->d_part_roots, B * (size_t)kLabelParts * 4));
     STREAM_TRY(dmalloc(&s->d_acc, B * (size_t)c->max_comp * sizeof(CompAcc)));
+    STREAM_TRY(dmalloc(&s->d_acc2, B * (size_t)c->cap * sizeof(CompAcc2)));
+    STREAM_TRY(dmalloc(&s->d_chunk_roots, B * (size_t)(c->cap / kRootChunk + 1) * 4));
     STREAM_TRY(dmalloc(&s->d_recs, B * (size_t)c->max_comp * sizeof(ReflOut)));
     // raw frames, or bitshuffle-LZ4 chunks (which can exceed the raw size by < 1 % when incompressible)
     s->h_img_bytes = B * ((size_t)L.W * L.H * c->pixel_bytes + (size_t)L.W * L.H * c->pixel_bytes / 128 + 4096);
@@ -762,6 +767,14 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     ca.strong_bytes = s->d_sbytes;
     ca.bpitch = L.bpitch;
     ca.bytes_frame_stride = L.bytes_frame_stride;
+    // FFS_CCL (A/B): 1 (default) = accumulators at the root, 4 launches (emit, union, reduce, finalize) and 40-byte
+    // records on the wire; 0 = numbered components (count, label, reduce, finalize), 56-byte records
+    static const int ccl_variant = std::getenv("FFS_CCL") ? std::atoi(std::getenv("FFS_CCL")) : 1;
+    const bool root_mode = ccl_variant >= 1 && L.H <= 65535;
+    ca.acc2 = root_mode ? s->d_acc2 : nullptr;
+    ca.n_comp = s->d_n_comp;
+    ca.summary = s->d_summary;
+    s->wire2 = root_mode;
     // (Measured and dropped: one workgroup per frame with the union-find forest, the entries' columns and
     // the row offsets in LDS instead of k_union + k_label -- correct, but 64 us against 50 + 24 us: a
     // frame's ~18 k entries are compute-bound on a single CU.)
@@ -770,7 +783,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     // the then three kernels: tiles that wait for a predecessor's count hold their CU slots.)
     // FFS_EMIT (A/B): 1 (default) = one wave per tile, runs linked in the same pass; 0 = one workgroup per tile + k_link_runs
     static const int emit_variant = std::getenv("FFS_EMIT") ? std::atoi(std::getenv("FFS_EMIT")) : 1;
-    if (emit_variant >= 1) {
+    if (emit_variant >= 1 || root_mode) {
         if (c->pixel_bytes == 2)
             hipLaunchKernelGGL(k_emit_list_w<uint16_t>, dim3(c->n_tiles, n), dim3(64), 0, s->st2, ca);
         else
@@ -804,14 +817,22 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     if (const char* e = std::getenv("FFS_CCL_GRID")) gx = std::max(1, std::atoi(e));
     const dim3 gseg((unsigned)gx, n), b256(256);
     static const int link_runs = std::getenv("FFS_LINK_RUNS") ? std::atoi(std::getenv("FFS_LINK_RUNS")) : 1;
-    sa.runs_linked = emit_variant >= 1 ? 2 : link_runs;
-    if (emit_variant < 1 && link_runs) hipLaunchKernelGGL(k_link_runs, gseg, b256, 0, s->st2, sa);
+    sa.runs_linked = (emit_variant >= 1 || root_mode) ? 2 : link_runs;
+    sa.acc2 = s->d_acc2;
+    sa.chunk_roots = s->d_chunk_roots;
+    sa.chunks_max = c->cap / kRootChunk + 1;
+    if (emit_variant < 1 && !root_mode && link_runs) hipLaunchKernelGGL(k_link_runs, gseg, b256, 0, s->st2, sa);
     hipLaunchKernelGGL(k_union<false>, gseg, b256, 0, s->st2, sa);
-    sa.part_roots = s->d_part_roots;
-    hipLaunchKernelGGL(k_count_roots, dim3(kLabelParts, n), b256, 0, s->st2, sa);
-    hipLaunchKernelGGL(k_label_parts, dim3(kLabelParts, n), b256, 0, s->st2, sa);
-    hipLaunchKernelGGL(k_reduce<false>, gseg, b256, 0, s->st2, sa);
-    hipLaunchKernelGGL(k_finalize<false>, dim3(8, n), b256, 0, s->st2, sa);
+    if (root_mode) {
+        hipLaunchKernelGGL(k_reduce_roots, gseg, b256, 0, s->st2, sa);
+        hipLaunchKernelGGL(k_finalize_roots, gseg, b256, 0, s->st2, sa);
+    } else {
+        sa.part_roots = s->d_part_roots;
+        hipLaunchKernelGGL(k_count_roots, dim3(kLabelParts, n), b256, 0, s->st2, sa);
+        hipLaunchKernelGGL(k_label_parts, dim3(kLabelParts, n), b256, 0, s->st2, sa);
+        hipLaunchKernelGGL(k_reduce<false>, gseg, b256, 0, s->st2, sa);
+        hipLaunchKernelGGL(k_finalize<false>, dim3(8, n), b256, 0, s->st2, sa);
+    }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(s->ev[3], s->st2));
 
@@ -822,7 +843,8 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
         s->spec_recs_copied = (uint64_t)B * c->max_comp;  // everything is on the host already
     } else {
         s->spec_recs_copied = std::min<uint64_t>((uint64_t)s->spec_recs_per_frame * n, (uint64_t)B * c->max_comp);
-        HIP_TRY(c, hipMemcpyAsync(s->h_recs, s->d_recs, s->spec_recs_copied * sizeof(ReflOut), hipMemcpyDeviceToHost, s->st2));
+        HIP_TRY(c, hipMemcpyAsync(s->h_recs, s->d_recs, s->spec_recs_copied * (s->wire2 ? sizeof(WireRec2) : sizeof(ReflOut)),
+                                  hipMemcpyDeviceToHost, s->st2));
     }
     HIP_TRY(c, hipEventRecord(s->ev[4], s->st2));
     s->busy = true;
@@ -1185,8 +1207,10 @@ extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_
     }
     bool second_phase = false;
     if (total_recs > s->spec_recs_copied) {  // more records than the speculative copy brought: fetch the rest
-        HIP_TRY(c, hipMemcpyAsync(s->h_recs + s->spec_recs_copied, s->d_recs + s->spec_recs_copied,
-                                  (total_recs - s->spec_recs_copied) * sizeof(ReflOut), hipMemcpyDeviceToHost, s->st2));
+        const size_t rb = s->wire2 ? sizeof(WireRec2) : sizeof(ReflOut);
+        HIP_TRY(c, hipMemcpyAsync(reinterpret_cast<uint8_t*>(s->h_recs) + s->spec_recs_copied * rb,
+                                  reinterpret_cast<const uint8_t*>(s->d_recs) + s->spec_recs_copied * rb,
+                                  (total_recs - s->spec_recs_copied) * rb, hipMemcpyDeviceToHost, s->st2));
         second_phase = true;
     }
     s->spec_recs_per_frame = std::max<uint32_t>(s->spec_recs_per_frame,
@@ -1229,10 +1253,33 @@ extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_
     if (p.want_reflections) s->refls.reserve(total_recs);
     std::vector<size_t> box_at(n), refl_at(n);
     const ReflOut* rec = s->h_recs;
+    const WireRec2* wrec = reinterpret_cast<const WireRec2*>(s->h_recs);
     for (uint32_t f = 0; f < n; ++f) {
         box_at[f] = s->boxes.size();
         refl_at[f] = s->refls.size();
-        for (uint32_t q = 0; q < h_nc[f]; ++q, ++rec) {
+        const uint32_t nc = std::min<uint32_t>(h_nc[f], c->max_comp);
+        if (s->wire2) {
+            for (uint32_t q = 0; q < nc; ++q, ++wrec) {
+                const uint32_t npx = wrec->npx_flags & 0x3FFFFFFFu, flags = wrec->npx_flags >> 30;
+                if (p.min_spot_size == 0 || npx >= p.min_spot_size)
+                    s->boxes.push_back(ffs_box{wrec->x_min, wrec->y_min, wrec->x_max, wrec->y_max, (int32_t)npx});
+                if (p.want_reflections && flags == 0) {
+                    ffs_reflection r{};
+                    r.x_min = wrec->x_min; r.x_max = wrec->x_max; r.y_min = wrec->y_min; r.y_max = wrec->y_max;
+                    r.z_min = 0; r.z_max = 0;
+                    r.num_pixels = (int32_t)npx;
+                    r.com_x = wrec->com_x; r.com_y = wrec->com_y; r.com_z = 0.5f;  // z = 0 for a single frame
+                    r.peak_x = wrec->peak_x; r.peak_y = wrec->peak_y; r.peak_z = 0;
+                    r.peak_intensity = wrec->peak_intensity;
+                    r.peak_centroid_distance = wrec->peak_centroid_distance;
+                    r.flags = 0;
+                    r.sum_intensity = wrec->sum_intensity;
+                    s->refls.push_back(r);
+                }
+            }
+            continue;
+        }
+        for (uint32_t q = 0; q < nc; ++q, ++rec) {
             if (p.min_spot_size == 0 || (uint32_t)rec->num_pixels >= p.min_spot_size)
                 s->boxes.push_back(ffs_box{rec->x_min, rec->y_min, rec->x_max, rec->y_max, rec->num_pixels});
             if (p.want_reflections && rec->flags == 0) {

@@ -77,6 +77,27 @@ struct ThresholdArgs {
 };
 
 // ---- strong-pixel lists and connected components -------------------------------------------------
+// 2D only (round 2): the accumulator of a component sits at the list index of its ROOT (its smallest
+// member, always the first pixel of a horizontal run), so no pass has to number the components before
+// they can be reduced.  k_emit_list_w resets the accumulator of every run start.
+struct CompAcc2 {
+    unsigned long long sum_i, sum_xi, sum_yi, peak;
+    uint32_t x_min, x_max, y_min, y_max;
+    uint32_t num_pixels, pad;
+};
+
+// 2D record as it crosses PCIe (40 bytes instead of the 56 of ffs_reflection: the z fields are constants
+// for a single frame and the coordinates fit 16 bits); ffs_wait() widens it again.
+struct WireRec2 {
+    uint16_t x_min, x_max, y_min, y_max;
+    uint32_t npx_flags;        // num_pixels | flags << 30
+    float com_x, com_y;
+    uint16_t peak_x, peak_y;
+    uint32_t peak_intensity;
+    float peak_centroid_distance;
+    unsigned long long sum_intensity;
+};
+
 struct CclArgs {
     const void* image;
     uint64_t frame_stride;
@@ -99,6 +120,8 @@ struct CclArgs {
     uint32_t cap;              // list capacity per frame
     uint32_t max_comp;         // record capacity per frame
     int pixel_bytes;
+    CompAcc2* acc2;            // [n][cap] or null: reset the accumulator of every run start (k_reduce_roots)
+    uint32_t* summary;         // [n][8]: with acc2, the compaction zeroes n_comp and summary (the root-indexed kernels add into them)
     uint8_t* strong_bytes;     // byte masks [n][H][bpitch]: the compaction sets the 1s (the threshold kernels zero-fill)
     uint32_t bpitch;
     uint64_t bytes_frame_stride;
@@ -143,6 +166,10 @@ struct SegArgs {
     float max_sep;
     void* recs;               // ffs_reflection, packed: segment s starts at sum_{q<s} n_comp[q]
     uint32_t* summary;        // [n_seg][8]: n_boxes, n_strong_filtered, n_refl, n_filt_size, n_filt_sep
+    // 2D, accumulators at the root (k_reduce_roots / k_finalize_roots)
+    CompAcc2* acc2;           // [n_seg][seg_stride]
+    uint32_t* chunk_roots;    // [n_seg][chunks_max] roots per chunk of kRootChunk list entries
+    uint32_t chunks_max;
 };
 
 
