@@ -63,22 +63,29 @@ def pmc_traffic(workload, batch):
     try:
         d = json.load(open(files[-1]))
         for k, v in d.items():
-            if "k_candidates" in k and "hbm_bytes_per_launch" in v:
-                return int(v["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+            if ("k_stream" in k or "k_candidates" in k) and "hbm_bytes_per_launch" in v:
+                src = os.path.relpath(files[-1], ROOT)
+                if d.get("_commit"):
+                    src += f" (rocprofv3 PMC passes taken at commit {d['_commit']}; not re-measured in this run)"
+                return int(v["hbm_bytes_per_launch"]), src
     except Exception:
         pass
     return None, None
 
 
-def cpu_baseline(frames, mask, ext=False, budget_s=20.0):
+def cpu_baseline(frames, mask, ext=False, budget_s=12.0):
     """Reference CPU path timed on this box's host cores: dispersion threshold by the
     reference's own standalone.cc when oracle/_ref is present (else our restatement), then the
     oracle's connected components; one frame per thread, the reference's threading model
-    (spotfinder/spotfinder.cc:725-752)."""
+    (spotfinder/spotfinder.cc:725-752).  Two legs: one core, and every
+    core this process may use."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     H, W = mask.shape
-    cores = max(1, min(os.cpu_count() or 1, 16, len(frames)))
+    try:
+        nproc = len(os.sched_getaffinity(0))
+    except AttributeError:
+        nproc = os.cpu_count() or 1
     kind = "reference" if O.have_ref() and not ext else "port"   # baseline.cpp's extended class needs DIALS
 
     def worker(idx_list):
@@ -99,16 +106,29 @@ def cpu_baseline(frames, mask, ext=False, budget_s=20.0):
                 break
         return done
 
-    per = 4  # frames per thread: ~16 x 4 x 0.35 s = 20-25 core-seconds
-    jobs = [[(c * per + j) % len(frames) for j in range(per)] for c in range(cores)]
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        done = sum(ex.map(worker, jobs))
-    dt = time.perf_counter() - t0
+    def leg(cores, per):
+        jobs = [[(c * per + j) % len(frames) for j in range(per)] for c in range(cores)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            done = sum(ex.map(worker, jobs))
+        dt = time.perf_counter() - t0
+        return done, dt
+
+    done1, dt1 = leg(1, 8)                       # ~8 x 0.13 s on one core
+    # "all cores" = this job's CPU share: a 1-GPU box of the pool shows every core of the host (nproc, reported)
+    # but grants 16 per GPU; FFS_BENCH_CPU_THREADS overrides (256 threads measured 32 frames/s against 40 with
+    # 16: the summed-area tables of 256 frames do not fit the caches)
+    cores = max(1, min(nproc, int(os.environ.get("FFS_BENCH_CPU_THREADS", "16"))))
+    done, dt = leg(cores, 4)
+    what = ("reference baseline/spotfinder/standalone.cc (oracle/_ref)" if kind == "reference"
+            else "oracle port" + (" of baseline.cpp DispersionExtendedThreshold" if ext else ""))
     return {
-        "value": round(done / dt, 3), "unit": "frames/s", "cores": cores, "kind": kind,
-        "sample": f"{done} {W}x{H} frames of the same workload, one frame per thread on {cores} threads; "
-                  f"threshold = {'reference baseline/spotfinder/standalone.cc (oracle/_ref)' if kind == 'reference' else 'oracle port' + (' of baseline.cpp DispersionExtendedThreshold' if ext else '')}"
+        "value": round(done / dt, 3), "unit": "frames/s", "cores": cores, "kind": kind, "nproc": nproc,
+        "single_core": {"value": round(done1 / dt1, 3), "unit": "frames/s", "cores": 1,
+                        "ms_per_frame": round(dt1 / done1 * 1e3, 1), "sample": f"{done1} frames, {dt1:.1f} s wall"},
+        "ms_per_frame_per_core": round(dt * cores / done * 1e3, 1),
+        "sample": f"{done} {W}x{H} frames of the same workload, one frame per thread on {cores} threads "
+                  f"(the CPU share of one GPU on this pool; the host shows {nproc} cores); threshold = {what}"
                   f", connected components = oracle port (Boost.Graph absent); {dt:.1f} s wall",
     }
 
@@ -120,16 +140,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="frames per step and per GPU")
     ap.add_argument("--workload", default="eiger16m", choices=sorted(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=2, help="batches in flight per GPU")
+    ap.add_argument("--streams", type=int, default=4, help="batches in flight per GPU (measured: 2 -> 52.8 k, 3 -> 59.9 k, 4 -> 61.1 k, 6 -> 64.1 k frames/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--algorithm", default="dispersion", choices=["dispersion", "dispersion_extended"],
                     help="dispersion = the headline metric; dispersion_extended = the second algorithm of the "
                          "same CLI flag (SURVEY 8f), reported as its own metric")
     ap.add_argument("--gather-every", type=int, default=4,
                     help="N>1: batches whose spot lists are gathered by one RCCL collective")
-    ap.add_argument("--streamed", action="store_true",
-                    help="also time the PCIe-inclusive path (pinned host frames -> ffs_submit); reported as "
-                         "streamed_frames_per_s, never as `value`")
+    ap.add_argument("--no-streamed", action="store_true",
+                    help="skip the two short PCIe-inclusive legs (pinned host frames -> ffs_submit, and bitshuffle-LZ4 "
+                         "chunks -> ffs_submit_compressed); they are reported as streamed_frames_per_s / "
+                         "streamed_compressed, never as `value`")
+    ap.add_argument("--streamed", action="store_true", help="(kept for old command lines: the streamed legs are on by default)")
     args = ap.parse_args()
 
     import torch
@@ -187,7 +209,7 @@ def main():
             return
         tg = time.perf_counter()
         for g in range(pending, G):      # unused slots of a partial group: zero spots
-            pack_host[cur][g, spot_cap, 0] = 0
+            pack_host[cur][g, spot_cap] = 0          # (rows written, rows wanted) = (0, 0)
         pack_dev[cur].copy_(pack_host[cur], non_blocking=True)
         dist.all_gather_into_tensor(gather_buf[cur].view(-1), pack_dev[cur].view(-1))
         ev = torch.cuda.Event()
@@ -261,16 +283,18 @@ def main():
     achieved = alg_bytes / (ms_cand * 1e-3) / 1e9
     tm = streams[0].timings()
     traffic, traffic_src = (None, None) if ext else pmc_traffic(args.workload, B)
+    # ceiling measured on this box beside the nominal 8 TB/s
+    peak_read, peak_mix = streams[0].bench_hbm(iters=5)
 
     streamed = None
-    if args.streamed:
+    if not args.no_streamed:
         # host frames in each stream's pinned staging buffer -> H2D + full hot path per batch
         bufs = []
         for st in streams:
             hb = st.host_buffer()
             hb[:B] = frames[:B]
             bufs.append(hb)
-        n_st = max(4, args.steps // 2)
+        n_st = max(4, min(12, args.steps // 2))   # short legs: ~0.25 s raw, ~0.1 s compressed
         barrier()
         ts = time.perf_counter()
         inflight = []
@@ -348,7 +372,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel": "k_candidates_u16<ext>" if ext else "k_candidates", "ms_per_launch": round(ms_cand, 4),
+                         "measured_peak": {"read_only_GBps": round(peak_read, 1), "read_write_2to1_GBps": round(peak_mix, 1),
+                                           "probe": "ffs_bench_hbm: linear 16 B/lane reads of the batch's pixel buffer; the same with an "
+                                                    "8 B zero store per 16 B read (the kernel's read/write mix)"},
+                         "frac_of_measured_mix": round((traffic if traffic else alg_bytes) / (ms_cand * 1e-3) / 1e9 / max(peak_mix, 1.0), 4),
+                         "kernel": ("k_candidates_u16<ext>" if ext else
+                                    "k_stream_u16 (whole threshold stage)" if dt == np.uint16 else "k_candidates_u32_q"),
+                         "ms_per_launch": round(ms_cand, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "exact_kernel_ms_per_launch": round(ms_exact, 4)},
             "stage_ms_last_batch": {k: round(v, 4) for k, v in tm.items()},

@@ -1336,8 +1336,13 @@ extern "C" int ffs_stream_spot_centres(ffs_stream* s, float* rows4, uint32_t cap
         return FFS_ERR_INVALID;
     }
     uint32_t n = 0;
+    uint64_t wanted = 0;
     for (const ffs_frame_result& r : s->results) {
-        const float id = (float)r.frame_id;
+        // the id's low 32 bits as a bit pattern: as a float VALUE ids would collide from 2^24 on
+        const uint32_t id_bits = (uint32_t)((uint64_t)r.frame_id & 0xFFFFFFFFull);
+        float id;
+        std::memcpy(&id, &id_bits, 4);
+        wanted += r.n_reflections;
         for (uint32_t q = 0; q < r.n_reflections && n < cap; ++q, ++n) {
             float* row = rows4 + (size_t)n * 4;
             row[0] = id;
@@ -1346,11 +1351,13 @@ extern "C" int ffs_stream_spot_centres(ffs_stream* s, float* rows4, uint32_t cap
             row[3] = r.reflections[q].com_z;
         }
     }
+    // last row: (rows written, rows wanted) as uint32 bit patterns -- wanted > written tells the receiver
+    // that `cap` was too small (nothing is dropped silently)
     float* last = rows4 + (size_t)cap * 4;
-    last[0] = (float)n;
-    last[1] = last[2] = last[3] = 0.0f;
+    const uint32_t tail[4] = {n, (uint32_t)std::min<uint64_t>(wanted, 0xFFFFFFFFull), 0u, 0u};
+    std::memcpy(last, tail, sizeof(tail));
     if (n_written) *n_written = n;
-    return FFS_OK;
+    return wanted > n ? FFS_ERR_OVERFLOW : FFS_OK;
 }
 
 extern "C" int ffs_stream_debug_planes(ffs_stream* s, const uint8_t** strong_bytes, size_t* mask_pitch,
@@ -1432,6 +1439,63 @@ extern "C" int ffs_bench_threshold(ffs_stream* s, const void* device_pixels, siz
     if (ms_candidate) *ms_candidate = t1 / iters;
     if (ms_exact) *ms_exact = std::max(0.0f, (t2 - t1) / iters);
     s->bits_dirty = true;  // no compaction ran: the strong plane still holds this batch's bits
+    return FFS_OK;
+}
+
+// ---- measured memory ceiling (a ceiling measured on the box beside the nominal 8 TB/s) ----
+// k_probe<0>: every byte of the batch's pixel buffer is read once (16 B per lane, consecutive).
+// k_probe<1|2>: the same reads plus one 8-byte zero store per 16 bytes read into the byte-mask buffer -- the 2:1
+// read/write mix of the threshold kernel (2 B pixel in, 1 B mask out), again perfectly linear.
+template <int WRITE>  // 0 = reads only, 1 = plain stores, 2 = non-temporal stores
+__global__ __launch_bounds__(256) void k_probe(const uint4* src, uint2* dst, uint64_t n16, uint32_t* sink) {
+    uint32_t acc = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) {
+        const uint4 v = src[i];
+        acc += v.x ^ v.y ^ v.z ^ v.w;
+        if (WRITE == 1) dst[i] = make_uint2(0u, 0u);
+        if (WRITE == 2) {
+            __builtin_nontemporal_store(0u, &dst[i].x);
+            __builtin_nontemporal_store(0u, &dst[i].y);
+        }
+    }
+    if (acc == 0x9E3779B9u) *sink = acc;  // keeps the loads alive
+}
+
+extern "C" int ffs_bench_hbm(ffs_stream* s, uint32_t iters, float* read_gbps, float* mix_gbps) {
+    if (!s || iters == 0) return FFS_ERR_INVALID;
+    ffs_ctx* c = s->ctx;
+    if (s->busy) {
+        c->err = "stream busy";
+        return FFS_ERR_INVALID;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint64_t n16 = (uint64_t)c->max_batch * c->L.frame_stride / 16;
+    // the byte-mask buffer holds half as many bytes as the pixel buffer for 16-bit pixels, a quarter for 32-bit
+    const uint64_t n16w = std::min<uint64_t>(n16, (uint64_t)c->max_batch * c->L.bytes_frame_stride / 8);
+    const uint4* src = reinterpret_cast<const uint4*>(s->d_img);
+    uint2* dst = reinterpret_cast<uint2*>(s->d_sbytes);
+    float out[3] = {0, 0, 0};
+    for (int mode = 0; mode < 3; ++mode) {
+        const uint64_t n = mode ? n16w : n16;
+        auto launch = [&]() {
+            if (mode == 2) hipLaunchKernelGGL(k_probe<2>, dim3(4096), dim3(256), 0, s->st, src, dst, n, s->d_tile_counts);
+            else if (mode == 1) hipLaunchKernelGGL(k_probe<1>, dim3(4096), dim3(256), 0, s->st, src, dst, n, s->d_tile_counts);
+            else hipLaunchKernelGGL(k_probe<0>, dim3(4096), dim3(256), 0, s->st, src, dst, n, s->d_tile_counts);
+        };
+        launch();  // warm-up
+        HIP_TRY(c, hipEventRecord(s->ev[0], s->st));
+        for (uint32_t i = 0; i < iters; ++i) launch();
+        HIP_TRY(c, hipEventRecord(s->ev[1], s->st));
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventSynchronize(s->ev[1]));
+        float ms = 0;
+        HIP_TRY(c, hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
+        const double bytes = (double)n * 16.0 + (mode ? (double)n * 8.0 : 0.0);
+        out[mode] = (float)(bytes * iters / (ms * 1e-3) / 1e9);
+    }
+    if (read_gbps) *read_gbps = out[0];
+    if (mix_gbps) *mix_gbps = std::max(out[1], out[2]);  // the better of plain and non-temporal stores
     return FFS_OK;
 }
 

@@ -74,7 +74,7 @@ EXPORTS = [
     "ffs_ctx_apply_resolution_mask", "ffs_ctx_get_mask", "ffs_ctx_set_params",
     "ffs_stream_create", "ffs_stream_destroy", "ffs_stream_host_buffer", "ffs_submit",
     "ffs_submit_device", "ffs_ctx_device_layout", "ffs_wait", "ffs_stream_batch_arrays", "ffs_stream_timings",
-    "ffs_submit_compressed", "ffs_decode_only", "ffs_stream_spot_centres", "ffs_bench_threshold", "ffs_stream_debug_planes", "ffs_stream_debug_bitplane", "ffs_selftest_sqrt", "ffs_stack3d_create",
+    "ffs_submit_compressed", "ffs_decode_only", "ffs_stream_spot_centres", "ffs_bench_threshold", "ffs_bench_hbm", "ffs_stream_debug_planes", "ffs_stream_debug_bitplane", "ffs_selftest_sqrt", "ffs_stack3d_create",
     "ffs_stack3d_destroy", "ffs_stack3d_add_batch", "ffs_stack3d_add_slice", "ffs_stack3d_finish", "ffs_stack3d_signals",
 ]
 
@@ -111,6 +111,7 @@ def load_library():
                                               C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
         L.ffs_bench_threshold.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32,
                                           C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.ffs_bench_hbm.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.ffs_stream_debug_planes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                               C.POINTER(C.c_size_t)]
         L.ffs_stream_spot_centres.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -371,6 +372,12 @@ class Stream:
         self.ctx._check(self._lib.ffs_bench_threshold(self._h, C.c_void_p(dev_ptr), pitch_bytes,
                                                       frame_stride_bytes, n_frames, iters,
                                                       C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def bench_hbm(self, iters: int = 5):
+        """(read-only GB/s, 2:1 read/write GB/s) measured on this stream's buffers (ffs_bench_hbm)."""
+        a, b = C.c_float(), C.c_float()
+        self.ctx._check(self._lib.ffs_bench_hbm(self._h, iters, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def pack_spot_centres(self, out: np.ndarray, cap: int) -> int:

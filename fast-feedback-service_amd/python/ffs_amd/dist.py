@@ -19,19 +19,31 @@ def frame_shard(n_frames: int, rank: int, world: int) -> list[int]:
     return list(range(rank, n_frames, world))
 
 
+class SpotGatherTruncated(RuntimeError):
+    """A rank had more spots than its block of the gather holds."""
+
+
+def _ids_as_float_lanes(ids) -> np.ndarray:
+    """Frame ids travel in a float32 lane of the (frame_id, x, y, z) rows.  As VALUES they would collide
+    from 2^24 on, so the lane carries the low 32 bits of the id as a bit pattern."""
+    return (np.asarray(ids, np.int64) & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+
+
 def pack_spots(results, cap: int) -> np.ndarray:
-    """(cap + 1, 4) float32: rows = (frame_id, com_x, com_y, com_z); last row holds the count."""
+    """(cap + 1, 4) float32: rows = (frame_id bits, com_x, com_y, com_z); the last row holds, as uint32 bit
+    patterns, (rows written, rows wanted) -- wanted > written means the block was too small."""
     out = np.zeros((cap + 1, 4), np.float32)
-    n = 0
+    n = wanted = 0
     for r in results:
         refl = r.reflections
+        wanted += len(refl)
         m = min(len(refl), cap - n)
-        out[n:n + m, 0] = r.frame_id
+        out[n:n + m, 0] = _ids_as_float_lanes([r.frame_id])[0]
         out[n:n + m, 1] = refl["com_x"][:m]
         out[n:n + m, 2] = refl["com_y"][:m]
         out[n:n + m, 3] = refl["com_z"][:m]
         n += m
-    out[cap, 0] = n
+    out[cap].view(np.uint32)[:2] = (n, wanted)
     return out
 
 
@@ -42,8 +54,9 @@ def pack_spots_batch(results, refl_all: np.ndarray, cap: int, out: np.ndarray | 
     if out is None:
         out = np.empty((cap + 1, 4), np.float32)
     counts = np.fromiter((len(r.reflections) for r in results), np.int64, len(results))
-    ids = np.fromiter((r.frame_id for r in results), np.float32, len(results))
-    n = int(min(counts.sum(), cap))
+    ids = _ids_as_float_lanes(np.fromiter((r.frame_id for r in results), np.int64, len(results)))
+    wanted = int(counts.sum())
+    n = int(min(wanted, cap))
     out[:n, 0] = np.repeat(ids, counts)[:n]
     # com_x, com_y, com_z are three consecutive float32 fields of the record: one strided copy
     off = refl_all.dtype.fields["com_x"][1]
@@ -55,19 +68,24 @@ def pack_spots_batch(results, refl_all: np.ndarray, cap: int, out: np.ndarray | 
         out[:n, 1] = refl_all["com_x"][:n]
         out[:n, 2] = refl_all["com_y"][:n]
         out[:n, 3] = refl_all["com_z"][:n]
-    out[cap] = (n, 0, 0, 0)
+    out[cap] = 0
+    out[cap].view(np.uint32)[:2] = (n, wanted)
     return out
 
 
-def unpack_spots(gathered: np.ndarray, world: int, cap: int):
-    """-> {frame_id: (n,3) float32 centres} merged over ranks, insertion in frame order."""
-    g = gathered.reshape(world, cap + 1, 4)
+def unpack_spots(gathered: np.ndarray, world: int, cap: int, blocks_per_rank: int = 1):
+    """-> {frame_id: (n,3) float32 centres} merged over ranks, insertion in frame order.  Frame ids come
+    back as the low 32 bits of what was packed.  Raises SpotGatherTruncated if any block was too small."""
+    g = np.ascontiguousarray(gathered, np.float32).reshape(world * blocks_per_rank, cap + 1, 4)
     merged = {}
-    for r in range(world):
-        n = int(g[r, cap, 0])
+    for r in range(world * blocks_per_rank):
+        n, wanted = (int(v) for v in g[r, cap].view(np.uint32)[:2])
+        if wanted > n:
+            raise SpotGatherTruncated(f"block {r}: {wanted} spots, room for {cap}")
         rows = g[r, :n]
-        for fid in np.unique(rows[:, 0]):
-            merged[int(fid)] = rows[rows[:, 0] == fid, 1:4].copy()
+        ids = rows[:, 0].view(np.uint32)
+        for fid in np.unique(ids):
+            merged[int(fid)] = rows[ids == fid, 1:4].copy()
     return dict(sorted(merged.items()))
 
 

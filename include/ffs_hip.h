@@ -196,9 +196,11 @@ int ffs_stream_timings(ffs_stream *s, float ms[5]);
 
 /* Centres of mass of the last batch's reflections as rows (frame_id, x, y, z) of float32 -- the
  * payload of `--output-for-index` (spot_centers, spotfinder.cc:919-933,1004-1006), in frame order;
- * used to feed a multi-GPU gather without a per-frame loop on the caller's side.  Writes at most
- * `cap` rows, then one more row (n_written, 0, 0, 0): rows4 must hold (cap + 1) * 4 floats.
- * Needs want_reflections. */
+ * used to feed a multi-GPU gather without a per-frame loop on the caller's side.  Lane 0 carries the
+ * low 32 bits of the frame id as a BIT PATTERN (read it as uint32: as a float value ids would collide
+ * from 2^24 on).  Writes at most `cap` rows, then one more row whose first two lanes are, again as uint32
+ * bit patterns, (rows written, rows wanted): rows4 must hold (cap + 1) * 4 floats.  Returns
+ * FFS_ERR_OVERFLOW (rows written are valid) when wanted > cap.  Needs want_reflections. */
 int ffs_stream_spot_centres(ffs_stream *s, float *rows4, uint32_t cap, uint32_t *n_written);
 
 /* ---- kernel-only entry points (bench.py roofline leg, kernel parity tests) ------------------ */
@@ -208,6 +210,12 @@ int ffs_stream_spot_centres(ffs_stream *s, float *rows4, uint32_t cap, uint32_t 
 int ffs_bench_threshold(ffs_stream *s, const void *device_pixels, size_t pitch_bytes,
                         size_t frame_stride_bytes, uint32_t n_frames, uint32_t iters,
                         float *ms_candidate, float *ms_exact);
+/* Memory ceiling measured on this device (BASELINE.md section 3 asks for one beside the nominal 8 TB/s): the
+ * stream's own buffers are read linearly, 16 B per lane (read_gbps), and read while one 8-byte zero store per
+ * 16 bytes read goes to the byte-mask buffer -- the threshold kernel's 2:1 read/write mix with the friendliest
+ * possible addresses (mix_gbps).  GB/s of bytes moved.  Overwrites the stream's byte masks; no batch in flight.
+ * (The reference prints GBps per image, spotfinder/spotfinder.cc:1056-1076, against no ceiling.) */
+int ffs_bench_hbm(ffs_stream *s, uint32_t iters, float *read_gbps, float *mix_gbps);
 /* Device pointers of the last batch's dense planes (strong byte mask rows are
  * mask_pitch apart) -- for parity tests that want the raw kernel output. */
 int ffs_stream_debug_planes(ffs_stream *s, const uint8_t **device_strong_bytes,

@@ -114,6 +114,22 @@ def test_pack_spots_batch_equals_pack_spots():
         parts.append(refl)
     allr = np.concatenate(parts)
     a, b = D.pack_spots(results, 32), D.pack_spots_batch(results, allr, 32)
-    n = int(a[32, 0])
-    assert n == len(allr) == int(b[32, 0])
+    n = int(a[32].view(np.uint32)[0])
+    assert n == len(allr) == int(b[32].view(np.uint32)[0]) == int(b[32].view(np.uint32)[1])
     np.testing.assert_array_equal(a[:n], b[:n])      # rows beyond the count are don't-care
+
+
+def test_spot_rows_keep_large_frame_ids_and_flag_truncation():
+    from ffs_amd import dist as D
+    from oracle import oracle as O
+    refl = np.zeros(3, O.REFL_DT)
+    refl["com_x"], refl["com_y"], refl["com_z"] = (1.5, 2.5, 3.5), (4.5, 5.5, 6.5), 0.5
+    ids = [(1 << 24) + 1, (1 << 24) + 2, (1 << 31) + 7]     # collide or lose bits as float32 values
+    results = [_Fr(i, refl) for i in ids]
+    got = D.unpack_spots(D.pack_spots(results, 16), 1, 16)
+    assert list(got) == ids and all(len(v) == 3 for v in got.values())
+    allr = np.concatenate([refl] * 3)
+    got = D.unpack_spots(D.pack_spots_batch(results, allr, 16), 1, 16)
+    assert list(got) == ids
+    with pytest.raises(D.SpotGatherTruncated):
+        D.unpack_spots(D.pack_spots(results, 8), 1, 8)

@@ -1,0 +1,72 @@
+"""The RCCL leg of the multi-GPU path on ONE GPU: a 1-rank `nccl` process group gathers spot centres
+that the HIP path produced (ffs_stream_spot_centres -> device tensor -> all_gather_into_tensor), exactly the
+calls bench.py makes with N > 1 ranks, and the strong-pixel lists of a small sweep (dist.gather_strong_lists)
+that feed the 3D stack.  World size > 1 is covered on CPU by tests/test_distributed_gloo.py."""
+import socket
+
+import numpy as np
+import pytest
+
+from util import make_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_one_rank_nccl_gather_of_hip_spots(ffs):
+    import torch
+    import torch.distributed as dist
+    from ffs_amd import dist as D
+    from oracle import oracle as O
+    W, H, B = 517, 389, 6
+    frames, mask = [], None
+    for i in range(B):
+        img, mask = make_frame(W=W, H=H, seed=100 + i, n_spots=30)
+        frames.append(img)
+    ctx = ffs.Context(W, H, np.uint16, max_batch=B)
+    ctx.set_mask(mask)
+    ctx.set_params(want_reflections=1, want_strong_list=1)
+    st = ctx.stream()
+    first_id = (1 << 24) + 5            # ids beyond float32's integer range must survive the float lanes
+    res = st.process(np.stack(frames), first_frame_id=first_id)
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                            device_id=dev)
+    try:
+        cap = 64 * B
+        host = torch.empty((cap + 1, 4), dtype=torch.float32).pin_memory()
+        n = st.pack_spot_centres(host.numpy(), cap)
+        assert n == sum(len(r.reflections) for r in res) > 20
+        block = host.to(dev, non_blocking=True)
+        out = torch.empty((1, cap + 1, 4), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(out.view(-1), block.view(-1))
+        spots = D.unpack_spots(out.cpu().numpy(), 1, cap)
+        for i, (r, img) in enumerate(zip(res, frames)):
+            cc = O.cc2d(O.dispersion(img, mask), img, 3)
+            refl = O.cc2d_reflections(cc.k, cc.intensity, W, H, 3, 2.0).reflections
+            if len(refl) == 0:
+                assert first_id + i not in spots
+                continue
+            want = np.stack([refl["com_x"], refl["com_y"], refl["com_z"]], 1)
+            np.testing.assert_array_equal(spots[first_id + i], want)      # HIP -> RCCL -> here == oracle
+        # too small a block is reported, not dropped silently
+        with pytest.raises(ffs.FfsError):
+            st.pack_spot_centres(np.empty((9, 4), np.float32), 8)
+        # the rotation-sweep exchange: per-frame strong lists to the rank that owns the 3D stack
+        slices = {first_id + i: (r.strong_k.copy(), r.strong_intensity.copy()) for i, r in enumerate(res)}
+        merged = D.gather_strong_lists(slices, device=dev)
+        assert list(merged) == sorted(slices)
+        for fid, (k, inten) in slices.items():
+            np.testing.assert_array_equal(merged[fid][0], k)
+            np.testing.assert_array_equal(merged[fid][1], inten)
+    finally:
+        dist.destroy_process_group()

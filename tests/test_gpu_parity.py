@@ -219,7 +219,12 @@ def test_spot_centres_rows(ffs):
     want = D.pack_spots(res, 500)
     got = np.full((501, 4), -1, np.float32)
     n = st.pack_spot_centres(got, 500)
-    assert n == int(want[500, 0]) > 5 and np.array_equal(got[:n], want[:n]) and np.array_equal(got[500], want[500])
+    assert n == int(want[500].view(np.uint32)[0]) > 5
+    assert np.array_equal(got[:n].view(np.uint32), want[:n].view(np.uint32))     # frame ids are bit patterns
+    assert np.array_equal(got[500].view(np.uint32), want[500].view(np.uint32))   # (rows written, rows wanted)
     assert (got[n:500] == -1).all()                      # rows beyond the count are left alone
-    small = np.zeros((4, 4), np.float32)                 # capacity smaller than the batch: truncated, count says so
-    assert st.pack_spot_centres(small, 3) == 3 and np.array_equal(small[:3], want[:3]) and small[3, 0] == 3
+    small = np.zeros((4, 4), np.float32)                 # capacity smaller than the batch: reported, not silent
+    with pytest.raises(ffs.FfsError):
+        st.pack_spot_centres(small, 3)
+    assert np.array_equal(small[:3].view(np.uint32), want[:3].view(np.uint32))
+    assert tuple(small[3].view(np.uint32)[:2]) == (3, n)
