@@ -69,12 +69,21 @@ struct ffs_ctx {
 
 // per-tile strong counts of a batch + one word (the last) for the bright-list count; a multiple of 256 bytes so
 // that one fill kernel clears it
-static size_t tile_counts_bytes(const ffs_ctx* c) { return (((size_t)c->max_batch * c->n_tiles + 1) * 4 + 255) / 256 * 256; }
+struct ffs_stream;
+static size_t tile_counts_bytes(const ffs_stream* s);
 
 constexpr uint32_t kBrightCap = 1u << 20;  // entries of the bright-window list per batch (8 MB)
 
+struct OverflowFrame;
+
 struct ffs_stream {
     ffs_ctx* ctx = nullptr;
+    uint32_t max_batch = 1;   // frames per submit
+    uint32_t cap = 0;         // strong pixels per frame the lists hold
+    uint32_t max_comp = 0;    // components per frame the record buffers hold
+    ffs_stream* big = nullptr;               // one-frame stream with room for frames that exceed cap / max_comp
+    std::vector<OverflowFrame> ovf;          // such frames of the last batch, re-run on `big`
+    int force_variant = -1;                  // >= 0: threshold variant of the next enqueue (bright-list overflow -> 1)
     hipStream_t st = nullptr;    // threshold kernels (+ H2D)
     hipStream_t st2 = nullptr;   // compaction + connected components + D2H; == st unless the CUs are split
     hipEvent_t ev[6] = {};
@@ -127,6 +136,17 @@ struct ffs_stream {
     std::vector<ffs_box> boxes;
     std::vector<ffs_reflection> refls;
 };
+
+// Results of a frame that did not fit the stream's lists, from its re-run on the one-frame stream
+struct OverflowFrame {
+    uint32_t frame = 0;
+    ffs_frame_result res{};
+    std::vector<ffs_box> boxes;
+    std::vector<ffs_reflection> refls;
+    std::vector<uint32_t> k, inten;
+};
+
+static size_t tile_counts_bytes(const ffs_stream* s) { return (((size_t)s->max_batch * s->ctx->n_tiles + 1) * 4 + 255) / 256 * 256; }
 
 struct ffs_stack3d {
     ffs_ctx* ctx = nullptr;
@@ -283,7 +303,7 @@ static int rebuild_mask_tables(ffs_ctx* c) {
     return FFS_OK;
 }
 
-extern "C" int ffs_ctx_set_mask(ffs_ctx* c, const uint8_t* host_mask) {
+static int ffs_ctx_set_mask_impl(ffs_ctx* c, const uint8_t* host_mask) {
     if (!c) return FFS_ERR_INVALID;
     const Layout& L = c->L;
     std::vector<uint8_t> bits(L.plane_frame_stride, 0);
@@ -302,7 +322,7 @@ extern "C" int ffs_ctx_set_mask(ffs_ctx* c, const uint8_t* host_mask) {
     return rebuild_mask_tables(c);
 }
 
-extern "C" int ffs_ctx_get_mask(ffs_ctx* c, uint8_t* host_mask) {
+static int ffs_ctx_get_mask_impl(ffs_ctx* c, uint8_t* host_mask) {
     if (!c || !host_mask) return FFS_ERR_INVALID;
     const Layout& L = c->L;
     std::vector<uint8_t> bits(L.plane_frame_stride);
@@ -384,6 +404,7 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     if (s->job.joinable()) s->job.join();
+    if (s->big) ffs_stream_destroy(s->big);
     if (s->st) (void)hipStreamSynchronize(s->st);
     if (s->st2 && s->st2 != s->st) { (void)hipStreamSynchronize(s->st2); (void)hipStreamDestroy(s->st2); }
     // (d_n_comp, d_summary and d_overflow live inside the d_num_strong allocation)
@@ -401,15 +422,24 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     delete s;
 }
 
+static int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uint32_t max_comp, ffs_stream** out);
+
 extern "C" int ffs_stream_create(ffs_ctx* c, ffs_stream** out) {
     if (!c || !out) return FFS_ERR_INVALID;
+    return stream_create_sized(c, c->max_batch, c->cap, c->max_comp, out);
+}
+
+static int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uint32_t max_comp, ffs_stream** out) {
     *out = nullptr;
     HIP_TRY(c, hipSetDevice(c->device));
     ffs_stream* s = new (std::nothrow) ffs_stream();
     if (!s) return FFS_ERR_NOMEM;
     s->ctx = c;
+    s->max_batch = max_batch;
+    s->cap = cap;
+    s->max_comp = max_comp;
     const Layout& L = c->L;
-    const size_t B = c->max_batch;
+    const size_t B = s->max_batch;
 #define STREAM_TRY(expr)                                                        \
     do {                                                                        \
         hipError_t e_ = (expr);                                                 \
@@ -450,7 +480,7 @@ extern "C" int ffs_stream_create(ffs_ctx* c, ffs_stream** out) {
     STREAM_TRY(dmalloc(&s->d_img, B * L.frame_stride));
     STREAM_TRY(dmalloc(&s->d_bits, B * L.plane_frame_stride));
     STREAM_TRY(dmalloc(&s->d_sbytes, B * L.bytes_frame_stride));
-    STREAM_TRY(dmalloc(&s->d_tile_counts, tile_counts_bytes(c)));
+    STREAM_TRY(dmalloc(&s->d_tile_counts, tile_counts_bytes(s)));
     STREAM_TRY(dmalloc(&s->d_bright, (size_t)kBrightCap * sizeof(uint2)));
 
     // per-frame counters in the layout of h_counts, so that one copy brings them all back:
@@ -460,20 +490,20 @@ extern "C" int ffs_stream_create(ffs_ctx* c, ffs_stream** out) {
     s->d_summary = s->d_num_strong + 2 * B;
     s->d_overflow = s->d_num_strong + 10 * B;
     STREAM_TRY(dmalloc(&s->d_row_off, B * (size_t)(L.H + 1) * 4));
-    STREAM_TRY(dmalloc(&s->d_list_k, B * (size_t)c->cap * 4));
-    STREAM_TRY(dmalloc(&s->d_list_i, B * (size_t)c->cap * 4));
-    STREAM_TRY(dmalloc(&s->d_parent, B * (size_t)c->cap * 4));
-    STREAM_TRY(dmalloc(&s->d_comp_id, B * (size_t)c->cap * 4));
+    STREAM_TRY(dmalloc(&s->d_list_k, B * (size_t)s->cap * 4));
+    STREAM_TRY(dmalloc(&s->d_list_i, B * (size_t)s->cap * 4));
+    STREAM_TRY(dmalloc(&s->d_parent, B * (size_t)s->cap * 4));
+    STREAM_TRY(dmalloc(&s->d_comp_id, B * (size_t)s->cap * 4));
     STREAM_TRY(dmalloc(&s->d_part_roots, B * (size_t)kLabelParts * 4));
-    STREAM_TRY(dmalloc(&s->d_acc, B * (size_t)c->max_comp * sizeof(CompAcc)));
-    STREAM_TRY(dmalloc(&s->d_acc2, B * (size_t)c->cap * sizeof(CompAcc2)));
-    STREAM_TRY(dmalloc(&s->d_chunk_roots, B * (size_t)(c->cap / kRootChunk + 1) * 4));
-    STREAM_TRY(dmalloc(&s->d_recs, B * (size_t)c->max_comp * sizeof(ReflOut)));
+    STREAM_TRY(dmalloc(&s->d_acc, B * (size_t)s->max_comp * sizeof(CompAcc)));
+    STREAM_TRY(dmalloc(&s->d_acc2, B * (size_t)s->cap * sizeof(CompAcc2)));
+    STREAM_TRY(dmalloc(&s->d_chunk_roots, B * (size_t)(s->cap / kRootChunk + 1) * 4));
+    STREAM_TRY(dmalloc(&s->d_recs, B * (size_t)s->max_comp * sizeof(ReflOut)));
     // raw frames, or bitshuffle-LZ4 chunks (which can exceed the raw size by < 1 % when incompressible)
     s->h_img_bytes = B * ((size_t)L.W * L.H * c->pixel_bytes + (size_t)L.W * L.H * c->pixel_bytes / 128 + 4096);
     STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_img), s->h_img_bytes, hipHostMallocDefault));
     STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), (B * 10 + 1) * 4, hipHostMallocDefault));
-    STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_recs), B * (size_t)c->max_comp * sizeof(ReflOut),
+    STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_recs), B * (size_t)s->max_comp * sizeof(ReflOut),
                              hipHostMallocDefault));
     // k_finalize can write the (few MB of) records straight into this pinned, device-visible buffer:
     // no copy kernel after it.  FFS_DIRECT_RECS=0 keeps the device buffer + copy (A/B).
@@ -550,8 +580,10 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
         const char* v = std::getenv("FFS_K1_VARIANT");
         a.variant = v ? std::atoi(v) : 2;
         if (c->pixel_bytes != 2 && a.variant > 1) a.variant = 1;
+        if (s->force_variant >= 0) a.variant = std::min(a.variant, s->force_variant);
     }
-    a.bright_n = s->d_tile_counts + tile_counts_bytes(c) / 4 - 1;
+    a.overflow = s->d_overflow;
+    a.bright_n = s->d_tile_counts + tile_counts_bytes(s) / 4 - 1;
     a.bright_list = s->d_bright;
     a.bright_cap = kBrightCap;
     a.dbg = std::getenv("FFS_K1_DEBUG") ? std::atoi(std::getenv("FFS_K1_DEBUG")) : 0;
@@ -635,7 +667,7 @@ static void launch_extended(ffs_stream* s, const ThresholdArgs& a, uint32_t n_fr
 static int ensure_extended_buffers(ffs_stream* s) {
     if (s->d_dplane) return FFS_OK;
     ffs_ctx* c = s->ctx;
-    const size_t bytes = (size_t)c->max_batch * c->L.plane_frame_stride;
+    const size_t bytes = (size_t)s->max_batch * c->L.plane_frame_stride;
     if (dmalloc(&s->d_dplane, bytes) != hipSuccess || dmalloc(&s->d_eplane, bytes) != hipSuccess) {
         (void)hipGetLastError();
         c->err = "hipMalloc(extended dispersion planes) failed";
@@ -651,7 +683,7 @@ static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_
         b.n_strips = a.s_strips;
         b.band_rows = a.s_band_rows;
         b.n_bands = a.s_bands;
-        (void)hipMemsetAsync(a.tile_counts, 0, tile_counts_bytes(s->ctx), s->st);  // + the bright-list count (last word)
+        (void)hipMemsetAsync(a.tile_counts, 0, tile_counts_bytes(s), s->st);  // + the bright-list count (last word)
         const int bands8s = (b.n_bands + 7) / 8 * 8;
         const unsigned n_groups = (n_frames + (unsigned)a.group_frames - 1) / (unsigned)a.group_frames;
         const int ahead = std::getenv("FFS_K1_AHEAD") ? std::atoi(std::getenv("FFS_K1_AHEAD")) : 2;
@@ -693,7 +725,7 @@ static void launch_exact(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frame
 
 static int check_layout(ffs_stream* s, size_t pitch, size_t fstride, uint32_t n_frames) {
     ffs_ctx* c = s->ctx;
-    if (n_frames == 0 || n_frames > c->max_batch) {
+    if (n_frames == 0 || n_frames > s->max_batch) {
         c->err = "n_frames must be in 1..max_batch";
         return FFS_ERR_INVALID;
     }
@@ -728,7 +760,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     // 37.2 k frames/s.  CU masks for the two stages: no gain either.)
     const bool one_kernel = c->pixel_bytes == 2 && ta.variant >= 2 && p.algorithm != FFS_ALGO_DISPERSION_EXTENDED;
     if (one_kernel && s->bits_dirty)  // (another algorithm / variant or a failed batch left bits behind)
-        HIP_TRY(c, hipMemsetAsync(s->d_bits, 0, (size_t)c->max_batch * L.plane_frame_stride, s->st));
+        HIP_TRY(c, hipMemsetAsync(s->d_bits, 0, (size_t)s->max_batch * L.plane_frame_stride, s->st));
     s->bits_dirty = !one_kernel;
     if (p.algorithm == FFS_ALGO_DISPERSION_EXTENDED) {
         launch_extended(s, ta, n);
@@ -761,8 +793,8 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     ca.mpitch = L.mpitch;
     ca.plane_frame_stride = L.plane_frame_stride;
     ca.n_tiles = c->n_tiles;
-    ca.cap = c->cap;
-    ca.max_comp = c->max_comp;
+    ca.cap = s->cap;
+    ca.max_comp = s->max_comp;
     ca.pixel_bytes = c->pixel_bytes;
     ca.strong_bytes = s->d_sbytes;
     ca.bpitch = L.bpitch;
@@ -799,10 +831,10 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     sa.parent = s->d_parent;
     sa.comp_id = s->d_comp_id;
     sa.seg_n = s->d_num_strong;
-    sa.seg_stride = c->cap;
+    sa.seg_stride = s->cap;
     sa.n_comp = s->d_n_comp;
     sa.acc = s->d_acc;
-    sa.max_comp = c->max_comp;
+    sa.max_comp = s->max_comp;
     sa.overflow = s->d_overflow;
     sa.W = (uint32_t)L.W;
     sa.H = (uint32_t)L.H;
@@ -820,7 +852,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     sa.runs_linked = (emit_variant >= 1 || root_mode) ? 2 : link_runs;
     sa.acc2 = s->d_acc2;
     sa.chunk_roots = s->d_chunk_roots;
-    sa.chunks_max = c->cap / kRootChunk + 1;
+    sa.chunks_max = s->cap / kRootChunk + 1;
     if (emit_variant < 1 && !root_mode && link_runs) hipLaunchKernelGGL(k_link_runs, gseg, b256, 0, s->st2, sa);
     hipLaunchKernelGGL(k_union<false>, gseg, b256, 0, s->st2, sa);
     if (root_mode) {
@@ -837,12 +869,12 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     HIP_TRY(c, hipEventRecord(s->ev[3], s->st2));
 
     // small counts first; ffs_wait() sizes the record copy from them
-    const size_t B = c->max_batch;
+    const size_t B = s->max_batch;
     HIP_TRY(c, hipMemcpyAsync(s->h_counts, s->d_num_strong, (B * 10 + 1) * 4, hipMemcpyDeviceToHost, s->st2));
     if (s->direct_recs) {
-        s->spec_recs_copied = (uint64_t)B * c->max_comp;  // everything is on the host already
+        s->spec_recs_copied = (uint64_t)B * s->max_comp;  // everything is on the host already
     } else {
-        s->spec_recs_copied = std::min<uint64_t>((uint64_t)s->spec_recs_per_frame * n, (uint64_t)B * c->max_comp);
+        s->spec_recs_copied = std::min<uint64_t>((uint64_t)s->spec_recs_per_frame * n, (uint64_t)B * s->max_comp);
         HIP_TRY(c, hipMemcpyAsync(s->h_recs, s->d_recs, s->spec_recs_copied * (s->wire2 ? sizeof(WireRec2) : sizeof(ReflOut)),
                                   hipMemcpyDeviceToHost, s->st2));
     }
@@ -876,7 +908,7 @@ extern "C" int ffs_submit(ffs_stream* s, const void* host_pixels, uint32_t n_fra
         c->err = "stream already has a batch in flight: call ffs_wait() first";
         return FFS_ERR_INVALID;
     }
-    if (n_frames == 0 || n_frames > c->max_batch) {
+    if (n_frames == 0 || n_frames > s->max_batch) {
         c->err = "n_frames must be in 1..max_batch";
         return FFS_ERR_INVALID;
     }
@@ -906,7 +938,7 @@ static int ensure_decode_buffers(ffs_stream* s) {
     s->dec_blocks = (uint32_t)(n_full + (rem >= 8 ? 1 : 0));
     s->dec_last = (uint32_t)(rem >= 8 ? rem / 8 * 8 : block);
     s->dec_tail = (uint32_t)(rem % 8);
-    const size_t tab_bytes = (size_t)c->max_batch * (s->dec_blocks + 1) * sizeof(uint2);
+    const size_t tab_bytes = (size_t)s->max_batch * (s->dec_blocks + 1) * sizeof(uint2);
     if (dmalloc(&s->d_comp, s->h_img_bytes + 64) != hipSuccess || dmalloc(&s->d_tab, tab_bytes) != hipSuccess
         || hipHostMalloc(reinterpret_cast<void**>(&s->h_tab), tab_bytes, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
@@ -1054,7 +1086,7 @@ static void launch_decode(ffs_stream* s, uint32_t n) {
     else hipLaunchKernelGGL(k_bshuf_lz4_decode<4>, grid, dim3(64), 0, s->st, da);
 }
 
-extern "C" int ffs_submit_compressed(ffs_stream* s, const void* const* chunks, const size_t* chunk_bytes,
+static int ffs_submit_compressed_impl(ffs_stream* s, const void* const* chunks, const size_t* chunk_bytes,
                                      uint32_t n_frames, int64_t first_frame_id) {
     if (!s || !chunks || !chunk_bytes) return FFS_ERR_INVALID;
     ffs_ctx* c = s->ctx;
@@ -1062,7 +1094,7 @@ extern "C" int ffs_submit_compressed(ffs_stream* s, const void* const* chunks, c
         c->err = "stream already has a batch in flight: call ffs_wait() first";
         return FFS_ERR_INVALID;
     }
-    if (n_frames == 0 || n_frames > c->max_batch) {
+    if (n_frames == 0 || n_frames > s->max_batch) {
         c->err = "n_frames must be in 1..max_batch";
         return FFS_ERR_INVALID;
     }
@@ -1110,7 +1142,7 @@ extern "C" int ffs_decode_only(ffs_stream* s, const void* const* chunks, const s
                                uint32_t iters, float* ms_decode, void* host_out) {
     if (!s || !chunks || !chunk_bytes || iters == 0) return FFS_ERR_INVALID;
     ffs_ctx* c = s->ctx;
-    if (s->busy || n_frames == 0 || n_frames > c->max_batch) {
+    if (s->busy || n_frames == 0 || n_frames > s->max_batch) {
         c->err = "ffs_decode_only: stream busy or n_frames out of range";
         return FFS_ERR_INVALID;
     }
@@ -1153,14 +1185,14 @@ extern "C" int ffs_decode_only(ffs_stream* s, const void* const* chunks, const s
 static int ensure_list_host(ffs_stream* s) {
     ffs_ctx* c = s->ctx;
     if (!s->h_list_k) {
-        const size_t bytes = (size_t)c->max_batch * c->cap * 4;
+        const size_t bytes = (size_t)s->max_batch * s->cap * 4;
         HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&s->h_list_k), bytes, hipHostMallocDefault));
         HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&s->h_list_i), bytes, hipHostMallocDefault));
     }
     return FFS_OK;
 }
 
-extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_results) {
+static int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_results) {
     if (!s) return FFS_ERR_INVALID;
     ffs_ctx* c = s->ctx;
     if (!s->busy) {
@@ -1179,7 +1211,7 @@ extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_
     }
     HIP_TRY(c, hipEventSynchronize(s->ev[4]));
     const uint32_t n = s->n_frames;
-    const size_t B = c->max_batch;
+    const size_t B = s->max_batch;
     const Layout& L = c->L;
     const ffs_params& p = s->batch_params;
     const uint32_t* h_ns = s->h_counts;
@@ -1187,6 +1219,7 @@ extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_
     const uint32_t* h_sm = s->h_counts + 2 * B;
     const uint32_t overflow = s->h_counts[10 * B];
     s->busy = false;
+    s->ovf.clear();
     if (overflow) {
         s->bits_dirty = true;
         (void)hipMemsetAsync(s->d_overflow, 0, 4, s->st2);
@@ -1195,15 +1228,86 @@ extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_
             c->err = "corrupt bitshuffle-LZ4 chunk: an LZ4 block did not decode to its block size";
             return FFS_ERR_INVALID;
         }
-        c->err = (overflow & 1u) ? "a frame has more strong pixels than max_strong_per_frame"
-                                 : "a frame has more connected components than the context holds";
-        return FFS_ERR_OVERFLOW;
+        if (overflow & 8u) {
+            // more bright-window pixels than the list k_stream_u16 hands to k_bright_fix holds (a batch of
+            // saturated frames): run the batch again through the two-kernel threshold path, which has no such list
+            s->force_variant = 1;
+            int rc = enqueue_batch(s, s->cur_img, s->cur_pitch, s->cur_fstride, s->n_frames, &s->batch_params);
+            s->force_variant = -1;
+            if (rc != FFS_OK) return rc;
+            return ffs_wait_impl(s, results, n_results);
+        }
+        // A frame with more strong pixels than the stream's lists hold (flag 1) or more components than its
+        // record buffers (flag 2) -- an ice ring, the direct beam.  The reference has no such limit (std::map of
+        // signals, connected_components.cc:24-32), so neither may the drop-in: the other frames of the batch are
+        // complete (lists and records are per frame), and each frame that did not fit is run again on its own on
+        // a one-frame stream with room for it (kept for the next time).
+        for (uint32_t f = 0; f < n; ++f) {
+            if (h_ns[f] <= s->cap && h_nc[f] <= s->max_comp) continue;
+            uint64_t need_cap = std::max<uint64_t>(h_ns[f], s->cap);
+            uint64_t need_comp = h_ns[f] > s->cap ? need_cap : std::max<uint64_t>(h_nc[f], s->max_comp);  // list truncated: count unknown
+            for (int attempt = 0;; ++attempt) {
+                if (s->big && (s->big->cap < need_cap || s->big->max_comp < need_comp)) {
+                    ffs_stream_destroy(s->big);
+                    s->big = nullptr;
+                }
+                if (!s->big) {
+                    const uint64_t npx = (uint64_t)L.W * L.H;
+                    const uint32_t bc = (uint32_t)std::min<uint64_t>(npx, need_cap + need_cap / 4 + 1024);
+                    const uint32_t bm = (uint32_t)std::min<uint64_t>(bc, need_comp + need_comp / 4 + 1024);
+                    int rc = stream_create_sized(c, 1, bc, bm, &s->big);
+                    if (rc != FFS_OK) return rc;  // a real out-of-memory
+                }
+                ffs_stream* b = s->big;
+                const uint8_t* img = static_cast<const uint8_t*>(s->cur_img) + (size_t)f * s->cur_fstride;
+                b->first_id = s->first_id + f;
+                HIP_TRY(c, hipEventRecord(b->ev[0], b->st));
+                HIP_TRY(c, hipEventRecord(b->ev[1], b->st));
+                int rc = enqueue_batch(b, img, s->cur_pitch, s->cur_fstride, 1, &s->batch_params);
+                if (rc != FFS_OK) return rc;
+                HIP_TRY(c, hipEventSynchronize(b->ev[4]));
+                const uint32_t b_ovf = b->h_counts[10 * (size_t)b->max_batch];
+                if (b_ovf & 3u) {  // only the component count can still be short (it was a guess while the list was cut)
+                    (void)hipMemsetAsync(b->d_overflow, 0, 4, b->st2);
+                    (void)hipStreamSynchronize(b->st2);
+                    b->busy = false;
+                    b->bits_dirty = true;
+                    need_cap = std::max<uint64_t>(need_cap, b->h_counts[0]);
+                    need_comp = std::max<uint64_t>(need_comp * 2, b->h_counts[b->max_batch]);
+                    if (attempt >= 4) {
+                        c->err = "a frame still overflows its one-frame stream";
+                        return FFS_ERR_OVERFLOW;
+                    }
+                    continue;
+                }
+                const ffs_frame_result* br = nullptr;
+                uint32_t bn = 0;
+                rc = ffs_wait_impl(b, &br, &bn);
+                if (rc != FFS_OK) return rc;
+                s->ovf.emplace_back();
+                OverflowFrame& o = s->ovf.back();
+                o.frame = f;
+                o.res = br[0];
+                o.boxes.assign(br[0].boxes, br[0].boxes + br[0].n_boxes);
+                if (br[0].reflections) o.refls.assign(br[0].reflections, br[0].reflections + br[0].n_reflections);
+                if (br[0].strong_k) {
+                    o.k.assign(br[0].strong_k, br[0].strong_k + br[0].num_strong_pixels);
+                    o.inten.assign(br[0].strong_intensity, br[0].strong_intensity + br[0].num_strong_pixels);
+                }
+                break;
+            }
+        }
     }
+    auto overflow_frame = [&](uint32_t f) -> const OverflowFrame* {
+        for (const OverflowFrame& o : s->ovf)
+            if (o.frame == f) return &o;
+        return nullptr;
+    };
     uint64_t total_recs = 0;
     uint32_t max_ns = 0;
     for (uint32_t f = 0; f < n; ++f) {
-        total_recs += h_nc[f];
-        max_ns = std::max(max_ns, h_ns[f]);
+        total_recs += std::min<uint32_t>(h_nc[f], s->max_comp);  // (the kernels never write more than max_comp per frame)
+        max_ns = std::max(max_ns, std::min<uint32_t>(h_ns[f], s->cap));
     }
     bool second_phase = false;
     if (total_recs > s->spec_recs_copied) {  // more records than the speculative copy brought: fetch the rest
@@ -1214,14 +1318,14 @@ extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_
         second_phase = true;
     }
     s->spec_recs_per_frame = std::max<uint32_t>(s->spec_recs_per_frame,
-                                                (uint32_t)std::min<uint64_t>(c->max_comp, (total_recs / n + 1) * 5 / 4));
+                                                (uint32_t)std::min<uint64_t>(s->max_comp, (total_recs / n + 1) * 5 / 4));
     if (p.want_strong_list && max_ns) {
         second_phase = true;
         int rc = ensure_list_host(s);
         if (rc != FFS_OK) return rc;
-        HIP_TRY(c, hipMemcpy2DAsync(s->h_list_k, (size_t)c->cap * 4, s->d_list_k, (size_t)c->cap * 4,
+        HIP_TRY(c, hipMemcpy2DAsync(s->h_list_k, (size_t)s->cap * 4, s->d_list_k, (size_t)s->cap * 4,
                                     (size_t)max_ns * 4, n, hipMemcpyDeviceToHost, s->st2));
-        HIP_TRY(c, hipMemcpy2DAsync(s->h_list_i, (size_t)c->cap * 4, s->d_list_i, (size_t)c->cap * 4,
+        HIP_TRY(c, hipMemcpy2DAsync(s->h_list_i, (size_t)s->cap * 4, s->d_list_i, (size_t)s->cap * 4,
                                     (size_t)max_ns * 4, n, hipMemcpyDeviceToHost, s->st2));
     }
     if (p.want_strong_mask) {
@@ -1257,7 +1361,14 @@ extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_
     for (uint32_t f = 0; f < n; ++f) {
         box_at[f] = s->boxes.size();
         refl_at[f] = s->refls.size();
-        const uint32_t nc = std::min<uint32_t>(h_nc[f], c->max_comp);
+        const uint32_t nc = std::min<uint32_t>(h_nc[f], s->max_comp);
+        if (const OverflowFrame* o = overflow_frame(f)) {  // re-run on the one-frame stream: skip the cut records
+            if (s->wire2) wrec += nc;
+            else rec += nc;
+            s->boxes.insert(s->boxes.end(), o->boxes.begin(), o->boxes.end());
+            if (p.want_reflections) s->refls.insert(s->refls.end(), o->refls.begin(), o->refls.end());
+            continue;
+        }
         if (s->wire2) {
             for (uint32_t q = 0; q < nc; ++q, ++wrec) {
                 const uint32_t npx = wrec->npx_flags & 0x3FFFFFFFu, flags = wrec->npx_flags >> 30;
@@ -1303,10 +1414,24 @@ extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_
         r.n_filtered_size = sm[3];
         r.n_filtered_sep = sm[4];
         if (p.want_strong_list) {
-            r.strong_k = s->h_list_k ? s->h_list_k + (size_t)f * c->cap : nullptr;
-            r.strong_intensity = s->h_list_i ? s->h_list_i + (size_t)f * c->cap : nullptr;
+            r.strong_k = s->h_list_k ? s->h_list_k + (size_t)f * s->cap : nullptr;
+            r.strong_intensity = s->h_list_i ? s->h_list_i + (size_t)f * s->cap : nullptr;
         }
         if (p.want_strong_mask) r.strong_mask = s->h_mask + (size_t)f * L.W * L.H;
+        if (const OverflowFrame* o = overflow_frame(f)) {
+            const ffs_frame_result& b = o->res;
+            r.num_strong_pixels = b.num_strong_pixels;
+            r.num_strong_pixels_filtered = b.num_strong_pixels_filtered;
+            r.n_components = b.n_components;
+            r.n_boxes = b.n_boxes;
+            r.n_reflections = p.want_reflections ? b.n_reflections : 0;
+            r.n_filtered_size = b.n_filtered_size;
+            r.n_filtered_sep = b.n_filtered_sep;
+            if (p.want_strong_list) {
+                r.strong_k = o->k.data();
+                r.strong_intensity = o->inten.data();
+            }
+        }
     }
     if (results) *results = s->results.data();
     if (n_results) *n_results = n;
@@ -1373,7 +1498,7 @@ extern "C" int ffs_stream_debug_bitplane(ffs_stream* s, uint32_t frame, int whic
     if (!s || !host_out || which < 0 || which > 2) return FFS_ERR_INVALID;
     ffs_ctx* c = s->ctx;
     const Layout& L = c->L;
-    if (s->busy || frame >= c->max_batch) {
+    if (s->busy || frame >= s->max_batch) {
         c->err = "ffs_stream_debug_bitplane: stream busy or frame out of range";
         return FFS_ERR_INVALID;
     }
@@ -1470,9 +1595,9 @@ extern "C" int ffs_bench_hbm(ffs_stream* s, uint32_t iters, float* read_gbps, fl
         return FFS_ERR_INVALID;
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    const uint64_t n16 = (uint64_t)c->max_batch * c->L.frame_stride / 16;
+    const uint64_t n16 = (uint64_t)s->max_batch * c->L.frame_stride / 16;
     // the byte-mask buffer holds half as many bytes as the pixel buffer for 16-bit pixels, a quarter for 32-bit
-    const uint64_t n16w = std::min<uint64_t>(n16, (uint64_t)c->max_batch * c->L.bytes_frame_stride / 8);
+    const uint64_t n16w = std::min<uint64_t>(n16, (uint64_t)s->max_batch * c->L.bytes_frame_stride / 8);
     const uint4* src = reinterpret_cast<const uint4*>(s->d_img);
     uint2* dst = reinterpret_cast<uint2*>(s->d_sbytes);
     float out[3] = {0, 0, 0};
@@ -1558,9 +1683,9 @@ extern "C" int ffs_stack3d_add_batch(ffs_stack3d* st, ffs_stream* s) {
         sl.k.resize(n);
         sl.inten.resize(n);
         if (n) {
-            HIP_TRY(c, hipMemcpyAsync(sl.k.data(), s->d_list_k + (size_t)f * c->cap, (size_t)n * 4,
+            HIP_TRY(c, hipMemcpyAsync(sl.k.data(), s->d_list_k + (size_t)f * s->cap, (size_t)n * 4,
                                       hipMemcpyDeviceToHost, s->st2));
-            HIP_TRY(c, hipMemcpyAsync(sl.inten.data(), s->d_list_i + (size_t)f * c->cap, (size_t)n * 4,
+            HIP_TRY(c, hipMemcpyAsync(sl.inten.data(), s->d_list_i + (size_t)f * s->cap, (size_t)n * 4,
                                       hipMemcpyDeviceToHost, s->st2));
         }
     }
@@ -1726,4 +1851,36 @@ extern "C" int ffs_stack3d_finish(ffs_stack3d* st, const ffs_reflection** reflec
     if (n_f_size) *n_f_size = fs;
     if (n_f_sep) *n_f_sep = fp;
     return FFS_OK;
+}
+
+// ---- no exception crosses the C ABI -----------------------------------------------------------------------
+// The entry points that grow std::vectors (results, staging tables, masks) run inside a catch-all: an
+// allocation failure or a length error becomes FFS_ERR_NOMEM with its text in ffs_last_error, instead of
+// std::terminate -> abort() in the caller's process.
+template <typename F>
+static int guarded(ffs_ctx* c, F&& body) {
+    try {
+        return body();
+    } catch (const std::exception& e) {
+        if (c) c->err = std::string("exception inside libffs_hip: ") + e.what();
+        else g_create_error = std::string("exception inside libffs_hip: ") + e.what();
+        return FFS_ERR_NOMEM;
+    } catch (...) {
+        if (c) c->err = "unknown exception inside libffs_hip";
+        return FFS_ERR_NOMEM;
+    }
+}
+
+extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_results) {
+    return guarded(s ? s->ctx : nullptr, [&] { return ffs_wait_impl(s, results, n_results); });
+}
+extern "C" int ffs_submit_compressed(ffs_stream* s, const void* const* chunks, const size_t* chunk_bytes,
+                                     uint32_t n_frames, int64_t first_frame_id) {
+    return guarded(s ? s->ctx : nullptr, [&] { return ffs_submit_compressed_impl(s, chunks, chunk_bytes, n_frames, first_frame_id); });
+}
+extern "C" int ffs_ctx_set_mask(ffs_ctx* c, const uint8_t* host_mask) {
+    return guarded(c, [&] { return ffs_ctx_set_mask_impl(c, host_mask); });
+}
+extern "C" int ffs_ctx_get_mask(ffs_ctx* c, uint8_t* host_mask) {
+    return guarded(c, [&] { return ffs_ctx_get_mask_impl(c, host_mask); });
 }

@@ -73,6 +73,7 @@ struct ThresholdArgs {
     uint32_t* bright_n;        // [1] pixels handed to k_bright_fix (window sum >= 65536)
     uint2* bright_list;        // [bright_cap] (frame << 16 | x, y)
     uint32_t bright_cap;
+    uint32_t* overflow;        // status word: 8 = the bright-window list overflowed
     int dbg;                   // FFS_K1_DEBUG: timing experiments only (results are wrong when set)
 };
 

@@ -426,6 +426,7 @@ rows_done:
 // Pixels whose window holds sum p >= 65536 (k_stream_u16 cannot vouch for its 32-bit sum of p^2): exact
 // 64-bit sums gathered from memory, then the same predicate.  A handful per frame at most.
 __global__ __launch_bounds__(256) void k_bright_fix(const ThresholdArgs a) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *a.bright_n > a.bright_cap) atomicOr(a.overflow, 8u);  // the host re-runs the batch
     const uint32_t n = min(*a.bright_n, a.bright_cap);
     for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
         const uint2 r = a.bright_list[e];

@@ -116,7 +116,10 @@ int ffs_device_total_mem(int device, uint64_t *bytes);
 /* ---- context: one per (GPU, detector geometry) --------------------------------------------- */
 /* pixel_bytes: 2 (uint16) or 4 (uint32) -- replaces the compile-time pixel_t switch
  * (h5read/include/h5read.h:16-20, spotfinder/CMakeLists.txt:45-73).
- * max_batch: frames per submit.  max_strong_per_frame: 0 = default (min(W*H, 1<<20)). */
+ * max_batch: frames per submit.  max_strong_per_frame: strong pixels per frame the batch lists are sized for,
+ * 0 = default min(W*H, 2^18) (and min(that, 65536) components).  Not a limit on the data: a frame that exceeds
+ * either is run again on its own with room for it inside ffs_wait() (the reference's std::map of signals,
+ * connected_components.cc:24-32, has no bound), at the price of that extra pass. */
 int ffs_ctx_create(int device, uint32_t width, uint32_t height, int pixel_bytes,
                    uint32_t max_batch, uint32_t max_strong_per_frame, ffs_ctx **out);
 void ffs_ctx_destroy(ffs_ctx *ctx);

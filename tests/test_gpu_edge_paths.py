@@ -3,7 +3,7 @@ chunked path of the exact kernel), capacity overflow errors, extreme shapes."""
 import numpy as np
 import pytest
 
-from util import assert_frame_matches_oracle
+from util import assert_frame_matches_oracle, make_frame
 
 pytestmark = pytest.mark.gpu
 
@@ -34,21 +34,26 @@ def test_dense_candidate_frames(ffs, kind, variant, monkeypatch):
     assert_frame_matches_oracle(fr, img, mask)
 
 
-def test_capacity_overflow_is_an_error_not_a_crash(ffs):
+def test_capacity_overflow_is_absorbed(ffs):
+    """More strong pixels than `max_strong_per_frame`: not an error any more -- the frame is run again with
+    room for it and the result is the oracle's (the reference has no capacity at all)."""
     rng = np.random.default_rng(3)
     H, W = 120, 200
     img = rng.poisson(1.0, (H, W)).astype(np.uint16)
     img[::7, ::5] = 900                      # ~700 isolated strong pixels
+    mask = np.ones((H, W), np.uint8)
     ctx = ffs.Context(W, H, np.uint16, max_strong_per_frame=100)
+    ctx.set_params(want_strong_list=1)
     st = ctx.stream()
-    with pytest.raises(ffs.FfsError) as e:
-        st.process(img)
-    assert e.value.code == -4                # FFS_ERR_OVERFLOW
+    fr = st.process(img)[0]
+    assert fr.num_strong_pixels > 600
+    assert_frame_matches_oracle(fr, img, mask)
     # the stream stays usable
     quiet = rng.poisson(1.0, (H, W)).astype(np.uint16)
     quiet[50, 60:63] = 300
     fr = st.process(quiet)[0]
     assert 1 <= fr.num_strong_pixels <= 100
+    assert_frame_matches_oracle(fr, quiet, mask)
 
 
 @pytest.mark.parametrize("H,W", [(1, 1), (3, 5), (7, 9), (6, 700), (2000, 8), (40, 4097), (16, 10240)])
@@ -114,3 +119,53 @@ def test_stream_closed_with_a_compressed_batch_in_flight(ffs):
     st.close()                                                          # no wait()
     st2 = ctx.stream()
     assert st2.process(img)[0].num_strong_pixels > 0                    # the context is still usable
+
+
+def _checker_frame(W, H, lo=0, hi=1000):
+    img = np.full((H, W), lo, np.uint16)
+    img[::2, ::2] = hi
+    img[1::2, 1::2] = hi
+    return img
+
+
+def test_frame_beyond_the_list_capacity_inside_a_batch(ffs):
+    """One frame with far more strong pixels (and components) than the stream's lists hold, between two
+    normal frames: the batch must come back complete and equal to the oracle (the reference's
+    ConnectedComponents has no capacity, connected_components.cc:24-32)."""
+    W, H = 300, 200
+    normal0, mask = make_frame(W=W, H=H, seed=11, n_spots=25)
+    normal1, _ = make_frame(W=W, H=H, seed=12, n_spots=25)
+    dense = _checker_frame(W, H)                       # every other pixel strong, each its own component
+    frames = np.stack([normal0, dense, normal1])
+    ctx = ffs.Context(W, H, np.uint16, max_batch=3, max_strong_per_frame=2000)   # lists far too small for `dense`
+    ctx.set_params(want_strong_mask=1, want_strong_list=1)
+    st = ctx.stream()
+    res = st.process(frames, first_frame_id=7)
+    assert [r.frame_id for r in res] == [7, 8, 9]
+    assert res[1].num_strong_pixels > 20000 and res[1].n_components > 20000
+    for fr, img in zip(res, frames):
+        assert_frame_matches_oracle(fr, img, mask)
+    # the same stream keeps working, and a second overflowing batch reuses the one-frame stream
+    res2 = st.process(frames[::-1].copy())
+    for fr, img in zip(res2, frames[::-1]):
+        assert_frame_matches_oracle(fr, img, mask)
+    # components alone over the limit: many 1-pixel components, few enough strong pixels for the list
+    ctx2 = ffs.Context(W, H, np.uint16, max_batch=2, max_strong_per_frame=40000)
+    ctx2.set_params(want_strong_list=1)
+    st2 = ctx2.stream()
+    for fr, img in zip(st2.process(np.stack([dense, normal0])), (dense, normal0)):
+        assert_frame_matches_oracle(fr, img, mask)
+
+
+def test_default_capacity_overflow_full_size_lists(ffs):
+    """Default capacities (2^18 strong pixels, 65536 components per frame) exceeded by a frame that is half
+    strong pixels."""
+    W, H = 1024, 640
+    dense = _checker_frame(W, H)
+    normal, mask = make_frame(W=W, H=H, seed=5, n_spots=40)
+    ctx = ffs.Context(W, H, np.uint16, max_batch=2)
+    st = ctx.stream()
+    res = st.process(np.stack([normal, dense]))
+    assert res[1].num_strong_pixels > (1 << 18)
+    for fr, img in zip(res, (normal, dense)):
+        assert_frame_matches_oracle(fr, img, mask)
