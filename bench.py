@@ -133,13 +133,79 @@ def cpu_baseline(frames, mask, ext=False, budget_s=12.0):
     }
 
 
+def bench_sweep(args, dev, local_rank):
+    """BASELINE.json configs[4]: 100-frame Eiger-16M fine-phi sweep (800 reflections with a rocking curve,
+    min_spot_size 3, min_spot_size_3d 15 -- tests/3d_connected_components.sh:27-37), frames resident in HBM.
+    One step = the whole sweep: four 25-frame batches through threshold + 2D components, their strong-pixel
+    lists appended to the device-resident 3D stack, then ffs_stack3d_finish (3D union-find, centroids,
+    filters, per-signal labels) with the reflections on the host."""
+    import torch
+    import ffs_amd
+    from ffs_amd import synth
+    W, H, NZ, B = 4148, 4362, 100, 25
+    p = synth.sweep_params(seed=5000, n_frames=NZ, n_spots=800)
+    mask = synth.mask_eiger16m()
+    ctx = ffs_amd.Context(W, H, np.uint16, max_batch=B, device=local_rank)
+    ctx.set_mask(mask)
+    ctx.set_params(want_reflections=0, min_spot_size=3, min_spot_size_3d=15)
+    pitch, fstride = ctx.device_layout()
+    d_frames = torch.empty(NZ * fstride, dtype=torch.uint8, device=dev)
+    host = np.zeros((B, H, pitch // 2), np.uint16)
+    for z0 in range(0, NZ, B):
+        host[:, :, :W] = synth.frames(p, range(z0, z0 + B), threads=min(16, os.cpu_count() or 1))
+        d_frames[z0 * fstride:(z0 + B) * fstride].copy_(torch.from_numpy(host.view(np.uint8).reshape(-1)))
+    del host
+    streams = [ctx.stream() for _ in range(2)]
+    n_refl, finish_ms = 0, []
+
+    def sweep():
+        nonlocal n_refl
+        stack = ffs_amd.Stack3D(ctx)
+        inflight = []
+        for b in range(NZ // B + len(streams)):
+            if len(inflight) == len(streams) or (b >= NZ // B and inflight):
+                s = inflight.pop(0)
+                s.wait(copy=False)
+                stack.add_batch(s)
+            if b < NZ // B:
+                s = streams[b % len(streams)]
+                s.submit_device(d_frames.data_ptr() + b * B * fstride, pitch, fstride, B, first_frame_id=b * B)
+                inflight.append(s)
+        refl, n_calc, fs, fp = stack.finish()
+        finish_ms.append(stack.last_finish_ms())
+        n_refl = len(refl)
+        stack.close()
+
+    for _ in range(max(1, args.warmup // 2)):
+        sweep()
+    torch.cuda.synchronize(dev)
+    finish_ms.clear()
+    steps = max(1, args.steps // 10)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sweep()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "detector frames/s (Eiger-16M 100-frame sweep, 2D + 3D connected components)", "value": round(steps * NZ / elapsed, 1),
+        "unit": "frames/s", "n_gpus": 1, "steps": steps, "warmup": max(1, args.warmup // 2), "ms_per_step": round(elapsed / steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+        "config": {"workload": "sweep16m: 100 x 4148x4362 uint16 frames resident in HBM, 800 reflections with a rocking curve, "
+                               "min_spot_size 3, min_spot_size_3d 15; one step = whole sweep incl. ffs_stack3d_finish",
+                   "frames_per_batch": B, "streams": len(streams), "reflections_3d": n_refl,
+                   "stack3d_finish_device_ms": round(float(np.mean(finish_ms)), 3)},
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="frames per step and per GPU")
-    ap.add_argument("--workload", default="eiger16m", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="eiger16m", choices=sorted(WORKLOADS) + ["sweep16m"],
+                    help="sweep16m = BASELINE.json configs[4]: a 100-frame Eiger-16M rotation sweep through the 2D path, "
+                         "the device-resident 3D stack and its finish (one step = one whole sweep)")
     ap.add_argument("--streams", type=int, default=4, help="batches in flight per GPU (measured: 2 -> 52.8 k, 3 -> 59.9 k, 4 -> 61.1 k, 6 -> 64.1 k frames/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--algorithm", default="dispersion", choices=["dispersion", "dispersion_extended"],
@@ -169,6 +235,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import ffs_amd
+    if args.workload == "sweep16m":
+        return bench_sweep(args, dev, local_rank)
     W, H, dt, bytes_per_px = WORKLOADS[args.workload]
     B = args.batch
     n_unique = B

@@ -20,6 +20,7 @@
 #include "kernels_threshold.hpp"
 #include "kernels_extended.hpp"
 #include "kernels_stream.hpp"
+#include "kernels_stack3d.hpp"
 #include "kernels_decode.hpp"
 
 using namespace ffsamd;
@@ -57,6 +58,25 @@ struct ffs_ctx {
     uint8_t* d_mmap = nullptr;   // per-pixel window counts
     ThreadError err;  // the calling thread's most recent error on any context
 };
+
+// ---- no exception crosses the C ABI -----------------------------------------------------------------------
+// The entry points that grow std::vectors (results, staging tables, masks) run inside a catch-all: an
+// allocation failure or a length error becomes FFS_ERR_NOMEM with its text in ffs_last_error, instead of
+// std::terminate -> abort() in the caller's process.
+template <typename F>
+static int guarded(ffs_ctx* c, F&& body) {
+    try {
+        return body();
+    } catch (const std::exception& e) {
+        if (c) c->err = std::string("exception inside libffs_hip: ") + e.what();
+        else g_create_error = std::string("exception inside libffs_hip: ") + e.what();
+        return FFS_ERR_NOMEM;
+    } catch (...) {
+        if (c) c->err = "unknown exception inside libffs_hip";
+        return FFS_ERR_NOMEM;
+    }
+}
+
 
 #define HIP_TRY(ctx, expr)                                                              \
     do {                                                                                \
@@ -148,18 +168,58 @@ struct OverflowFrame {
 
 static size_t tile_counts_bytes(const ffs_stream* s) { return (((size_t)s->max_batch * s->ctx->n_tiles + 1) * 4 + 255) / 256 * 256; }
 
+// Growable device (or pinned host) buffer of the 3D stack: reallocated with slack when too small
+template <typename T>
+struct PoolBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    bool pinned_host = false;
+    hipError_t ensure(size_t n, bool keep = false, hipStream_t st = nullptr) {
+        if (n <= cap) return hipSuccess;
+        const size_t want = std::max<size_t>(n + n / 2, 1024);
+        T* q = nullptr;
+        hipError_t e = pinned_host ? hipHostMalloc(reinterpret_cast<void**>(&q), want * sizeof(T), hipHostMallocDefault)
+                                   : hipMalloc(reinterpret_cast<void**>(&q), want * sizeof(T) + 256);
+        if (e != hipSuccess) return e;
+        if (keep && p && cap) {
+            e = hipMemcpyAsync(q, p, cap * sizeof(T), pinned_host ? hipMemcpyHostToHost : hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { pinned_host ? (void)hipHostFree(q) : (void)hipFree(q); return e; }
+        }
+        release();
+        p = q;
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) pinned_host ? (void)hipHostFree(p) : (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
 struct ffs_stack3d {
     ffs_ctx* ctx = nullptr;
     uint64_t max_total = 0;
+    hipStream_t st = nullptr;  // the stack's own stream
+    std::mutex mu;             // worker threads add their batches concurrently (the reference's rotation_slices_mutex)
+    // slices as they arrive: lists appended to the arrival buffers on the device
     struct Slice {
-        std::vector<uint32_t> k, inten;
+        uint32_t off = 0, n = 0;
     };
-    std::map<int64_t, Slice> slices;
+    std::map<int64_t, Slice> slices;  // frame id -> place in the arrival buffers (std::map order = z order, spotfinder.cc:1105-1108)
+    uint64_t arrived = 0;
+    PoolBuf<uint32_t> a_k, a_i;
+    PoolBuf<StackSlice> d_table, h_table;
+    // the stack in (z, k) order and the scratch of its labelling (sized in finish, kept for the next one)
+    PoolBuf<uint32_t> d_k, d_i, d_z, d_parent, d_comp, d_begin, d_chunk_roots, d_small, d_sx, d_sy, d_sc;
+    PoolBuf<CompAcc> d_acc;
+    PoolBuf<ReflOut> d_recs;
     std::vector<ffs_reflection> out;
     // per-signal view of the last finish (vertex order)
     std::vector<uint32_t> sig_x, sig_y, sig_i;
     std::vector<int32_t> sig_z, sig_refl;
-    // device scratch (allocated in finish)
+    float last_finish_ms = 0;
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -1648,49 +1708,138 @@ extern "C" int ffs_selftest_sqrt(ffs_ctx* c, uint64_t begin, uint64_t end, uint6
 
 // ---- 3D stack ------------------------------------------------------------------------------------------
 
-extern "C" int ffs_stack3d_create(ffs_ctx* c, uint64_t max_total, ffs_stack3d** out) {
-    if (!c || !out) return FFS_ERR_INVALID;
+static int stack3d_create_impl(ffs_ctx* c, uint64_t max_total, ffs_stack3d** out) {
     ffs_stack3d* st = new (std::nothrow) ffs_stack3d();
     if (!st) return FFS_ERR_NOMEM;
     st->ctx = c;
-    st->max_total = max_total ? max_total : (1ull << 26);
+    st->max_total = max_total ? max_total : (1ull << 30);
+    st->h_table.pinned_host = true;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipError_t e = hipStreamCreateWithFlags(&st->st, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        c->err = std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(e);
+        delete st;
+        return FFS_ERR_DEVICE;
+    }
     *out = st;
     return FFS_OK;
 }
 
-extern "C" void ffs_stack3d_destroy(ffs_stack3d* st) { delete st; }
+extern "C" int ffs_stack3d_create(ffs_ctx* c, uint64_t max_total, ffs_stack3d** out) {
+    if (!c || !out) return FFS_ERR_INVALID;
+    *out = nullptr;
+    return stack3d_create_impl(c, max_total, out);
+}
+
+extern "C" void ffs_stack3d_destroy(ffs_stack3d* st) {
+    if (!st) return;
+    (void)hipSetDevice(st->ctx->device);
+    if (st->st) (void)hipStreamSynchronize(st->st);
+    st->a_k.release(); st->a_i.release(); st->d_table.release(); st->h_table.release();
+    st->d_k.release(); st->d_i.release(); st->d_z.release(); st->d_parent.release(); st->d_comp.release();
+    st->d_begin.release(); st->d_chunk_roots.release(); st->d_small.release();
+    st->d_sx.release(); st->d_sy.release(); st->d_sc.release(); st->d_acc.release(); st->d_recs.release();
+    if (st->st) (void)hipStreamDestroy(st->st);
+    delete st;
+}
+
+#define STK_TRY(c, expr)                                                        \
+    do {                                                                        \
+        hipError_t e_ = (expr);                                                 \
+        if (e_ != hipSuccess) {                                                 \
+            (c)->err = std::string(#expr) + ": " + hipGetErrorString(e_);       \
+            return e_ == hipErrorOutOfMemory ? FFS_ERR_NOMEM : FFS_ERR_DEVICE;  \
+        }                                                                       \
+    } while (0)
+
+// room for `more` entries behind the ones that have arrived (the lists already there are kept)
+static int stack3d_reserve(ffs_stack3d* st, uint64_t more) {
+    ffs_ctx* c = st->ctx;
+    if (st->arrived + more > st->max_total || st->arrived + more >= (1ull << 32) - 1) {
+        c->err = "ffs_stack3d: too many strong pixels in the stack";
+        return FFS_ERR_OVERFLOW;
+    }
+    STK_TRY(c, st->a_k.ensure(st->arrived + more, true, st->st));
+    STK_TRY(c, st->a_i.ensure(st->arrived + more, true, st->st));
+    return FFS_OK;
+}
+
+static int stack3d_add_slice_impl(ffs_stack3d* st, int64_t frame_id, const uint32_t* k, const uint32_t* inten, uint32_t n) {
+    ffs_ctx* c = st->ctx;
+    std::lock_guard<std::mutex> lock(st->mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = stack3d_reserve(st, n);
+    if (rc != FFS_OK) return rc;
+    if (n) {
+        STK_TRY(c, hipMemcpyAsync(st->a_k.p + st->arrived, k, (size_t)n * 4, hipMemcpyHostToDevice, st->st));
+        STK_TRY(c, hipMemcpyAsync(st->a_i.p + st->arrived, inten, (size_t)n * 4, hipMemcpyHostToDevice, st->st));
+        STK_TRY(c, hipStreamSynchronize(st->st));  // the caller's arrays may go away
+    }
+    st->slices[frame_id] = ffs_stack3d::Slice{(uint32_t)st->arrived, n};  // (a frame added twice: the later list counts)
+    st->arrived += n;
+    return FFS_OK;
+}
 
 extern "C" int ffs_stack3d_add_slice(ffs_stack3d* st, int64_t frame_id, const uint32_t* k,
                                      const uint32_t* inten, uint32_t n) {
     if (!st || (n && (!k || !inten))) return FFS_ERR_INVALID;
-    auto& sl = st->slices[frame_id];
-    sl.k.assign(k, k + n);
-    sl.inten.assign(inten, inten + n);
-    return FFS_OK;
+    return guarded(st->ctx, [&] { return stack3d_add_slice_impl(st, frame_id, k, inten, n); });
 }
 
-extern "C" int ffs_stack3d_add_batch(ffs_stack3d* st, ffs_stream* s) {
-    if (!st || !s || s->ctx != st->ctx) return FFS_ERR_INVALID;
+// The lists of the stream's last batch go from its device buffers to the stack's, device to device.
+static int stack3d_add_batch_impl(ffs_stack3d* st, ffs_stream* s) {
     ffs_ctx* c = s->ctx;
     if (s->busy || s->results.empty()) {
         c->err = "ffs_stack3d_add_batch: call after ffs_wait()";
         return FFS_ERR_INVALID;
     }
+    std::lock_guard<std::mutex> lock(st->mu);
     HIP_TRY(c, hipSetDevice(c->device));
-    for (uint32_t f = 0; f < s->n_frames; ++f) {
-        const uint32_t n = s->results[f].num_strong_pixels;
-        auto& sl = st->slices[s->results[f].frame_id];
-        sl.k.resize(n);
-        sl.inten.resize(n);
-        if (n) {
-            HIP_TRY(c, hipMemcpyAsync(sl.k.data(), s->d_list_k + (size_t)f * s->cap, (size_t)n * 4,
-                                      hipMemcpyDeviceToHost, s->st2));
-            HIP_TRY(c, hipMemcpyAsync(sl.inten.data(), s->d_list_i + (size_t)f * s->cap, (size_t)n * 4,
-                                      hipMemcpyDeviceToHost, s->st2));
+    const uint32_t nf = s->n_frames;
+    uint64_t more = 0;
+    for (uint32_t f = 0; f < nf; ++f) more += s->results[f].num_strong_pixels;
+    int rc = stack3d_reserve(st, more);
+    if (rc != FFS_OK) return rc;
+    STK_TRY(c, st->h_table.ensure(nf));
+    STK_TRY(c, st->d_table.ensure(nf));
+    uint64_t at = st->arrived;
+    uint32_t biggest = 0;
+    for (uint32_t f = 0; f < nf; ++f) {
+        const ffs_frame_result& r = s->results[f];
+        const OverflowFrame* o = nullptr;
+        for (const OverflowFrame& q : s->ovf)
+            if (q.frame == f) o = &q;
+        const uint32_t n = r.num_strong_pixels;
+        // a frame that did not fit the stream's lists was re-run on its one-frame stream: its list is on the host
+        st->h_table.p[f] = StackSlice{0u, (uint32_t)at, o ? 0u : n, 0u};
+        if (o && n) {
+            if (o->k.size() != n) {  // (lists are only kept with want_strong_list)
+                c->err = "ffs_stack3d_add_batch: a frame overflowed the stream's lists; set want_strong_list (or a larger "
+                         "max_strong_per_frame) for rotation sweeps";
+                return FFS_ERR_OVERFLOW;
+            }
+            STK_TRY(c, hipMemcpyAsync(st->a_k.p + at, o->k.data(), (size_t)n * 4, hipMemcpyHostToDevice, st->st));
+            STK_TRY(c, hipMemcpyAsync(st->a_i.p + at, o->inten.data(), (size_t)n * 4, hipMemcpyHostToDevice, st->st));
         }
+        if (!o) biggest = std::max(biggest, n);
+        st->slices[r.frame_id] = ffs_stack3d::Slice{(uint32_t)at, n};
+        at += n;
     }
-    HIP_TRY(c, hipStreamSynchronize(s->st2));
+    if (biggest) {
+        STK_TRY(c, hipMemcpyAsync(st->d_table.p, st->h_table.p, (size_t)nf * sizeof(StackSlice), hipMemcpyHostToDevice, st->st));
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(k_stack_append, dim3(std::min<uint32_t>(64, (biggest + 255) / 256), nf), dim3(256), 0, st->st,
+                           s->d_list_k, s->d_list_i, (uint64_t)s->cap, st->d_table.p, st->a_k.p, st->a_i.p);
+        STK_TRY(c, hipGetLastError());
+    }
+    STK_TRY(c, hipStreamSynchronize(st->st));  // the stream's lists may be overwritten by its next batch
+    st->arrived = at;
     return FFS_OK;
+}
+
+extern "C" int ffs_stack3d_add_batch(ffs_stack3d* st, ffs_stream* s) {
+    if (!st || !s || s->ctx != st->ctx) return FFS_ERR_INVALID;
+    return guarded(st->ctx, [&] { return stack3d_add_batch_impl(st, s); });
 }
 
 extern "C" int ffs_stack3d_signals(ffs_stack3d* st, const uint32_t** x, const uint32_t** y, const int32_t** z,
@@ -1705,130 +1854,101 @@ extern "C" int ffs_stack3d_signals(ffs_stack3d* st, const uint32_t** x, const ui
     return FFS_OK;
 }
 
-extern "C" int ffs_stack3d_finish(ffs_stack3d* st, const ffs_reflection** reflections, uint32_t* n_refl,
-                                  uint32_t* n_calculated, uint32_t* n_f_size, uint32_t* n_f_sep) {
-    if (!st) return FFS_ERR_INVALID;
+static int stack3d_finish_impl(ffs_stack3d* st, const ffs_reflection** reflections, uint32_t* n_refl,
+                               uint32_t* n_calculated, uint32_t* n_f_size, uint32_t* n_f_sep) {
     ffs_ctx* c = st->ctx;
+    std::lock_guard<std::mutex> lock(st->mu);
     HIP_TRY(c, hipSetDevice(c->device));
     // z = rank of the frame id among the slices held (std::map order, spotfinder.cc:1105-1108)
     const int nz = (int)st->slices.size();
-    std::vector<uint32_t> begin(nz + 1, 0), hk, hi;
     uint64_t total = 0;
-    {
-        int z = 0;
-        for (auto& kv : st->slices) {
-            begin[z] = (uint32_t)total;
-            total += kv.second.k.size();
-            ++z;
-        }
-        begin[nz] = (uint32_t)total;
-    }
+    for (auto& kv : st->slices) total += kv.second.n;
     st->out.clear();
-    if (total >= (1ull << 32) - 1 || total > st->max_total) {
-        c->err = "ffs_stack3d_finish: too many strong pixels in the stack";
-        return FFS_ERR_OVERFLOW;
-    }
+    st->sig_x.clear(); st->sig_y.clear(); st->sig_z.clear(); st->sig_i.clear(); st->sig_refl.clear();
     uint32_t n_calc = 0, fs = 0, fp = 0;
     if (total > 0) {
-        hk.reserve(total);
-        hi.reserve(total);
-        for (auto& kv : st->slices) {
-            hk.insert(hk.end(), kv.second.k.begin(), kv.second.k.end());
-            hi.insert(hi.end(), kv.second.inten.begin(), kv.second.inten.end());
-        }
         const uint32_t N = (uint32_t)total;
-        uint32_t *d_k = nullptr, *d_i = nullptr, *d_par = nullptr, *d_cid = nullptr, *d_begin = nullptr;
-        uint32_t *d_n = nullptr, *d_nc = nullptr, *d_ovf = nullptr, *d_sum = nullptr;
-        CompAcc* d_acc = nullptr;
-        ReflOut* d_recs = nullptr;
-        std::vector<void*> to_free;
-        auto cleanup = [&]() {
-            for (void* p : to_free) (void)hipFree(p);
-        };
-#define ST_TRY(expr)                                                            \
-    do {                                                                        \
-        hipError_t e_ = (expr);                                                 \
-        if (e_ != hipSuccess) {                                                 \
-            c->err = std::string(#expr) + ": " + hipGetErrorString(e_);         \
-            cleanup();                                                          \
-            return e_ == hipErrorOutOfMemory ? FFS_ERR_NOMEM : FFS_ERR_DEVICE;  \
-        }                                                                       \
-    } while (0)
-#define ST_ALLOC(ptr, bytes)            \
-    ST_TRY(dmalloc(&ptr, (bytes)));     \
-    to_free.push_back(ptr)
-        ST_ALLOC(d_k, (size_t)N * 4);
-        ST_ALLOC(d_i, (size_t)N * 4);
-        ST_ALLOC(d_par, (size_t)N * 4);
-        ST_ALLOC(d_cid, (size_t)N * 4);
-        ST_ALLOC(d_begin, (size_t)(nz + 1) * 4);
-        ST_ALLOC(d_n, 4);
-        ST_ALLOC(d_nc, 4);
-        ST_ALLOC(d_ovf, 4);
-        ST_ALLOC(d_sum, 32);
-        ST_ALLOC(d_acc, (size_t)N * sizeof(CompAcc));
-        ST_ALLOC(d_recs, (size_t)N * sizeof(ReflOut));
-        std::vector<uint32_t> iota(N);
-        for (uint32_t i = 0; i < N; ++i) iota[i] = i;
-        ST_TRY(hipMemcpy(d_k, hk.data(), (size_t)N * 4, hipMemcpyHostToDevice));
-        ST_TRY(hipMemcpy(d_i, hi.data(), (size_t)N * 4, hipMemcpyHostToDevice));
-        ST_TRY(hipMemcpy(d_par, iota.data(), (size_t)N * 4, hipMemcpyHostToDevice));
-        ST_TRY(hipMemcpy(d_begin, begin.data(), (size_t)(nz + 1) * 4, hipMemcpyHostToDevice));
-        ST_TRY(hipMemcpy(d_n, &N, 4, hipMemcpyHostToDevice));
-        ST_TRY(hipMemset(d_ovf, 0, 4));
-        SegArgs sa{};
-        sa.list_k = d_k;
-        sa.list_i = d_i;
-        sa.parent = d_par;
-        sa.comp_id = d_cid;
-        sa.seg_n = d_n;
-        sa.seg_stride = N;
-        sa.n_comp = d_nc;
-        sa.acc = d_acc;
-        sa.max_comp = N;
-        sa.overflow = d_ovf;
-        sa.W = (uint32_t)c->L.W;
-        sa.H = (uint32_t)c->L.H;
-        sa.row_off = nullptr;
-        sa.slice_begin = d_begin;
-        sa.n_slices = nz;
-        sa.min_spot_size = c->params.min_spot_size_3d;
-        sa.max_sep = c->params.max_peak_centroid_separation;
-        sa.recs = d_recs;
-        sa.summary = d_sum;
-        const unsigned nb = (unsigned)std::min<uint64_t>(2048, ((uint64_t)N + 255) / 256);
-        hipLaunchKernelGGL(k_union<true>, dim3(nb, 1), dim3(256), 0, 0, sa);
-        hipLaunchKernelGGL(k_label, dim3(1), dim3(1024), 0, 0, sa);
-        hipLaunchKernelGGL(k_reduce<true>, dim3(nb, 1), dim3(256), 0, 0, sa);
-        hipLaunchKernelGGL(k_finalize<true>, dim3(nb, 1), dim3(256), 0, 0, sa);
-        ST_TRY(hipGetLastError());
-        ST_TRY(hipDeviceSynchronize());
-        ST_TRY(hipMemcpy(&n_calc, d_nc, 4, hipMemcpyDeviceToHost));
-        std::vector<ReflOut> recs(n_calc);
-        if (n_calc) ST_TRY(hipMemcpy(recs.data(), d_recs, (size_t)n_calc * sizeof(ReflOut), hipMemcpyDeviceToHost));
-        std::vector<uint32_t> h_par(N), h_cid(N);
-        ST_TRY(hipMemcpy(h_par.data(), d_par, (size_t)N * 4, hipMemcpyDeviceToHost));
-        ST_TRY(hipMemcpy(h_cid.data(), d_cid, (size_t)N * 4, hipMemcpyDeviceToHost));
-        cleanup();
-        // signal -> component: parents always point to a smaller index (union by minimum), so one
-        // ascending sweep resolves every root
-        st->sig_refl.assign(N, -1);
-        for (uint32_t i = 0; i < N; ++i) {
-            if (h_par[i] != i) h_par[i] = h_par[h_par[i]];  // root of the parent is final already
-            st->sig_refl[i] = (int32_t)h_cid[h_par[i]];      // component number (label order), remapped below
-        }
-        st->sig_x.resize(N);
-        st->sig_y.resize(N);
-        st->sig_z.resize(N);
-        st->sig_i = hi;
-        for (int z = 0; z < nz; ++z)
-            for (uint32_t e = begin[z]; e < begin[z + 1]; ++e) {
-                st->sig_x[e] = hk[e] % (uint32_t)c->L.W;
-                st->sig_y[e] = hk[e] / (uint32_t)c->L.W;
-                st->sig_z[e] = z;
+        const uint32_t chunks = (N + kRootChunk - 1) / kRootChunk;
+        STK_TRY(c, st->h_table.ensure(nz));
+        STK_TRY(c, st->d_table.ensure(nz));
+        STK_TRY(c, st->d_begin.ensure((size_t)nz + 1));
+        STK_TRY(c, st->d_k.ensure(N)); STK_TRY(c, st->d_i.ensure(N)); STK_TRY(c, st->d_z.ensure(N));
+        STK_TRY(c, st->d_parent.ensure(N)); STK_TRY(c, st->d_comp.ensure(N));
+        STK_TRY(c, st->d_acc.ensure(N)); STK_TRY(c, st->d_recs.ensure(N));
+        STK_TRY(c, st->d_chunk_roots.ensure(chunks));
+        STK_TRY(c, st->d_small.ensure(16));  // [0] n, [1] n_comp, [2] status, [8..15] summary
+        STK_TRY(c, st->d_sx.ensure(N)); STK_TRY(c, st->d_sy.ensure(N)); STK_TRY(c, st->d_sc.ensure(N));
+        std::vector<uint32_t> begin(nz + 1, 0);
+        {
+            int z = 0;
+            uint32_t at = 0, biggest = 0;
+            for (auto& kv : st->slices) {
+                begin[z] = at;
+                st->h_table.p[z] = StackSlice{kv.second.off, at, kv.second.n, (uint32_t)z};
+                biggest = std::max(biggest, kv.second.n);
+                at += kv.second.n;
+                ++z;
             }
-#undef ST_TRY
-#undef ST_ALLOC
+            begin[nz] = at;
+            hipEvent_t e0, e1;
+            STK_TRY(c, hipEventCreate(&e0));
+            STK_TRY(c, hipEventCreate(&e1));
+            const uint32_t small[16] = {N, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            (void)hipEventRecord(e0, st->st);
+            STK_TRY(c, hipMemcpyAsync(st->d_table.p, st->h_table.p, (size_t)nz * sizeof(StackSlice), hipMemcpyHostToDevice, st->st));
+            STK_TRY(c, hipMemcpyAsync(st->d_begin.p, begin.data(), (size_t)(nz + 1) * 4, hipMemcpyHostToDevice, st->st));
+            STK_TRY(c, hipMemcpyAsync(st->d_small.p, small, sizeof(small), hipMemcpyHostToDevice, st->st));
+            SegArgs sa{};
+            sa.list_k = st->d_k.p;
+            sa.list_i = st->d_i.p;
+            sa.parent = st->d_parent.p;
+            sa.comp_id = st->d_comp.p;
+            sa.seg_n = st->d_small.p;
+            sa.seg_stride = N;
+            sa.n_comp = st->d_small.p + 1;
+            sa.acc = st->d_acc.p;
+            sa.max_comp = N;
+            sa.overflow = st->d_small.p + 2;
+            sa.W = (uint32_t)c->L.W;
+            sa.H = (uint32_t)c->L.H;
+            sa.row_off = nullptr;
+            sa.slice_begin = st->d_begin.p;
+            sa.n_slices = nz;
+            sa.zs = st->d_z.p;
+            sa.min_spot_size = c->params.min_spot_size_3d;
+            sa.max_sep = c->params.max_peak_centroid_separation;
+            sa.recs = st->d_recs.p;
+            sa.summary = st->d_small.p + 8;
+            sa.chunk_roots = st->d_chunk_roots.p;
+            sa.chunks_max = chunks;
+            (void)hipGetLastError();
+            const unsigned nb = (unsigned)std::min<uint64_t>(4096, ((uint64_t)N + 255) / 256);
+            hipLaunchKernelGGL(k_stack_gather, dim3(std::min<uint32_t>(64, (biggest + 255) / 256), nz), dim3(256), 0, st->st,
+                               st->a_k.p, st->a_i.p, st->d_table.p, st->d_k.p, st->d_i.p, st->d_z.p, st->d_parent.p, st->d_acc.p);
+            hipLaunchKernelGGL(k_union<true>, dim3(nb, 1), dim3(256), 0, st->st, sa);
+            hipLaunchKernelGGL(k_reduce_roots3d, dim3(std::min<unsigned>(chunks, 2048u)), dim3(256), 0, st->st, sa);
+            hipLaunchKernelGGL(k_finalize_roots3d, dim3(std::min<unsigned>(chunks, 1024u)), dim3(256), 0, st->st, sa);
+            hipLaunchKernelGGL(k_stack_labels, dim3(nb), dim3(256), 0, st->st, sa, st->d_sx.p, st->d_sy.p, st->d_sc.p);
+            STK_TRY(c, hipGetLastError());
+            uint32_t back[16];
+            STK_TRY(c, hipMemcpyAsync(back, st->d_small.p, sizeof(back), hipMemcpyDeviceToHost, st->st));
+            (void)hipEventRecord(e1, st->st);
+            STK_TRY(c, hipStreamSynchronize(st->st));
+            (void)hipEventElapsedTime(&st->last_finish_ms, e0, e1);
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            n_calc = back[1];
+        }
+        std::vector<ReflOut> recs(n_calc);
+        if (n_calc) STK_TRY(c, hipMemcpyAsync(recs.data(), st->d_recs.p, (size_t)n_calc * sizeof(ReflOut), hipMemcpyDeviceToHost, st->st));
+        std::vector<uint32_t> comp(N), zs(N);
+        st->sig_x.resize(N); st->sig_y.resize(N); st->sig_i.resize(N);
+        STK_TRY(c, hipMemcpyAsync(st->sig_x.data(), st->d_sx.p, (size_t)N * 4, hipMemcpyDeviceToHost, st->st));
+        STK_TRY(c, hipMemcpyAsync(st->sig_y.data(), st->d_sy.p, (size_t)N * 4, hipMemcpyDeviceToHost, st->st));
+        STK_TRY(c, hipMemcpyAsync(st->sig_i.data(), st->d_i.p, (size_t)N * 4, hipMemcpyDeviceToHost, st->st));
+        STK_TRY(c, hipMemcpyAsync(comp.data(), st->d_sc.p, (size_t)N * 4, hipMemcpyDeviceToHost, st->st));
+        STK_TRY(c, hipMemcpyAsync(zs.data(), st->d_z.p, (size_t)N * 4, hipMemcpyDeviceToHost, st->st));
+        STK_TRY(c, hipStreamSynchronize(st->st));
         std::vector<int32_t> kept_index(n_calc, -1);
         for (uint32_t q = 0; q < n_calc; ++q) {
             const ReflOut& r = recs[q];
@@ -1841,9 +1961,12 @@ extern "C" int ffs_stack3d_finish(ffs_stack3d* st, const ffs_reflection** reflec
                 st->out.push_back(o);
             }
         }
-        for (auto& l : st->sig_refl) l = (l >= 0 && (uint32_t)l < n_calc) ? kept_index[l] : -1;
-    } else {
-        st->sig_x.clear(); st->sig_y.clear(); st->sig_z.clear(); st->sig_i.clear(); st->sig_refl.clear();
+        st->sig_z.resize(N);
+        st->sig_refl.resize(N);
+        for (uint32_t i = 0; i < N; ++i) {
+            st->sig_z[i] = (int32_t)zs[i];
+            st->sig_refl[i] = comp[i] < n_calc ? kept_index[comp[i]] : -1;
+        }
     }
     if (reflections) *reflections = st->out.data();
     if (n_refl) *n_refl = (uint32_t)st->out.size();
@@ -1853,24 +1976,7 @@ extern "C" int ffs_stack3d_finish(ffs_stack3d* st, const ffs_reflection** reflec
     return FFS_OK;
 }
 
-// ---- no exception crosses the C ABI -----------------------------------------------------------------------
-// The entry points that grow std::vectors (results, staging tables, masks) run inside a catch-all: an
-// allocation failure or a length error becomes FFS_ERR_NOMEM with its text in ffs_last_error, instead of
-// std::terminate -> abort() in the caller's process.
-template <typename F>
-static int guarded(ffs_ctx* c, F&& body) {
-    try {
-        return body();
-    } catch (const std::exception& e) {
-        if (c) c->err = std::string("exception inside libffs_hip: ") + e.what();
-        else g_create_error = std::string("exception inside libffs_hip: ") + e.what();
-        return FFS_ERR_NOMEM;
-    } catch (...) {
-        if (c) c->err = "unknown exception inside libffs_hip";
-        return FFS_ERR_NOMEM;
-    }
-}
-
+// ---- guarded entry points (see `guarded` near the top) -------------------------------------------------------
 extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_results) {
     return guarded(s ? s->ctx : nullptr, [&] { return ffs_wait_impl(s, results, n_results); });
 }
@@ -1883,4 +1989,14 @@ extern "C" int ffs_ctx_set_mask(ffs_ctx* c, const uint8_t* host_mask) {
 }
 extern "C" int ffs_ctx_get_mask(ffs_ctx* c, uint8_t* host_mask) {
     return guarded(c, [&] { return ffs_ctx_get_mask_impl(c, host_mask); });
+}
+extern "C" int ffs_stack3d_finish(ffs_stack3d* st, const ffs_reflection** reflections, uint32_t* n_refl,
+                                  uint32_t* n_calculated, uint32_t* n_f_size, uint32_t* n_f_sep) {
+    if (!st) return FFS_ERR_INVALID;
+    return guarded(st->ctx, [&] { return stack3d_finish_impl(st, reflections, n_refl, n_calculated, n_f_size, n_f_sep); });
+}
+extern "C" int ffs_stack3d_last_finish_ms(const ffs_stack3d* st, float* ms) {
+    if (!st || !ms) return FFS_ERR_INVALID;
+    *ms = st->last_finish_ms;
+    return FFS_OK;
 }

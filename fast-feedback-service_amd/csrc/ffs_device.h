@@ -162,6 +162,7 @@ struct SegArgs {
     // 3D only
     const uint32_t* slice_begin;  // [n_slices + 1] entry offsets of each slice inside the segment
     int n_slices;
+    const uint32_t* zs;           // slice of every entry (k_stack_gather), or null
     // finalize
     uint32_t min_spot_size;
     float max_sep;

@@ -7,7 +7,6 @@
 //                                (popcount + wave/block prefix sums; no sort needed)
 //   k_union                    : lock-free union-find, union-by-minimum-index (atomicMin hooks),
 //                                neighbours found by binary search in the sorted list
-//   k_flatten, k_label         : roots, component numbers in order of minimum vertex
 //   k_reduce                   : per-component bbox / sums / peak with integer atomics
 //   k_finalize                 : centre of mass, peak-centroid distance, filters
 // The same kernels serve the 3D case (a z-stack of per-frame lists, one extra edge to the same
@@ -340,6 +339,7 @@ __global__ __launch_bounds__(256) void k_union(const SegArgs a) {
         uint32_t s_end = n, nb = 0, ne = 0;
         if (IS3D) {
             // slice of entry i (slices ascending; advance monotonically within this thread)
+            if (a.zs) z = a.zs[i];
             while (a.slice_begin[z + 1] <= i) ++z;
             s_end = a.slice_begin[z + 1];
             if ((int)z + 1 < a.n_slices) { nb = a.slice_begin[z + 1]; ne = a.slice_begin[z + 2]; }
@@ -385,54 +385,6 @@ __global__ __launch_bounds__(256) void k_union(const SegArgs a) {
 }
 template __global__ void k_union<false>(const SegArgs);
 template __global__ void k_union<true>(const SegArgs);
-
-__global__ __launch_bounds__(256) void k_flatten(const SegArgs a) {
-    const int seg = blockIdx.y;
-    const uint32_t n = min(a.seg_n[seg], (uint32_t)a.seg_stride);
-    uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const uint32_t r = uf_find(parent, i);
-        if (r != i) __hip_atomic_store(parent + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// One block per segment: number the roots in ascending order and reset their accumulators.
-__global__ __launch_bounds__(1024) void k_label(const SegArgs a) {
-    __shared__ uint32_t s_wave[16];
-    const int seg = blockIdx.x;
-    const uint32_t n = min(a.seg_n[seg], (uint32_t)a.seg_stride);
-    const uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
-    uint32_t* comp_id = a.comp_id + (uint64_t)seg * a.seg_stride;
-    CompAcc* acc = a.acc + (uint64_t)seg * a.max_comp;
-    const uint32_t per = (n + 1023u) / 1024u;
-    const uint32_t b0 = min(threadIdx.x * per, n), b1 = min(b0 + per, n);
-    uint32_t mine = 0;
-    for (uint32_t i = b0; i < b1; ++i) mine += parent[i] == i ? 1u : 0u;
-    uint32_t running;
-    uint32_t c = block_exclusive_scan<1024>(mine, s_wave, running);
-    for (uint32_t i = b0; i < b1; ++i) {
-        if (parent[i] != i) continue;
-        comp_id[i] = c;
-        if (c < a.max_comp) {
-            CompAcc z;
-            z.sum_i = z.sum_xi = z.sum_yi = z.sum_zi = 0ull;
-            z.peak = 0ull;
-            z.x_min = 0xFFFFFFFFu; z.x_max = 0u;
-            z.y_min = 0xFFFFFFFFu; z.y_max = 0u;
-            z.z_min = 0x7FFFFFFF; z.z_max = (int32_t)0x80000000;
-            z.num_pixels = 0u;
-            z.root = i;
-            acc[c] = z;
-        }
-        ++c;
-    }
-    if (threadIdx.x == 0) {
-        a.n_comp[seg] = running;
-        if (running > a.max_comp) atomicOr(a.overflow, 2u);
-        uint32_t* sm = a.summary + (uint64_t)seg * 8;
-        for (int q = 0; q < 8; ++q) sm[q] = 0;
-    }
-}
 
 // The same numbering with several workgroups per segment (2D batches: a frame's list can hold 10^5
 // entries, and one workgroup walking it was 24-85 us): kLabelParts parts per segment, k_count_roots
@@ -653,7 +605,6 @@ __global__ __launch_bounds__(256) void k_reduce(const SegArgs a) {
     }
 }
 template __global__ void k_reduce<false>(const SegArgs);
-template __global__ void k_reduce<true>(const SegArgs);
 
 
 // ---- 2D: reduction with the accumulators at the root (no numbering pass) ---------------------------------
@@ -937,6 +888,5 @@ __global__ __launch_bounds__(256) void k_finalize(const SegArgs a) {
     }
 }
 template __global__ void k_finalize<false>(const SegArgs);
-template __global__ void k_finalize<true>(const SegArgs);
 
 }  // namespace ffsamd

@@ -75,7 +75,7 @@ EXPORTS = [
     "ffs_stream_create", "ffs_stream_destroy", "ffs_stream_host_buffer", "ffs_submit",
     "ffs_submit_device", "ffs_ctx_device_layout", "ffs_wait", "ffs_stream_batch_arrays", "ffs_stream_timings",
     "ffs_submit_compressed", "ffs_decode_only", "ffs_stream_spot_centres", "ffs_bench_threshold", "ffs_bench_hbm", "ffs_stream_debug_planes", "ffs_stream_debug_bitplane", "ffs_selftest_sqrt", "ffs_stack3d_create",
-    "ffs_stack3d_destroy", "ffs_stack3d_add_batch", "ffs_stack3d_add_slice", "ffs_stack3d_finish", "ffs_stack3d_signals",
+    "ffs_stack3d_destroy", "ffs_stack3d_add_batch", "ffs_stack3d_add_slice", "ffs_stack3d_finish", "ffs_stack3d_signals", "ffs_stack3d_last_finish_ms",
 ]
 
 _lib = None
@@ -434,6 +434,11 @@ class Stack3D:
         self.ctx._check(self._lib.ffs_stack3d_finish(self._h, C.byref(r), C.byref(n), C.byref(nc),
                                                      C.byref(fs), C.byref(fp)))
         return _copy_array(r, n.value, _Refl, REFL_DT), nc.value, fs.value, fp.value
+
+    def last_finish_ms(self) -> float:
+        ms = C.c_float()
+        self.ctx._check(self._lib.ffs_stack3d_last_finish_ms(self._h, C.byref(ms)))
+        return ms.value
 
     def signals(self):
         """Per-signal view of the last finish(): dict of x, y, z, intensity, reflection (-1 = filtered)."""

@@ -252,6 +252,8 @@ int ffs_stack3d_add_slice(ffs_stack3d *st, int64_t frame_id, const uint32_t *k,
 int ffs_stack3d_finish(ffs_stack3d *st, const ffs_reflection **reflections,
                        uint32_t *n_reflections, uint32_t *n_calculated,
                        uint32_t *n_filtered_size, uint32_t *n_filtered_sep);
+/* Device time of the last ffs_stack3d_finish (upload of the slice table to the labels of every strong pixel), ms. */
+int ffs_stack3d_last_finish_ms(const ffs_stack3d *st, float *ms);
 /* Per-signal view of the last ffs_stack3d_finish: every strong pixel of the stack in the reference's
  * vertex order (slice by slice, ascending linear index -- the order Reflection3D::signals_ is filled
  * in, connected_components.cc:409-446) with the index of its reflection in the array finish

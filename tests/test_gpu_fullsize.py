@@ -96,3 +96,46 @@ def test_sweep_3d_eiger_slab(ffs):
     assert (n_calc, fs, fp) == (want.n_calculated, want.n_filtered_size, want.n_filtered_sep)
     assert_reflections_equal(refl, want.reflections)
     assert len(refl) > 20
+
+
+def test_sweep_3d_eiger_100_frames(ffs):
+    """configs[4] at its stated size: a 100-frame Eiger-16M fine-phi sweep, 800 reflections with a rocking
+    curve, `--min-spot-size 3 --min-spot-size-3d 15` (the shape of the reference's
+    tests/3d_connected_components.sh:27-37), through the batch path, the device-resident 3D stack and its
+    finish; checked against the oracle's 3D labelling, three frames' strong lists against the oracle's
+    dispersion + 2D labelling."""
+    from ffs_amd import synth
+    from oracle import oracle as O
+    from util import assert_reflections_equal, assert_frame_matches_oracle
+    NZ, B = 100, 25
+    p = synth.sweep_params(seed=5000, n_frames=NZ, n_spots=800)
+    mask = synth.mask_eiger16m()
+    ctx = ffs.Context(4148, 4362, np.uint16, max_batch=B)
+    ctx.set_mask(mask)
+    ctx.set_params(want_strong_list=1, min_spot_size=3, min_spot_size_3d=15)
+    st = ctx.stream()
+    stack = ffs.Stack3D(ctx)
+    slices = []
+    for z0 in range(0, NZ, B):
+        frames = synth.frames(p, range(z0, z0 + B), threads=16)
+        res = st.process(frames, first_frame_id=z0)
+        stack.add_batch(st)
+        slices += [(r.strong_k.copy(), r.strong_intensity.copy()) for r in res]
+        if z0 == 50:
+            for j in (0, 11, 24):
+                assert_frame_matches_oracle(res[j], frames[j], mask)
+        del frames
+    refl, n_calc, fs, fp = stack.finish()
+    assert stack.last_finish_ms() > 0
+    want = O.cc3d(slices, 4148, 4362, 15, 2.0)
+    assert (n_calc, fs, fp) == (want.n_calculated, want.n_filtered_size, want.n_filtered_sep)
+    assert_reflections_equal(refl, want.reflections)
+    assert len(refl) > 300 and (refl["z_max"] - refl["z_min"]).max() >= 3
+    sig = stack.signals()
+    want_sig = O.cc3d_signals(slices, 4148, 4362, 15, 2.0)
+    assert np.array_equal(sig["reflection"], want_sig)
+    assert np.array_equal(sig["z"], np.concatenate([np.full(len(k), z) for z, (k, _) in enumerate(slices)]))
+    # a second finish on the same stack gives the same answer (pooled buffers, nothing consumed)
+    refl2, n_calc2, _, _ = stack.finish()
+    assert n_calc2 == n_calc
+    assert_reflections_equal(refl2, want.reflections)
