@@ -15,6 +15,9 @@
 #include <atomic>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is loaded with dlopen when several devices are in use
+
 #include "ffs_hip.h"
 #include "kernels_ccl.hpp"
 #include "kernels_threshold.hpp"
@@ -104,6 +107,8 @@ struct ffs_stream {
     ffs_stream* big = nullptr;               // one-frame stream with room for frames that exceed cap / max_comp
     std::vector<OverflowFrame> ovf;          // such frames of the last batch, re-run on `big`
     int force_variant = -1;                  // >= 0: threshold variant of the next enqueue (bright-list overflow -> 1)
+    uint32_t *d_pack_k = nullptr, *d_pack_i = nullptr;  // a batch's lists packed end to end for another device's 3D stack
+    StackSlice *d_pack_tab = nullptr, *h_pack_tab = nullptr;
     hipStream_t st = nullptr;    // threshold kernels (+ H2D)
     hipStream_t st2 = nullptr;   // compaction + connected components + D2H; == st unless the CUs are split
     hipEvent_t ev[6] = {};
@@ -468,7 +473,8 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     if (s->st) (void)hipStreamSynchronize(s->st);
     if (s->st2 && s->st2 != s->st) { (void)hipStreamSynchronize(s->st2); (void)hipStreamDestroy(s->st2); }
     // (d_n_comp, d_summary and d_overflow live inside the d_num_strong allocation)
-    void* dev[] = {s->d_acc2, s->d_chunk_roots, s->d_bright, s->d_comp, s->d_tab, s->d_dplane, s->d_eplane, s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_num_strong,
+    if (s->h_pack_tab) (void)hipHostFree(s->h_pack_tab);
+    void* dev[] = {s->d_pack_k, s->d_pack_i, s->d_pack_tab, s->d_acc2, s->d_chunk_roots, s->d_bright, s->d_comp, s->d_tab, s->d_dplane, s->d_eplane, s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_num_strong,
                    s->d_list_k, s->d_list_i, s->d_parent, s->d_comp_id, s->d_part_roots, s->d_acc, s->d_recs};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -1786,6 +1792,154 @@ extern "C" int ffs_stack3d_add_slice(ffs_stack3d* st, int64_t frame_id, const ui
     return guarded(st->ctx, [&] { return stack3d_add_slice_impl(st, frame_id, k, inten, n); });
 }
 
+// ---- several GPUs in one process: the exchange step of rotation sweeps ---------------------------------------
+// Frames are independent, so a driver with one context per GPU needs no collective for stills.  A rotation
+// sweep does have one exchange: every frame's strong-pixel list has to reach the GPU that owns the 3D stack.
+// Transport between two different devices: RCCL point-to-point (ncclSend / ncclRecv inside one group, over
+// xGMI) when librccl can be loaded and ffs_multi_init() built the communicators, else hipMemcpyPeerAsync.
+// The reference has nothing to compare with: one process, one device (src/ffs/cuda_arg_parser.cc:56-61).
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static std::mutex g_multi_mu;
+static RcclApi g_rccl;
+static std::vector<int> g_comm_devices;     // distinct devices, rank = position
+static std::vector<ncclComm_t> g_comms;     // one communicator per rank (ncclCommInitAll)
+static std::string g_multi_transport = "none";
+
+static int comm_rank_of(int device) {
+    for (size_t r = 0; r < g_comm_devices.size(); ++r)
+        if (g_comm_devices[r] == device) return (int)r;
+    return -1;
+}
+
+extern "C" int ffs_multi_init(const int* devices, int n_devices, const char* transport) {
+    if (!devices || n_devices <= 0) return FFS_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(g_multi_mu);
+    std::vector<int> distinct;
+    for (int i = 0; i < n_devices; ++i)
+        if (std::find(distinct.begin(), distinct.end(), devices[i]) == distinct.end()) distinct.push_back(devices[i]);
+    const std::string want = transport ? transport : (std::getenv("FFS_GATHER") ? std::getenv("FFS_GATHER") : "rccl");
+    if (!g_comms.empty() && distinct == g_comm_devices) return FFS_OK;
+    if (!g_comms.empty() && g_rccl.CommDestroy) {
+        for (ncclComm_t cm : g_comms) (void)g_rccl.CommDestroy(cm);
+        g_comms.clear();
+    }
+    g_comm_devices = distinct;
+    g_multi_transport = distinct.size() > 1 ? "peer" : "none";
+    if (want != "rccl") return FFS_OK;
+    if (!g_rccl.lib) {
+        g_rccl.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!g_rccl.lib) g_rccl.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (g_rccl.lib) {
+            g_rccl.CommInitAll = reinterpret_cast<decltype(g_rccl.CommInitAll)>(dlsym(g_rccl.lib, "ncclCommInitAll"));
+            g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(g_rccl.lib, "ncclCommDestroy"));
+            g_rccl.GroupStart = reinterpret_cast<decltype(g_rccl.GroupStart)>(dlsym(g_rccl.lib, "ncclGroupStart"));
+            g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(dlsym(g_rccl.lib, "ncclGroupEnd"));
+            g_rccl.Send = reinterpret_cast<decltype(g_rccl.Send)>(dlsym(g_rccl.lib, "ncclSend"));
+            g_rccl.Recv = reinterpret_cast<decltype(g_rccl.Recv)>(dlsym(g_rccl.lib, "ncclRecv"));
+            g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(g_rccl.lib, "ncclGetErrorString"));
+        }
+    }
+    if (!g_rccl.lib || !g_rccl.CommInitAll || !g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)
+        return FFS_OK;  // no RCCL here: peer copies
+    g_comms.assign(distinct.size(), nullptr);
+    const ncclResult_t r = g_rccl.CommInitAll(g_comms.data(), (int)distinct.size(), distinct.data());
+    if (r != ncclSuccess) {
+        g_comms.clear();
+        g_create_error = std::string("ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "failed");
+        return FFS_OK;  // still usable through peer copies; ffs_multi_transport() tells which
+    }
+    g_multi_transport = "rccl";
+    return FFS_OK;
+}
+
+extern "C" const char* ffs_multi_transport(void) {
+    std::lock_guard<std::mutex> lock(g_multi_mu);
+    return g_multi_transport.c_str();
+}
+
+// Lists of a batch processed on ANOTHER context (same detector geometry, usually another GPU) into this stack:
+// packed end to end on the source device, then one transfer per array.
+static int stack3d_add_batch_remote(ffs_stack3d* st, ffs_stream* s, uint64_t more, uint32_t biggest) {
+    ffs_ctx* c = st->ctx;       // home
+    ffs_ctx* sc = s->ctx;       // source
+    const uint32_t nf = s->n_frames;
+    // source side: pack buffers and table (offsets from 0), on the source stream
+    HIP_TRY(c, hipSetDevice(sc->device));
+    if (!s->d_pack_k) {
+        const size_t cap_all = (size_t)s->max_batch * s->cap;
+        if (dmalloc(&s->d_pack_k, cap_all * 4) != hipSuccess || dmalloc(&s->d_pack_i, cap_all * 4) != hipSuccess
+            || dmalloc(&s->d_pack_tab, (size_t)s->max_batch * sizeof(StackSlice)) != hipSuccess
+            || hipHostMalloc(reinterpret_cast<void**>(&s->h_pack_tab), (size_t)s->max_batch * sizeof(StackSlice), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            c->err = "allocation of the list pack buffers failed";
+            return FFS_ERR_NOMEM;
+        }
+    }
+    uint32_t at = 0;
+    for (uint32_t f = 0; f < nf; ++f) {
+        const uint32_t n = s->results[f].num_strong_pixels;
+        s->h_pack_tab[f] = StackSlice{0u, at, n, 0u};
+        at += n;
+    }
+    if (biggest) {
+        STK_TRY(c, hipMemcpyAsync(s->d_pack_tab, s->h_pack_tab, (size_t)nf * sizeof(StackSlice), hipMemcpyHostToDevice, s->st2));
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(k_stack_append, dim3(std::min<uint32_t>(64, (biggest + 255) / 256), nf), dim3(256), 0, s->st2,
+                           s->d_list_k, s->d_list_i, (uint64_t)s->cap, s->d_pack_tab, s->d_pack_k, s->d_pack_i);
+        STK_TRY(c, hipGetLastError());
+    }
+    uint32_t* dst_k = st->a_k.p + st->arrived;
+    uint32_t* dst_i = st->a_i.p + st->arrived;
+    std::lock_guard<std::mutex> lock(g_multi_mu);
+    const int r_src = comm_rank_of(sc->device), r_home = comm_rank_of(c->device);
+    const char* forced = std::getenv("FFS_GATHER");
+    const bool use_rccl = !g_comms.empty() && r_src >= 0 && r_home >= 0 && !(forced && std::string(forced) != "rccl")
+                          && (sc->device != c->device || (forced && std::string(forced) == "rccl"));
+    if (more == 0) {
+        STK_TRY(c, hipStreamSynchronize(s->st2));
+        return FFS_OK;
+    }
+    if (use_rccl) {
+        // one group: the source rank sends on its stream, the home rank receives on the stack's stream
+        ncclResult_t r = g_rccl.GroupStart();
+        if (r == ncclSuccess) r = g_rccl.Send(s->d_pack_k, more, ncclUint32, r_home, g_comms[r_src], s->st2);
+        if (r == ncclSuccess) r = g_rccl.Recv(dst_k, more, ncclUint32, r_src, g_comms[r_home], st->st);
+        if (r == ncclSuccess) r = g_rccl.Send(s->d_pack_i, more, ncclUint32, r_home, g_comms[r_src], s->st2);
+        if (r == ncclSuccess) r = g_rccl.Recv(dst_i, more, ncclUint32, r_src, g_comms[r_home], st->st);
+        const ncclResult_t re = g_rccl.GroupEnd();
+        if (r == ncclSuccess) r = re;
+        if (r != ncclSuccess) {
+            c->err = std::string("RCCL send/recv of the strong-pixel lists: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "failed");
+            return FFS_ERR_DEVICE;
+        }
+        STK_TRY(c, hipStreamSynchronize(s->st2));
+        HIP_TRY(c, hipSetDevice(c->device));
+        STK_TRY(c, hipStreamSynchronize(st->st));
+        return FFS_OK;
+    }
+    // peer copy (or plain device-to-device when both contexts sit on one GPU): after the pack has finished
+    STK_TRY(c, hipStreamSynchronize(s->st2));
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (sc->device == c->device) {
+        STK_TRY(c, hipMemcpyAsync(dst_k, s->d_pack_k, more * 4, hipMemcpyDeviceToDevice, st->st));
+        STK_TRY(c, hipMemcpyAsync(dst_i, s->d_pack_i, more * 4, hipMemcpyDeviceToDevice, st->st));
+    } else {
+        STK_TRY(c, hipMemcpyPeerAsync(dst_k, c->device, s->d_pack_k, sc->device, more * 4, st->st));
+        STK_TRY(c, hipMemcpyPeerAsync(dst_i, c->device, s->d_pack_i, sc->device, more * 4, st->st));
+    }
+    STK_TRY(c, hipStreamSynchronize(st->st));
+    return FFS_OK;
+}
+
 // The lists of the stream's last batch go from its device buffers to the stack's, device to device.
 static int stack3d_add_batch_impl(ffs_stack3d* st, ffs_stream* s) {
     ffs_ctx* c = s->ctx;
@@ -1794,10 +1948,38 @@ static int stack3d_add_batch_impl(ffs_stack3d* st, ffs_stream* s) {
         return FFS_ERR_INVALID;
     }
     std::lock_guard<std::mutex> lock(st->mu);
-    HIP_TRY(c, hipSetDevice(c->device));
     const uint32_t nf = s->n_frames;
     uint64_t more = 0;
     for (uint32_t f = 0; f < nf; ++f) more += s->results[f].num_strong_pixels;
+    if (s->ctx != st->ctx) {
+        // a batch from another context: same detector, another GPU (or another context on this one)
+        ffs_ctx* home = st->ctx;
+        if (home->L.W != c->L.W || home->L.H != c->L.H) {
+            c->err = "ffs_stack3d_add_batch: the stream's context has another frame shape than the stack's";
+            return FFS_ERR_INVALID;
+        }
+        if (!s->ovf.empty()) {
+            c->err = "ffs_stack3d_add_batch: a frame overflowed the lists of a stream on another device; use a larger max_strong_per_frame";
+            return FFS_ERR_OVERFLOW;
+        }
+        HIP_TRY(home, hipSetDevice(home->device));
+        int rc = stack3d_reserve(st, more);
+        if (rc != FFS_OK) { c->err = home->err; return rc; }
+        uint32_t big = 0;
+        for (uint32_t f = 0; f < nf; ++f) big = std::max(big, s->results[f].num_strong_pixels);
+        rc = stack3d_add_batch_remote(st, s, more, big);
+        if (rc != FFS_OK) { c->err = home->err; return rc; }
+        uint64_t at = st->arrived;
+        for (uint32_t f = 0; f < nf; ++f) {
+            const uint32_t n = s->results[f].num_strong_pixels;
+            st->slices[s->results[f].frame_id] = ffs_stack3d::Slice{(uint32_t)at, n};
+            at += n;
+        }
+        st->arrived = at;
+        (void)hipSetDevice(c->device);
+        return FFS_OK;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
     int rc = stack3d_reserve(st, more);
     if (rc != FFS_OK) return rc;
     STK_TRY(c, st->h_table.ensure(nf));
@@ -1838,8 +2020,8 @@ static int stack3d_add_batch_impl(ffs_stack3d* st, ffs_stream* s) {
 }
 
 extern "C" int ffs_stack3d_add_batch(ffs_stack3d* st, ffs_stream* s) {
-    if (!st || !s || s->ctx != st->ctx) return FFS_ERR_INVALID;
-    return guarded(st->ctx, [&] { return stack3d_add_batch_impl(st, s); });
+    if (!st || !s) return FFS_ERR_INVALID;
+    return guarded(s->ctx, [&] { return stack3d_add_batch_impl(st, s); });
 }
 
 extern "C" int ffs_stack3d_signals(ffs_stack3d* st, const uint32_t** x, const uint32_t** y, const int32_t** z,

@@ -54,6 +54,7 @@ struct Args {
     bool images_set = false, wavelength_set = false, detector_set = false;
     float max_sep = 2.0f, timeout = 30.0f, dmin = -1.f, dmax = -1.f, wavelength = 0.f;
     int pipe_fd = -1, device = 0;
+    std::vector<int> devices;  // --devices / --gpus: the frame queue is dealt to all of them
     std::string algorithm = "dispersion", detector_json;
     bool cpu_decode = false;
 };
@@ -65,6 +66,10 @@ static void usage() {
       "                  [--min-spot-size-3d N] [--max-peak-centroid-separation N] [--start-index N]\n"
       "                  [-t S] [-fd FD] [-a ALGO] [--dmin MIN D] [--dmax MAX D] [-w \xce\xbb] [--detector JSON]\n"
       "                  [-h5] [--output-for-index] [--batch N] [--cpu-decode] [--strict-dtype]\n"
+      "                  [--devices D0,D1,... | --gpus N]\n"
+      "--devices / --gpus: one context and worker pool per GPU, all pulling frames from the one queue\n"
+      "              (-n threads are dealt round-robin to the GPUs, at least one each); rotation sweeps send\n"
+      "              their strong-pixel lists to the first GPU's 3D stack (RCCL over xGMI, else peer copies)\n"
       "--cpu-decode: decompress bitshuffle-LZ4 chunks on the worker thread (the reference's way) instead\n"
       "              of sending them to the GPU as they are\n"
       "FILE: NXmx .nxs/.h5 (needs an HDF5 build), a /dev/shm directory, a ####.cbf template, or\n"
@@ -138,6 +143,13 @@ static Args parse_args(int argc, char** argv) {
         else if (s == "-h5" || s == "--save-h5") r.save_h5 = true;
         else if (s == "--output-for-index") r.output_for_index = true;
         else if (s == "--batch") r.batch = u32(need(i, s), s);
+        else if (s == "--gpus") { const uint32_t n = u32(need(i, s), s); r.devices.clear(); for (uint32_t d = 0; d < n; ++d) r.devices.push_back((int)d); }
+        else if (s == "--devices") {
+            r.devices.clear();
+            std::stringstream ss(need(i, s));
+            std::string tok;
+            while (std::getline(ss, tok, ',')) r.devices.push_back((int)u32(tok, s));
+        }
         else if (s == "--strict-dtype") r.strict_dtype = true;
         else if (!s.empty() && s[0] == '-' && s.size() > 1) arg_error("Unknown argument: " + s);
         else if (r.file.empty()) r.file = s;
@@ -406,30 +418,50 @@ int main(int argc, char** argv) {
     std::printf("GPU batches: %u frames per submit, one stream per CPU thread\n", batch);
     std::printf("Running with %u CPU threads\n", args.threads);
 
-    ffs_ctx* ctx = nullptr;
-    if (ffs_ctx_create(args.device, width, height, (int)bytes_per_pixel, batch, 0, &ctx) != FFS_OK) {
-        std::printf("Error: %s\n", ffs_last_error(nullptr));
-        return 1;
+    // One context per GPU (the reference has one device, -d: src/ffs/cuda_arg_parser.cc:30-61).  With
+    // --devices / --gpus the one frame queue (next_image below) feeds the worker threads of all of them.
+    std::vector<int> devices = args.devices.empty() ? std::vector<int>{args.device} : args.devices;
+    {
+        const int have = ffs_device_count();
+        for (int d : devices)
+            if (d < 0 || d >= have) {
+                std::printf("Error: device %d does not exist (%d visible)\n", d, have);
+                return 1;
+            }
     }
+    const uint32_t n_dev = (uint32_t)devices.size();
+    if (args.threads < n_dev) args.threads = n_dev;  // at least one worker per GPU
+    if (n_dev > 1) {
+        std::string list;
+        for (int d : devices) list += (list.empty() ? "" : ", ") + std::to_string(d);
+        (void)ffs_multi_init(devices.data(), (int)n_dev, nullptr);
+        std::printf("GPUs:        %s (frame queue shared; exchange of rotation lists: %s)\n", list.c_str(), ffs_multi_transport());
+    }
+    std::vector<ffs_ctx*> ctxs(n_dev, nullptr);
+    for (uint32_t di = 0; di < n_dev; ++di) {
+        if (ffs_ctx_create(devices[di], width, height, (int)bytes_per_pixel, batch, 0, &ctxs[di]) != FFS_OK) {
+            std::printf("Error: %s\n", ffs_last_error(nullptr));
+            return 1;
+        }
+    }
+    ffs_ctx* ctx = ctxs[0];  // owns the 3D stack; also the context the one-off steps below report from
     {  // upload_mask, spotfinder.cc:61-108
         size_t valid = 0;
         const auto t0 = std::chrono::steady_clock::now();
-        if (const auto mask = reader.get_mask()) {
-            for (uint8_t v : *mask) valid += v != 0;
-            FFS_CHECK(ctx, ffs_ctx_set_mask(ctx, mask->data()));
-        } else {
-            valid = (size_t)width * height;
-            FFS_CHECK(ctx, ffs_ctx_set_mask(ctx, nullptr));
-        }
+        const auto mask = reader.get_mask();
+        if (mask) for (uint8_t v : *mask) valid += v != 0;
+        else valid = (size_t)width * height;
+        for (ffs_ctx* cx : ctxs) FFS_CHECK(cx, ffs_ctx_set_mask(cx, mask ? mask->data() : nullptr));
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         std::printf("Uploaded mask (%.2f Mpx) in %.2f ms (%.1f GBps)\n", valid / 1e6, ms,
-                    (double)width * height / (ms * 1e-3) / 1e9);
+                    (double)width * height * n_dev / (ms * 1e-3) / 1e9);
     }
     if (const auto mask = reader.get_mask(); args.writeout && mask) write_mask_png("mask_source.png", mask->data(), width, height);
     if (args.dmin > 0 || args.dmax > 0) {  // spotfinder.cc:648-683
-        FFS_CHECK(ctx, ffs_ctx_apply_resolution_mask(ctx, wavelength, detector.distance, detector.beam_center_x,
-                                                     detector.beam_center_y, detector.pixel_size_x,
-                                                     detector.pixel_size_y, args.dmin, args.dmax));
+        for (ffs_ctx* cx : ctxs)
+            FFS_CHECK(cx, ffs_ctx_apply_resolution_mask(cx, wavelength, detector.distance, detector.beam_center_x,
+                                                        detector.beam_center_y, detector.pixel_size_x,
+                                                        detector.pixel_size_y, args.dmin, args.dmax));
         if (args.writeout) {
             std::vector<uint8_t> m((size_t)width * height);
             FFS_CHECK(ctx, ffs_ctx_get_mask(ctx, m.data()));
@@ -445,7 +477,7 @@ int main(int argc, char** argv) {
     prm.want_reflections = (!rotation && (args.save_h5 || args.output_for_index)) ? 1 : 0;
     prm.want_strong_mask = args.writeout ? 1 : 0;
     prm.algorithm = algorithm;
-    FFS_CHECK(ctx, ffs_ctx_set_params(ctx, &prm));
+    for (ffs_ctx* cx : ctxs) FFS_CHECK(cx, ffs_ctx_set_params(cx, &prm));
     if (args.validate)
         std::printf("Note: --validate is not linked into this build (the CPU baseline is test infrastructure: "
                     "run `pytest -m gpu`, which compares every stage with it)\n");
@@ -471,6 +503,7 @@ int main(int argc, char** argv) {
     std::mutex reflection_centers_2d_mutex;
 
     auto worker = [&](int thread_id) {
+        ffs_ctx* ctx = ctxs[(size_t)thread_id % ctxs.size()];  // this worker's GPU (shadows the home context)
         ffs_stream* s = nullptr;
         if (ffs_stream_create(ctx, &s) != FFS_OK) {
             std::printf("Error: %s\n", ffs_last_error(ctx));
@@ -736,6 +769,6 @@ int main(int argc, char** argv) {
     if (time_waiting < 10) std::printf("Total time waiting for images to appear: %.0f ms\n", time_waiting * 1000);
     else std::printf("Total time waiting for images to appear: %.2f s\n", time_waiting);
     pipe.reset();
-    ffs_ctx_destroy(ctx);
+    for (ffs_ctx* cx : ctxs) ffs_ctx_destroy(cx);
     return 0;
 }

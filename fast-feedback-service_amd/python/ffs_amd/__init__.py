@@ -7,4 +7,4 @@ missing -- there is no CPU fallback.
 from . import synth  # noqa: F401
 from .api import (Context, FrameResult, Params, Stack3D, Stream, device_count,  # noqa: F401
                   device_name, lib_path, load_library, FfsError, BOX_DT, REFL_DT,
-                  ALGO_DISPERSION, ALGO_DISPERSION_EXTENDED)
+                  ALGO_DISPERSION, ALGO_DISPERSION_EXTENDED, multi_init)

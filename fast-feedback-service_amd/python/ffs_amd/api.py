@@ -75,7 +75,7 @@ EXPORTS = [
     "ffs_stream_create", "ffs_stream_destroy", "ffs_stream_host_buffer", "ffs_submit",
     "ffs_submit_device", "ffs_ctx_device_layout", "ffs_wait", "ffs_stream_batch_arrays", "ffs_stream_timings",
     "ffs_submit_compressed", "ffs_decode_only", "ffs_stream_spot_centres", "ffs_bench_threshold", "ffs_bench_hbm", "ffs_stream_debug_planes", "ffs_stream_debug_bitplane", "ffs_selftest_sqrt", "ffs_stack3d_create",
-    "ffs_stack3d_destroy", "ffs_stack3d_add_batch", "ffs_stack3d_add_slice", "ffs_stack3d_finish", "ffs_stack3d_signals", "ffs_stack3d_last_finish_ms",
+    "ffs_stack3d_destroy", "ffs_stack3d_add_batch", "ffs_stack3d_add_slice", "ffs_stack3d_finish", "ffs_stack3d_signals", "ffs_stack3d_last_finish_ms", "ffs_multi_init", "ffs_multi_transport",
 ]
 
 _lib = None
@@ -111,6 +111,8 @@ def load_library():
                                               C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
         L.ffs_bench_threshold.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32,
                                           C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.ffs_multi_init.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_char_p]
+        L.ffs_multi_transport.restype = C.c_char_p
         L.ffs_bench_hbm.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.ffs_stream_debug_planes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                               C.POINTER(C.c_size_t)]
@@ -405,6 +407,16 @@ class Stream:
             self.close()
         except Exception:
             pass
+
+
+def multi_init(devices, transport=None) -> str:
+    """ffs_multi_init: prepare the exchange between the contexts of several GPUs; returns the transport in use."""
+    lib = load_library()
+    arr = (C.c_int * len(devices))(*devices)
+    rc = lib.ffs_multi_init(arr, len(devices), transport.encode() if transport else None)
+    if rc != 0:
+        raise FfsError(rc, lib.ffs_last_error(None).decode())
+    return lib.ffs_multi_transport().decode()
 
 
 class Stack3D:

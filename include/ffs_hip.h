@@ -252,6 +252,16 @@ int ffs_stack3d_add_slice(ffs_stack3d *st, int64_t frame_id, const uint32_t *k,
 int ffs_stack3d_finish(ffs_stack3d *st, const ffs_reflection **reflections,
                        uint32_t *n_reflections, uint32_t *n_calculated,
                        uint32_t *n_filtered_size, uint32_t *n_filtered_sep);
+/* ---- several GPUs in one process ------------------------------------------------------------------
+ * The reference drives ONE device (-d, src/ffs/cuda_arg_parser.cc:30-61).  A driver that owns several makes
+ * one ffs_ctx per GPU and deals its frame queue to all of them (spotfinder --devices / --gpus); stills need
+ * no exchange.  For rotation sweeps ffs_stack3d_add_batch() accepts a stream of ANOTHER context with the same
+ * frame shape: the batch's strong-pixel lists are packed on their GPU and sent to the stack's GPU -- by RCCL
+ * point-to-point over xGMI when ffs_multi_init() could load librccl and build the communicators, else by
+ * peer copies.  `devices`: the GPUs in use (duplicates allowed); transport: "rccl", "peer" or NULL (= the
+ * FFS_GATHER environment variable, default "rccl").  ffs_multi_transport(): "rccl", "peer" or "none". */
+int ffs_multi_init(const int *devices, int n_devices, const char *transport);
+const char *ffs_multi_transport(void);
 /* Device time of the last ffs_stack3d_finish (upload of the slice table to the labels of every strong pixel), ms. */
 int ffs_stack3d_last_finish_ms(const ffs_stack3d *st, float *ms);
 /* Per-signal view of the last ffs_stack3d_finish: every strong pixel of the stack in the reference's

@@ -299,3 +299,50 @@ def test_resolution_mask_flags(tmp_path):
     a = [json.loads(l)["num_strong_pixels"] for l in sorted(lines)]
     b = [json.loads(l)["num_strong_pixels"] for l in sorted(lines2)]
     assert all(x <= y for x, y in zip(a, b)) and sum(a) < sum(b)
+
+
+@pytest.mark.parametrize("transport", ["", "rccl", "peer"])
+def test_several_device_contexts_share_the_frame_queue(tmp_path, transport):
+    """--devices: one context and worker pool per listed GPU, all pulling from the one frame queue.  On a
+    one-GPU box the list names the same GPU twice, which still makes two contexts, two worker pools and --
+    for the rotation sweep -- the cross-context exchange of the strong-pixel lists into the 3D stack; with
+    FFS_GATHER=rccl that exchange goes through RCCL send/recv (a one-rank communicator talking to itself)."""
+    from oracle import oracle as O
+    N = 10
+    env = dict(os.environ)
+    if transport:
+        env["FFS_GATHER"] = transport
+    argv = ["synth:tinysweep:%d" % N, "--devices", "0,0", "--threads", "4", "--batch", "2", "--writeout", "--min-spot-size-3d", "4"]
+    r, w = os.pipe()
+    proc = subprocess.Popen([SPOTFINDER, *argv, "--pipe_fd", str(w)], pass_fds=[w], cwd=tmp_path, env=env,
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    os.close(w)
+    out, err = proc.communicate(timeout=300)
+    with os.fdopen(r) as f:
+        lines = [json.loads(l) for l in f.read().split("\n") if l]
+    assert proc.returncode == 0 and not err, err
+    txt = strip_ansi(out)
+    assert "GPUs:        0, 0" in txt
+    if transport == "rccl":
+        assert "exchange of rotation lists: rccl" in txt
+    frames = tiny_frames(N, sweep=True)
+    mask = np.ones((200, 300), np.uint8)
+    exp = expected(frames, mask)
+    # every frame exactly once, whatever GPU took it; JSON lines as with one device
+    assert sorted(l["file-number"] for l in lines) == list(range(N))
+    for l in lines:
+        cc, _ = exp[l["file-number"]]
+        assert l["num_strong_pixels"] == cc.num_strong_pixels and l["n_spots_total"] == len(cc.boxes)
+    want = O.cc3d([(cc.k, cc.intensity) for cc, _ in exp], 300, 200, 4, 2.0)
+    assert int(re.search(spots_match_regex, txt).group(1)) == want.n_calculated
+    assert f"Found {len(want.reflections)} spots" in txt
+    got = open(tmp_path / "3d_reflections.txt").read().strip().split("\n")
+    assert len(got) == len(want.reflections) > 3
+    for line, rr in zip(got, want.reflections):
+        m = re.match(r"X: \[(\d+), (\d+)\] Y: \[(\d+), (\d+)\] Z: \[(\d+), (\d+)\]", line)
+        assert [int(m.group(i)) for i in range(1, 7)] == [rr["x_min"], rr["x_max"], rr["y_min"], rr["y_max"], rr["z_min"], rr["z_max"]]
+
+
+def test_unknown_device_in_list_is_refused(tmp_path):
+    p = subprocess.run([SPOTFINDER, "synth:tiny:2", "--devices", "0,99"], capture_output=True, text=True, cwd=tmp_path)
+    assert p.returncode == 1 and "device 99 does not exist" in p.stdout

@@ -228,3 +228,36 @@ def test_spot_centres_rows(ffs):
         st.pack_spot_centres(small, 3)
     assert np.array_equal(small[:3].view(np.uint32), want[:3].view(np.uint32))
     assert tuple(small[3].view(np.uint32)[:2]) == (3, n)
+
+
+@pytest.mark.parametrize("transport", ["peer", "rccl"])
+def test_stack3d_fed_from_two_contexts(ffs, transport, monkeypatch):
+    """The multi-GPU rotation path with both contexts on the one GPU of the test box: frames alternate between
+    two contexts, every batch's lists cross over into the first context's 3D stack (ffs_stack3d_add_batch with
+    a foreign stream) -- by device copies, and by RCCL send/recv on a one-rank communicator."""
+    from oracle import oracle as O
+    from ffs_amd import synth
+    from util import assert_reflections_equal
+    monkeypatch.setenv("FFS_GATHER", transport)
+    used = ffs.multi_init([0, 0], transport)
+    assert used == ("rccl" if transport == "rccl" else "none")      # one distinct device: nothing to peer with
+    W, H, NZ = 300, 200, 12
+    p = synth.sweep_params(seed=78, n_frames=NZ, n_spots=60, width=W, height=H)
+    frames = synth.frames(p, range(NZ))
+    ctxs = [ffs.Context(W, H, np.uint16, max_batch=2) for _ in range(2)]
+    for c in ctxs:
+        c.set_params(want_strong_list=1, min_spot_size_3d=4)
+    streams = [c.stream() for c in ctxs]
+    stack = ffs.Stack3D(ctxs[0])
+    slices = [None] * NZ
+    for b, z0 in enumerate(range(0, NZ, 2)):
+        st = streams[b % 2]
+        res = st.process(frames[z0:z0 + 2], first_frame_id=z0)
+        stack.add_batch(st)
+        for j, r in enumerate(res):
+            slices[z0 + j] = (r.strong_k.copy(), r.strong_intensity.copy())
+    refl, n_calc, fs, fp = stack.finish()
+    want = O.cc3d(slices, W, H, 4, 2.0)
+    assert (n_calc, fs, fp) == (want.n_calculated, want.n_filtered_size, want.n_filtered_sep)
+    assert_reflections_equal(refl, want.reflections)
+    assert len(refl) > 5
