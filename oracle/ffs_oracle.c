@@ -847,6 +847,33 @@ int ffs_oracle_kabsch_variances(const ffs_oracle_slice *slices, size_t n_slices,
     return 0;
 }
 
+/* Resolution mask: spotfinder/kernels/masking.cu:37-73 (distance from the beam centre, d-spacing), :99-147
+ * (pixels outside [dmin, dmax] are masked; masked pixels stay masked), all in float32 as the kernel writes it.
+ * `0.5 * atanf(..)` is evaluated in double there and narrowed: halving is exact, so 0.5f * gives the same float.
+ * The transcendental functions are the host libm's (correctly rounded or within an ulp); a device library may
+ * differ from them in the last place, which can flip pixels whose d-spacing sits on a threshold -- the GPU
+ * test states and bounds those.  `resolution` (optional, W*H floats) receives the d-spacing of every pixel. */
+int ffs_oracle_resolution_mask(uint8_t *mask, int width, int height, float wavelength, float distance,
+                               float beam_center_x, float beam_center_y, float pixel_size_x, float pixel_size_y,
+                               float dmin, float dmax, float *resolution) {
+    if (!mask || width <= 0 || height <= 0) return -1;
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            const size_t k = (size_t)y * width + x;
+            const float dx = (((float)x + 0.5f) - beam_center_x) * pixel_size_x; /* :50-52 */
+            const float dy = (((float)y + 0.5f) - beam_center_y) * pixel_size_y;
+            const float r = sqrtf(dx * dx + dy * dy);
+            const float theta = 0.5f * atanf(r / distance);                      /* :71 */
+            const float res = wavelength / (2 * sinf(theta));                    /* :72 */
+            if (resolution) resolution[k] = res;
+            if (mask[k] == 0) continue;                                           /* :120-126 */
+            if (dmin > 0 && res < dmin) { mask[k] = 0; continue; }                /* :133-136 */
+            if (dmax > 0 && res > dmax) { mask[k] = 0; continue; }                /* :139-142 */
+            mask[k] = 1;                                                          /* :145 */
+        }
+    return 0;
+}
+
 void ffs_oracle_free(void *p) {
     free(p);
 }

@@ -304,6 +304,20 @@ def kabsch_variances(slices, width, signal_reflection, reflections, geometry: Ge
     return sb[:n], sm[:n], depth[:n]
 
 
+def resolution_mask(mask: np.ndarray, wavelength, distance, beam_center_x, beam_center_y, pixel_size_x, pixel_size_y,
+                    dmin=-1.0, dmax=-1.0):
+    """(mask after the resolution filter, d-spacing of every pixel as float32): masking.cu:37-147 in float32."""
+    H, W = mask.shape
+    out = np.ascontiguousarray(mask, np.uint8).copy()
+    res = np.empty((H, W), np.float32)
+    f = lib().ffs_oracle_resolution_mask
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_float] * 8 + [C.c_void_p]
+    if f(_ptr(out), W, H, wavelength, distance, beam_center_x, beam_center_y, pixel_size_x, pixel_size_y, dmin, dmax,
+         _ptr(res)) != 0:
+        raise ValueError("oracle resolution mask failed")
+    return out, res
+
+
 def cc2d_reflections(k, intensity, width, height, min_spot_size=3, max_sep=2.0) -> CC3D:
     """find_2d_components (connected_components.cc:238-266): one slice, z = 0."""
     return cc3d([(k, intensity)], width, height, min_spot_size, max_sep)
