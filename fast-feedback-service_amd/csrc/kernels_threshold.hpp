@@ -1,21 +1,25 @@
-// kernels_threshold.hpp (included by ffs_api.hip) -- dispersion thresholding for gfx950 (CDNA4), two kernels.
+// kernels_threshold.hpp (included by ffs_api.hip) -- dispersion thresholding as two kernels: a conservative
+// streaming candidate kernel and an exact kernel on its candidates.  Since round 2 the default path for 16-bit
+// pixels is the ONE-kernel formulation of kernels_stream.hpp; what is here serves 32-bit pixels, the first pass
+// of the extended algorithm and the A/B variants (FFS_K1_VARIANT=0/1).
 //
 // What the reference does: one 7x7 masked window sum per pixel from a shared-memory tile and a
 // float32 test (spotfinder/kernels/thresholding.cu:60-125, :145-234).  What "bit-exact" is judged
 // against: the float64 summed-area-table predicate of baseline/spotfinder/standalone.cc:113-174.
 //
-// MI355X design:
-//   K1 `k_candidates`  streams the frame once.  A wave64 marches down a 512-px column strip with a
+//   K1 `k_candidates_*` streams the frame once.  A wave64 marches down a 512-px column strip with a
 //      7-row register ring; the masked pixel value and the valid count share ONE 32-bit word
 //      (value + 2^22 per valid pixel: 49*65535 < 2^22, 49 < 2^6), so the exact integer window
 //      sums {sum p, n} cost one running vertical add/sub and one sliding horizontal add/sub per
-//      pixel; neighbours across lanes come from DPP wave shifts.  It evaluates a CONSERVATIVE
-//      float32 form of the signal test (b > nsig_s sqrt(x m)) and emits a 1-bit/pixel candidate
-//      plane (never misses a strong pixel; typically ~0.5 % of pixels pass) and zero-fills the
-//      byte mask.  No sum of squares, no fp64, no LDS in this kernel: it is a pure HBM stream.
-//   K2 `k_exact`       visits only the candidates: exact integer 7x7 sums {n, sum p, sum p^2}
+//      pixel; neighbours across lanes come from DPP wave shifts.  Variant 0 (`<false>`): a conservative
+//      float32 form of the signal test per pixel, no sum of squares, no LDS.  Variant 1 (`<true>`, and
+//      `k_candidates_u32_q`): also a running column sum of p^2, a group screen per lane and row, an LDS
+//      queue of the groups that pass and per-pixel conservative signal + dispersion tests on dense lanes
+//      when the queue drains -- the candidate plane then holds little more than the true strong pixels.
+//      Both emit a 1-bit/pixel candidate plane (a superset of the strong pixels) and zero-fill the byte mask.
+//   K2 `k_exact*`      visits only the candidates: exact integer 7x7 sums {n, sum p, sum p^2}
 //      and the oracle's fp64 predicate, operation for operation; clears failed candidates in the
-//      bit plane (it becomes the strong plane) and sets the byte mask.
+//      bit plane (it becomes the strong plane), sets the byte mask, counts the strong pixels per tile.
 #pragma once
 #include "ffs_device.h"
 
