@@ -210,15 +210,19 @@ __global__ __launch_bounds__(64) void k_emit_list_w(const CclArgs a) {
                 // the pixel left of this word's bit 0: bit 31 of the word before it, same row
                 const bool left = col != 0 && pg + 1 == g && (pw >> 31) != 0u;
                 int prev = -2;  // bit index of this word's previous strong pixel
+                uint32_t run_first = at;  // list index of the first pixel of the current run inside this word
                 while (w) {
                     const int bit = __ffs((int)w) - 1;
                     w &= w - 1;
                     const int x = xb + bit;
                     const bool linked = bit == 0 ? left : prev == bit - 1;
+                    if (!linked || bit == 0) run_first = at;
                     if (at < a.cap) {
                         lk[at] = (uint32_t)y * (uint32_t)a.W + (uint32_t)x;
                         li[at] = *reinterpret_cast<const PixelT*>(img + (uint64_t)y * a.pitch + (uint64_t)x * sizeof(PixelT));
-                        par[at] = linked ? at - 1 : at;
+                        // a run's pixels point at its first pixel in this word (a find is one step, not a walk
+                        // along the run); a run that continues from the previous word hooks on to that word's last pixel
+                        par[at] = !linked ? at : (bit == 0 ? at - 1 : run_first);
                         if (acc2 && !linked) {  // a run start may end up a root: fresh accumulator
                             CompAcc2 z;
                             z.sum_i = z.sum_xi = z.sum_yi = z.peak = 0ull;
