@@ -445,7 +445,7 @@ def main():
                                                     "8 B zero store per 16 B read (the kernel's read/write mix)"},
                          "frac_of_measured_mix": round((traffic if traffic else alg_bytes) / (ms_cand * 1e-3) / 1e9 / max(peak_mix, 1.0), 4),
                          "kernel": ("k_candidates_u16<ext>" if ext else
-                                    "k_stream_u16 (whole threshold stage)" if dt == np.uint16 else "k_candidates_u32_q"),
+                                    "k_stream_u16 (whole threshold stage)" if dt == np.uint16 else "k_stream_u32 (whole threshold stage)"),
                          "ms_per_launch": round(ms_cand, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "exact_kernel_ms_per_launch": round(ms_exact, 4)},

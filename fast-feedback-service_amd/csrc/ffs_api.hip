@@ -327,7 +327,8 @@ extern "C" int ffs_ctx_create(int device, uint32_t width, uint32_t height, int p
         return FFS_ERR_DEVICE;
     }
     hipError_t e = hipMalloc(&c->d_maskbits, L.plane_frame_stride + 256);
-    if (e == hipSuccess) e = hipMalloc(&c->d_ginfo, (size_t)(L.H + kInfoExtraRows) * (L.pitch_px / 2) + 256);
+    // one dword per lane group of 16 bytes of pixels: 8 pixels (16-bit) or 4 pixels (32-bit)
+    if (e == hipSuccess) e = hipMalloc(&c->d_ginfo, (size_t)(L.H + kInfoExtraRows) * ((size_t)L.pitch_px * pixel_bytes / 4) + 256);
     if (e == hipSuccess) e = hipMalloc(&c->d_mmap, (size_t)L.H * L.pitch_px + 256);
     if (e != hipSuccess) {
         g_create_error = std::string("hipMalloc(mask): ") + hipGetErrorString(e);
@@ -357,12 +358,16 @@ extern "C" void ffs_ctx_destroy(ffs_ctx* c) {
 // The tables of the one-kernel threshold path depend on the mask alone: rebuilt whenever it changes.
 static int rebuild_mask_tables(ffs_ctx* c) {
     const Layout& L = c->L;
-    const uint32_t gpitch = (uint32_t)L.pitch_px / 2;
+    const uint32_t gpitch = (uint32_t)L.pitch_px * (uint32_t)c->pixel_bytes / 4;
     HIP_TRY(c, hipMemset(c->d_ginfo, 0, (size_t)(L.H + kInfoExtraRows) * gpitch));
-    const int groups = L.pitch_px / 8;
+    const int groups = L.pitch_px / (c->pixel_bytes == 2 ? 8 : 4);
     (void)hipGetLastError();  // drop any stale error state: the check below is for this launch
-    hipLaunchKernelGGL(k_build_maps, dim3((groups + 255) / 256, L.H), dim3(256), 0, 0, c->d_maskbits, L.mpitch, L.W, L.H,
-                       L.pitch_px, c->d_mmap, c->d_ginfo, gpitch);
+    if (c->pixel_bytes == 2)
+        hipLaunchKernelGGL(k_build_maps, dim3((groups + 255) / 256, L.H), dim3(256), 0, 0, c->d_maskbits, L.mpitch, L.W, L.H,
+                           L.pitch_px, c->d_mmap, c->d_ginfo, gpitch);
+    else
+        hipLaunchKernelGGL(k_build_maps4, dim3((groups + 255) / 256, L.H), dim3(256), 0, 0, c->d_maskbits, L.mpitch, L.W, L.H,
+                           L.pitch_px, c->d_mmap, c->d_ginfo, gpitch);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipDeviceSynchronize());
     return FFS_OK;
@@ -645,7 +650,6 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
         // threshold in one streaming kernel (kernels_stream.hpp)
         const char* v = std::getenv("FFS_K1_VARIANT");
         a.variant = v ? std::atoi(v) : 2;
-        if (c->pixel_bytes != 2 && a.variant > 1) a.variant = 1;
         if (s->force_variant >= 0) a.variant = std::min(a.variant, s->force_variant);
     }
     a.overflow = s->d_overflow;
@@ -655,8 +659,8 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
     a.dbg = std::getenv("FFS_K1_DEBUG") ? std::atoi(std::getenv("FFS_K1_DEBUG")) : 0;
     a.ginfo = c->d_ginfo;
     a.mmap = c->d_mmap;
-    a.gpitch = (uint32_t)L.pitch_px / 2;
-    a.gpf = (L.W + 7) / 8;
+    a.gpitch = (uint32_t)L.pitch_px * (uint32_t)c->pixel_bytes / 4;
+    a.gpf = c->pixel_bytes == 2 ? (L.W + 7) / 8 : (L.W + 3) / 4;
     a.n_frames = (int)n_frames;
     {   // frames side by side in one super row, as many as keep every buffer of the group below 2 GiB
         const uint64_t per_frame = std::max<uint64_t>(fstride, L.bytes_frame_stride);
@@ -665,7 +669,8 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
         const int n_groups = ((int)n_frames + a.group_frames - 1) / a.group_frames;
         const long long lanes = (long long)a.group_frames * (a.gpf + 1);
         const long long lines = (long long)a.group_frames * (L.bpitch / 128);  // byte-mask lines to zero per row
-        a.s_strips = (int)std::max<long long>((lanes + kSOwned - 1) / kSOwned, (lines + 3) / 4);
+        const int lines_per_wave = c->pixel_bytes == 2 ? 4 : 2;  // a wave zero-fills 512 / 256 bytes of the byte mask per row
+        a.s_strips = (int)std::max<long long>((lanes + kSOwned - 1) / kSOwned, (lines + lines_per_wave - 1) / lines_per_wave);
         long long tw = 16384;
         if (const char* e = std::getenv("FFS_K1_TARGET_WAVES")) tw = std::max(1, std::atoi(e));
         const long long per_band = std::max<long long>(1, (long long)a.s_strips * n_groups);
@@ -743,7 +748,7 @@ static int ensure_extended_buffers(ffs_stream* s) {
 }
 
 static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
-    if (s->ctx->pixel_bytes == 2 && a.variant >= 2) {
+    if (a.variant >= 2) {
         // the whole threshold in one kernel: final strong plane + per-tile counts (atomics into zeroed counters)
         ThresholdArgs b = a;
         b.n_strips = a.s_strips;
@@ -753,11 +758,16 @@ static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_
         const int bands8s = (b.n_bands + 7) / 8 * 8;
         const unsigned n_groups = (n_frames + (unsigned)a.group_frames - 1) / (unsigned)a.group_frames;
         const int ahead = std::getenv("FFS_K1_AHEAD") ? std::atoi(std::getenv("FFS_K1_AHEAD")) : 2;
+        if (s->ctx->pixel_bytes == 4) {
+            hipLaunchKernelGGL(k_stream_u32<2>, dim3((unsigned)(b.n_strips * bands8s), n_groups), dim3(64), 0, s->st, b);
+            hipLaunchKernelGGL(k_bright_fix<uint32_t>, dim3(32), dim3(256), 0, s->st, b);
+            return;
+        }
         if (ahead >= 3)
             hipLaunchKernelGGL(k_stream_u16<3>, dim3((unsigned)(b.n_strips * bands8s), n_groups), dim3(64), 0, s->st, b);
         else
             hipLaunchKernelGGL(k_stream_u16<2>, dim3((unsigned)(b.n_strips * bands8s), n_groups), dim3(64), 0, s->st, b);
-        hipLaunchKernelGGL(k_bright_fix, dim3(32), dim3(256), 0, s->st, b);
+        hipLaunchKernelGGL(k_bright_fix<uint16_t>, dim3(32), dim3(256), 0, s->st, b);
         return;
     }
     const int bands8 = (a.n_bands + 7) / 8 * 8;  // XCD-aware mapping wants a multiple of 8 bands
@@ -777,7 +787,7 @@ static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_
 }
 
 static void launch_exact(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
-    if (s->ctx->pixel_bytes == 2 && a.variant >= 2) return;  // k_stream_u16 left the final plane and the counts
+    if (a.variant >= 2) return;  // k_stream_u16 / k_stream_u32 left the final plane and the counts
     dim3 grid((unsigned)a.n_tiles, n_frames), block(256);
     if (s->ctx->pixel_bytes == 2 && a.variant == 1)  // few candidates per tile: one wave per tile
         hipLaunchKernelGGL(k_exact_w64<uint16_t>, grid, dim3(64), 0, s->st, a);
@@ -824,7 +834,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     // stream's sparse stage runs under the other's dense kernel -- a small kernel queued behind a
     // 9000-workgroup dispatch of another queue gets no CUs until that dispatch drains; 35.3 k vs
     // 37.2 k frames/s.  CU masks for the two stages: no gain either.)
-    const bool one_kernel = c->pixel_bytes == 2 && ta.variant >= 2 && p.algorithm != FFS_ALGO_DISPERSION_EXTENDED;
+    const bool one_kernel = ta.variant >= 2 && p.algorithm != FFS_ALGO_DISPERSION_EXTENDED;
     if (one_kernel && s->bits_dirty)  // (another algorithm / variant or a failed batch left bits behind)
         HIP_TRY(c, hipMemsetAsync(s->d_bits, 0, (size_t)s->max_batch * L.plane_frame_stride, s->st));
     s->bits_dirty = !one_kernel;
@@ -842,7 +852,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     ca.frame_stride = fstride;
     ca.pitch = (uint32_t)pitch;
     ca.bits = s->d_bits;
-    ca.clear_bits = (c->pixel_bytes == 2 && ta.variant >= 2 && p.algorithm != FFS_ALGO_DISPERSION_EXTENDED) ? 1 : 0;
+    ca.clear_bits = (ta.variant >= 2 && p.algorithm != FFS_ALGO_DISPERSION_EXTENDED) ? 1 : 0;
     s->bits_cleared = ca.clear_bits != 0;
     ca.tile_counts = s->d_tile_counts;
     ca.num_strong = s->d_num_strong;

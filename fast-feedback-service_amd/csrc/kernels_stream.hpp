@@ -49,7 +49,8 @@ constexpr int kInfoExtraRows = 3;    // ginfo row y carries the mask bits of row
 // ---- tables that depend on the mask alone -------------------------------------------------------------
 // One thread per (group, row).  mmap[y][x] = number of valid pixels in the 7x7 window clipped to the
 // image (the oracle's m, standalone.cc:126-141); ginfo[y][g] byte 0 = mask bits of row y,
-// ginfo[y + 3][g] bytes 1, 2 = min / max of m over the VALID pixels of group g in row y (max = 0: none).
+// ginfo[y + 3][g] bytes 1, 2 = min / max of m over the VALID pixels of group g in row y (max = 0: none),
+// byte 3 = the mask bits of row y once more (row y is the centre row when row y + 3 comes in).
 __global__ __launch_bounds__(256) void k_build_maps(const uint8_t* maskbits, uint32_t mpitch, int W, int H, int pitch_px,
                                                     uint8_t* mmap, uint8_t* ginfo, uint32_t gpitch_bytes) {
     const int g = blockIdx.x * 256 + threadIdx.x;
@@ -76,6 +77,40 @@ __global__ __launch_bounds__(256) void k_build_maps(const uint8_t* maskbits, uin
     ginfo[(uint64_t)y * gpitch_bytes + g * 4] = (uint8_t)own;
     ginfo[(uint64_t)(y + kInfoExtraRows) * gpitch_bytes + g * 4 + 1] = (uint8_t)mn;
     ginfo[(uint64_t)(y + kInfoExtraRows) * gpitch_bytes + g * 4 + 2] = (uint8_t)mx;
+    ginfo[(uint64_t)(y + kInfoExtraRows) * gpitch_bytes + g * 4 + 3] = (uint8_t)own;  // the centre row's mask bits again
+}
+
+// The same tables for 32-bit pixels: lane groups of FOUR pixels (16 bytes), one ginfo dword per group (mask bits
+// in bits 0-3).  The counts are those of the mask alone; the oracle also drops neighbours >= 2^24 from its sums
+// and counts (standalone.cc:78,90) -- k_stream_u32 sends every window that holds such a pixel to the gather path.
+__global__ __launch_bounds__(256) void k_build_maps4(const uint8_t* maskbits, uint32_t mpitch, int W, int H, int pitch_px,
+                                                     uint8_t* mmap, uint8_t* ginfo, uint32_t gpitch_bytes) {
+    const int g = blockIdx.x * 256 + threadIdx.x;   // group of 4 pixels: columns 4g .. 4g+3
+    const int y = blockIdx.y;
+    if (g * 4 >= pitch_px) return;
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    const int byte0 = (g * 4) >> 3, sh = (g * 4) & 7;   // the group's bits sit at bit `sh` (0 or 4) of byte0
+    for (int dy = -3; dy <= 3; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        const uint8_t* row = maskbits + (uint64_t)yy * mpitch;
+        uint32_t b = (uint32_t)row[byte0] << 8;
+        if (byte0 > 0) b |= row[byte0 - 1];
+        if ((uint32_t)(byte0 + 1) < mpitch) b |= (uint32_t)row[byte0 + 1] << 16;
+        // bit 8 + sh + j is pixel j of the group; its window is bits (8 + sh + j - 3) .. (8 + sh + j + 3)
+        for (int j = 0; j < 4; ++j) cnt[j] += __popc((b >> (5 + sh + j)) & 0x7Fu);
+    }
+    const uint32_t own = (maskbits[(uint64_t)y * mpitch + byte0] >> sh) & 0xFu;
+    uint32_t mn = 255, mx = 0;
+    for (int j = 0; j < 4; ++j) {
+        mmap[(uint64_t)y * pitch_px + g * 4 + j] = (uint8_t)cnt[j];
+        if ((own >> j) & 1u) { mn = min(mn, cnt[j]); mx = max(mx, cnt[j]); }
+    }
+    if (mx == 0) mn = 0;
+    ginfo[(uint64_t)y * gpitch_bytes + g * 4] = (uint8_t)own;
+    ginfo[(uint64_t)(y + kInfoExtraRows) * gpitch_bytes + g * 4 + 1] = (uint8_t)mn;
+    ginfo[(uint64_t)(y + kInfoExtraRows) * gpitch_bytes + g * 4 + 2] = (uint8_t)mx;
+    ginfo[(uint64_t)(y + kInfoExtraRows) * gpitch_bytes + g * 4 + 3] = (uint8_t)own;
 }
 
 // The oracle's predicate on exact integer window sums, standalone.cc:165-170 operation for operation
@@ -96,15 +131,15 @@ __device__ __forceinline__ bool exact_predicate(const ThresholdArgs& a, uint32_t
     return av > cv && bv > dv;
 }
 
-// The same decision without the two square roots, for sums below 2^32 (then a = m y - x^2 - x (m - 1) and
-// b = m p - x are exact integers in float64, as they are in the oracle).  The oracle compares a with
+// The same decision without the two square roots, for m y < 2^53 (then a = m y - x^2 - x (m - 1) and
+// b = m p - x are exact integers in float64, as they are in the oracle; the callers check the range).  The oracle compares a with
 // c = fl(fl(x nsig_b) fl(sqrt(2 (m-1)))) and b with d = fl(nsig_s fl(sqrt(x m))): each within 2^-51 of
 // the real number.  Comparing the squares instead, a^2 against nsig_b^2 x^2 2 (m-1) and b^2 against
 // nsig_s^2 x m (a few float64 roundings each), settles the comparison whenever the two sides differ by
 // more than 2^-40 relative -- which is always, unless they are equal as real numbers; `certain` says so,
 // and the caller falls back to exact_predicate (with its correctly rounded square roots) otherwise.
-__device__ __forceinline__ bool exact_predicate_nosqrt(const ThresholdArgs& a, uint32_t m, uint32_t sx, uint32_t sy,
-                                                       uint32_t pc, bool& certain) {
+__device__ __forceinline__ bool exact_predicate_nosqrt(const ThresholdArgs& a, uint32_t m, unsigned long long sx,
+                                                       unsigned long long sy, uint32_t pc, bool& certain) {
     certain = true;
     const double src = (double)pc;
     if (!((int)m >= a.min_count && src > a.threshold)) return false;
@@ -425,6 +460,7 @@ rows_done:
 }
 // Pixels whose window holds sum p >= 65536 (k_stream_u16 cannot vouch for its 32-bit sum of p^2): exact
 // 64-bit sums gathered from memory, then the same predicate.  A handful per frame at most.
+template <typename PixelT>
 __global__ __launch_bounds__(256) void k_bright_fix(const ThresholdArgs a) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && *a.bright_n > a.bright_cap) atomicOr(a.overflow, 8u);  // the host re-runs the batch
     const uint32_t n = min(*a.bright_n, a.bright_cap);
@@ -432,7 +468,7 @@ __global__ __launch_bounds__(256) void k_bright_fix(const ThresholdArgs a) {
         const uint2 r = a.bright_list[e];
         const uint32_t frame = r.x >> 16, x = r.x & 0xFFFFu, y = r.y;
         const uint8_t* img = (const uint8_t*)a.image + (uint64_t)frame * a.frame_stride;
-        if (exact_strong<uint16_t>(a, img, (int)x, (int)y)) {
+        if (exact_strong<PixelT>(a, img, (int)x, (int)y)) {
             uint8_t* plane = a.bits + (uint64_t)frame * a.plane_frame_stride + (uint64_t)y * a.mpitch;
             atomicOr(reinterpret_cast<uint32_t*>(plane) + (x >> 5), 1u << (x & 31u));  // rows start on 4-byte boundaries
             atomicAdd(a.tile_counts + (uint64_t)frame * a.n_tiles + y / (uint32_t)kTileRows, 1u);
@@ -440,7 +476,278 @@ __global__ __launch_bounds__(256) void k_bright_fix(const ThresholdArgs a) {
     }
 }
 
+
+// ================================================================================================================
+// 32-bit pixels (the reference's PIXEL_DATA_32BIT build, h5read.h:16-20): the same one-kernel formulation with four
+// pixels (16 bytes) per lane.  Differences from k_stream_u16: the ring holds the four masked pixels of a row as they
+// are (nothing packed), p_in^2 - p_out^2 is a 32-bit multiply (low word: the sums are exact whenever they are used,
+// i.e. while the window sum is below 65536), a lane pair shares one byte of the strong plane (results are ORed in),
+// and the oracle's `src < 2^24` rule: a window that holds a valid pixel >= 2^24 has other sums AND another count
+// than the mask alone gives, so every valid pixel of a group whose 7-row x 10-column neighbourhood holds one goes
+// to the gather path (k_bright_fix<uint32_t>) -- never taken on photon-counting data, there for exactness.
+constexpr int kS4Words = 32;  // queue entry: 0-3 window sums, 4-7 centre pixels, 8 ginfo, 9 window counts, 10 result bits,
+                              // 11 tag (bit 31: neighbourhood holds a pixel >= 2^24), 12-21 / 22-31 low / high words of the
+                              // column sums of p^2 (L1 L2 L3 c0..c3 R0 R1 R2)
+
+template <int KAHEAD>
+__global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
+    __shared__ uint32_t s_q[kS4Words][kQCap];
+    __shared__ uint16_t s_list[kQCap * 4];
+
+    const int lane = threadIdx.x;
+    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int strip = qb % a.n_strips;
+    const int band = xcd + 8 * (qb / a.n_strips);
+    if (band >= a.n_bands) return;
+    const int f0 = blockIdx.y * a.group_frames;
+    const int nf = min(a.group_frames, a.n_frames - f0);
+    const int yb0 = band * a.band_rows;
+    const int yb1 = min(yb0 + a.band_rows, a.H);
+
+    const int gsep = a.gpf + 1;   // a.gpf = groups of four pixels per frame row
+    const int G = strip * kSOwned + lane - 1;
+    const int fl = G >= 0 ? G / gsep : 0;
+    const int g = G - fl * gsep;
+    const bool active = G >= 0 && fl < nf && g < a.gpf;
+    const bool owned = active && lane >= 1 && lane <= kSOwned;
+
+    const rsrc_t r_img = make_rsrc((const uint8_t*)a.image + (uint64_t)f0 * a.frame_stride,
+                                   (uint32_t)((uint64_t)(nf - 1) * a.frame_stride + (uint64_t)a.H * a.pitch));
+    const rsrc_t r_info = make_rsrc(a.ginfo, (uint32_t)(a.H + kInfoExtraRows) * a.gpitch);
+    const rsrc_t r_sb = make_rsrc(a.strong_bytes + (uint64_t)f0 * a.bytes_frame_stride,
+                                  (uint32_t)((uint64_t)nf * a.bytes_frame_stride));
+    constexpr uint32_t kOob = 0x80000000u;
+    const uint32_t off_px = active ? (uint32_t)((uint64_t)fl * a.frame_stride) + (uint32_t)g * 16u : kOob;
+    const uint32_t off_info = active ? (uint32_t)g * 4u : kOob;
+    uint32_t off_byte_st;   // zero-fill: wave `strip` clears the 128-byte lines 2 strip, 2 strip + 1 of the super row
+    {
+        const uint32_t lpf = a.bpitch >> 7;
+        const uint32_t u = (uint32_t)strip * 2u + ((uint32_t)lane >> 4);
+        const uint32_t fz = u / lpf, cz = u - fz * lpf;
+        off_byte_st = (lane < 32 && fz < (uint32_t)nf) ? (uint32_t)((uint64_t)fz * a.bytes_frame_stride) + cz * 128u + ((uint32_t)lane & 15u) * 8u : kOob;
+    }
+
+    const int total = (yb1 - yb0) + 6;
+    const float kS = a.kS;
+
+    uint32_t ring[7][4];
+    uint32_t col[4];
+    long long colq[4];   // sum p^2 over the 7 rows, exact (49 * 2^48 < 2^63)
+    uint32_t M[4] = {0, 0, 0, 0};  // 0 / ~0 per pixel of the current mask nibble
+    uint32_t mprev = 0;
+    uint32_t bighist = 0;          // bit s: the row in ring slot s holds a valid pixel >= 2^24 in this lane
+    RowRegsS pre[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ring[s][q] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { col[j] = 0; colq[j] = 0; }
+
+    auto fetch = [&](RowRegsS& dst, int i) {
+        const int yin = yb0 - 3 + i;
+        const bool in_rows = (i < total) & (yin >= 0);
+        const bool ok_img = in_rows & (yin < a.H);
+        const bool ok_info = in_rows & (yin < a.H + kInfoExtraRows);
+        const uint32_t row = ok_info ? (uint32_t)yin : 0u;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_img, off_px | (ok_img ? 0u : kOob), (ok_img ? row : 0u) * a.pitch, 0);
+        dst.raw = make_uint4(v[0], v[1], v[2], v[3]);
+        dst.info = __builtin_amdgcn_raw_buffer_load_b32(r_info, off_info | (ok_info ? 0u : kOob), row * a.gpitch, 0);
+    };
+
+    auto unpack = [&](const RowRegsS& r, uint32_t (&P)[4]) {
+        const uint32_t mb = r.info & 0xFu;
+        if (__ballot(mb != mprev) != 0ull) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) M[q] = (uint32_t)__builtin_amdgcn_sbfe((int)mb, q, 1);
+            mprev = mb;
+        }
+        P[0] = r.raw.x & M[0]; P[1] = r.raw.y & M[1]; P[2] = r.raw.z & M[2]; P[3] = r.raw.w & M[3];
+    };
+
+    auto push = [&](int s, const uint32_t (&P)[4]) {
+        const uint32_t big = ((P[0] | P[1]) | (P[2] | P[3])) >> 24 ? 1u : 0u;
+        bighist = (bighist & ~(1u << s)) | (big << s);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int32_t t = (int32_t)(P[q] - ring[s][q]), u = (int32_t)(P[q] + ring[s][q]);  // |t|, u < 2^25 (a pixel >= 2^24 sends its windows to the gather path)
+            col[q] += (uint32_t)t;
+            colq[q] += (long long)t * (long long)u;   // p_in^2 - p_out^2: one v_mad_i64_i32
+            ring[s][q] = P[q];
+        }
+    };
+
+    int qn = 0;
+    auto drain = [&]() {
+        const bool have = lane < qn && !(a.dbg & 2);
+        uint32_t todo = 0, row = 0, fe = 0, ge = 0, info = 0;
+        bool big = false;
+        if (have) {
+            const uint32_t tag = s_q[11][lane], ln = tag & 63u;
+            big = (tag >> 31) != 0u;
+            row = (tag & 0x7FFFFFFFu) >> 6;
+            const int Ge = strip * kSOwned + (int)ln - 1;
+            fe = (uint32_t)Ge / (uint32_t)gsep;
+            ge = (uint32_t)Ge - fe * (uint32_t)gsep;
+            info = s_q[8][lane];
+            const uint32_t mm = *reinterpret_cast<const uint32_t*>(a.mmap + (uint64_t)row * a.pitch_px + ge * 4u);
+            s_q[9][lane] = mm;
+            s_q[10][lane] = 0u;
+            if (!big) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t x = s_q[j][lane], pv = s_q[4 + j][lane];
+                    const uint32_t m = (mm >> (8 * j)) & 0xFFu;
+                    // conservative float32 signal test (b exact in 32 bits; the conversions stay far inside the 2^-16 margin of kS)
+                    const int32_t b = (int32_t)(m * pv) - (int32_t)x;
+                    const float bf = (float)b, tf = (float)x * (float)m;
+                    todo |= (bf * __builtin_fabsf(bf) > kS * tf) ? (1u << j) : 0u;
+                }
+            }
+        }
+        // groups next to a pixel >= 2^24: every valid pixel to the gather path
+        if (__ballot(big) != 0ull) {
+            if (big) {
+                for (uint32_t j = 0; j < 4; ++j) {
+                    if (!((info >> (24 + j)) & 1u)) continue;   // (byte 3 = mask bits of the centre row)
+                    const uint32_t at = atomicAdd(a.bright_n, 1u);
+                    if (at < a.bright_cap) a.bright_list[at] = make_uint2(((uint32_t)(f0 + (int)fe) << 16) | (ge * 4u + j), row);
+                }
+            }
+        }
+        int T = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool bit = (todo >> j) & 1u;
+            const unsigned long long bm = __builtin_amdgcn_ballot_w64(bit);
+            if (bit) {
+                const uint32_t pos = (uint32_t)T + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                s_list[pos] = (uint16_t)(((uint32_t)lane << 2) | (uint32_t)j);
+            }
+            T += __popcll(bm);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int base = 0; base < T; base += 64) {
+            const int idx = base + lane;
+            if (idx < T) {
+                const uint32_t ent = s_list[idx], e = ent >> 2, j = ent & 3u;
+                const uint32_t x = s_q[j][e], pv = s_q[4 + j][e];
+                const uint32_t m = (s_q[9][e] >> (8 * j)) & 0xFFu;
+                unsigned long long y = 0;   // window j = cq[j .. j+6], exact
+#pragma unroll
+                for (uint32_t t = 0; t < 7; ++t)
+                    y += ((unsigned long long)s_q[22 + j + t][e] << 32) | s_q[12 + j + t][e];
+                bool certain = false, strong = false;
+                if (y < (1ull << 46)) strong = exact_predicate_nosqrt(a, m, x, y, pv, certain);  // m y < 2^53: a exact in float64
+                if (!certain) strong = exact_predicate(a, m, x, y, pv);
+                if (strong) atomicOr(&s_q[10][e], 1u << j);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (have) {
+            const uint32_t cb = s_q[10][lane];
+            if (cb) {  // the plane is all zero when the kernel starts; a lane pair shares a byte, so OR the nibble in
+                const uint32_t x0 = ge * 4u;
+                uint32_t* plane = reinterpret_cast<uint32_t*>(a.bits + (uint64_t)(f0 + (int)fe) * a.plane_frame_stride + (uint64_t)row * a.mpitch);
+                atomicOr(plane + (x0 >> 5), cb << (x0 & 31u));
+                atomicAdd(a.tile_counts + (uint64_t)(f0 + (int)fe) * a.n_tiles + (row / (uint32_t)kTileRows), (uint32_t)__popc(cb));
+            }
+        }
+        qn = 0;
+    };
+
+#pragma unroll
+    for (int s = 0; s < KAHEAD; ++s) fetch(pre[s], s);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        uint32_t P[4];
+        unpack(pre[s], P);
+        fetch(pre[(s + KAHEAD) % 7], s + KAHEAD);
+        push(s, P);
+    }
+
+    for (int base = 6;; base += 7) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const int s = (6 + t) % 7;
+            const int sc = (s + 4) % 7;
+            const int i = base + t;
+            if (i >= total) goto rows_done;
+            {
+                uint32_t P[4];
+                const uint32_t info = pre[s].info;
+                unpack(pre[s], P);
+                fetch(pre[(s + KAHEAD) % 7], i + KAHEAD);
+                push(s, P);
+
+                // column sums c[-3..6] = L1 L2 L3 c0..c3 R0 R1 R2; every neighbour value rides on an add
+                const uint32_t s01 = col[0] + col[1], s23 = col[2] + col[3];
+                const uint32_t S = s01 + s23;
+                const uint32_t TL = dpp_shr_add(s23, S);       // L2 L3 c0..c3
+                const uint32_t TR = dpp_shl_add(s01, S);       // c0..c3 R0 R1
+                uint32_t Wn[4];
+                Wn[0] = dpp_shr_add(col[1], TL);
+                Wn[1] = dpp_shl_add(col[0], TL);
+                Wn[2] = dpp_shr_add(col[3], TR);
+                Wn[3] = dpp_shl_add(col[2], TR);
+
+                const int yout = __builtin_amdgcn_readfirstlane(yb0 + (i - 6));
+                if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, (uint32_t)yout * a.bpitch, 2);
+
+                const uint32_t xmin = min(min(min(Wn[0], Wn[1]), Wn[2]), Wn[3]);
+                const uint32_t pmax = max(max(max(ring[sc][0], ring[sc][1]), ring[sc][2]), ring[sc][3]);
+                const uint32_t mmin = (info >> 8) & 0xFFu, mmax = (info >> 16) & 0xFFu;
+                const int32_t B = (int32_t)(mmax * pmax) - (int32_t)xmin;   // (garbage when a pixel >= 2^24 is near: flagged below anyway)
+                const float bf = (float)B, tf = (float)xmin * (float)mmin;
+                const bool pass = bf * __builtin_fabsf(bf) > kS * tf;
+                // a valid pixel >= 2^24 in the 7 rows of this lane or of a neighbour
+                const uint32_t bl = bighist != 0u ? 1u : 0u;
+                bool near_big = false;
+                if (__ballot(bl != 0u) != 0ull) near_big = (bl | from_left(bl) | from_right(bl)) != 0u && mmax != 0u;
+                const bool flag = owned && (pass || near_big) && !(a.dbg & 1);
+                const unsigned long long fm = __builtin_amdgcn_ballot_w64(flag);
+                if (fm) {
+                    const int nfl = __popcll(fm);
+                    if (qn + nfl > kQCap) drain();
+                    uint32_t ql[4], qh[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) { ql[w] = (uint32_t)colq[w]; qh[w] = (uint32_t)((unsigned long long)colq[w] >> 32); }
+                    const uint32_t QL1 = from_left(ql[1]), QL2 = from_left(ql[2]), QL3 = from_left(ql[3]);
+                    const uint32_t QR0 = from_right(ql[0]), QR1 = from_right(ql[1]), QR2 = from_right(ql[2]);
+                    const uint32_t HL1 = from_left(qh[1]), HL2 = from_left(qh[2]), HL3 = from_left(qh[3]);
+                    const uint32_t HR0 = from_right(qh[0]), HR1 = from_right(qh[1]), HR2 = from_right(qh[2]);
+                    if (flag) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                        const int e = qn + (int)rank;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            s_q[w][e] = Wn[w];
+                            s_q[4 + w][e] = ring[sc][w];
+                            s_q[15 + w][e] = ql[w];
+                            s_q[25 + w][e] = qh[w];
+                        }
+                        s_q[8][e] = info;   // byte 3: mask bits of the centre row
+                        s_q[12][e] = QL1; s_q[13][e] = QL2; s_q[14][e] = QL3;
+                        s_q[19][e] = QR0; s_q[20][e] = QR1; s_q[21][e] = QR2;
+                        s_q[22][e] = HL1; s_q[23][e] = HL2; s_q[24][e] = HL3;
+                        s_q[29][e] = HR0; s_q[30][e] = HR1; s_q[31][e] = HR2;
+                        s_q[11][e] = ((uint32_t)yout << 6) | (uint32_t)lane | (near_big ? 0x80000000u : 0u);
+                    }
+                    qn += nfl;
+                }
+            }
+        }
+    }
+rows_done:
+    if (qn > 0) drain();
+}
+
+template __global__ void k_bright_fix<uint16_t>(const ThresholdArgs);
+template __global__ void k_bright_fix<uint32_t>(const ThresholdArgs);
+
 template __global__ void k_stream_u16<2>(const ThresholdArgs);
 template __global__ void k_stream_u16<3>(const ThresholdArgs);
+template __global__ void k_stream_u32<2>(const ThresholdArgs);
 
 }  // namespace ffsamd
