@@ -47,8 +47,35 @@ struct ThreadError {
     operator std::string() const { return text(); }
 };
 
+// Environment knobs (A/B switches of the measurements in DESIGN.md) are read ONCE, when a context is created:
+// nothing on the submit path calls getenv (which is not safe against a setenv in another thread of the host).
+struct Knobs {
+    int k1_variant = 2, ext_variant = 1, k1_debug = 0, k1_group = 1 << 30, k1_ahead = 2;
+    long long target_waves = 16384;
+    int emit_variant = 1, ccl_variant = 1, link_runs = 1, ccl_grid = 32, ccl_cus = 0, direct_recs = 1;
+    static int env_int(const char* name, int dflt) {
+        const char* e = std::getenv(name);
+        return e ? std::atoi(e) : dflt;
+    }
+    void read() {
+        k1_variant = env_int("FFS_K1_VARIANT", 2);
+        ext_variant = env_int("FFS_EXT_VARIANT", 1);
+        k1_debug = env_int("FFS_K1_DEBUG", 0);
+        k1_group = std::max(1, env_int("FFS_K1_GROUP", 1 << 30));
+        k1_ahead = env_int("FFS_K1_AHEAD", 2);
+        target_waves = std::max(1, env_int("FFS_K1_TARGET_WAVES", 16384));
+        emit_variant = env_int("FFS_EMIT", 1);
+        ccl_variant = env_int("FFS_CCL", 1);
+        link_runs = env_int("FFS_LINK_RUNS", 1);
+        ccl_grid = std::max(1, env_int("FFS_CCL_GRID", 32));
+        ccl_cus = env_int("FFS_CCL_CUS", 0);
+        direct_recs = env_int("FFS_DIRECT_RECS", 1);
+    }
+};
+
 struct ffs_ctx {
     int device = 0;
+    Knobs knobs;
     Layout L{};
     int pixel_bytes = 2;
     uint32_t max_batch = 1;
@@ -296,6 +323,7 @@ extern "C" int ffs_ctx_create(int device, uint32_t width, uint32_t height, int p
     ffs_ctx* c = new (std::nothrow) ffs_ctx();
     if (!c) return FFS_ERR_NOMEM;
     c->device = device;
+    c->knobs.read();
     c->pixel_bytes = pixel_bytes;
     c->max_batch = max_batch;
     Layout& L = c->L;
@@ -527,8 +555,7 @@ static int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uin
     // submitted on another ffs_stream.  Measured on MI355X (bench.py, 2 streams): 0 -> 34.4k fps,
     // 32 -> 34.9k, 64 -> 33.8k, 16 -> 21.8k: no gain worth the constraint, so it is off by default.
     {
-        int ncu = 0;
-        if (const char* e = std::getenv("FFS_CCL_CUS")) ncu = std::atoi(e);
+        const int ncu = c->knobs.ccl_cus;
         hipDeviceProp_t prop;
         STREAM_TRY(hipGetDeviceProperties(&prop, c->device));
         const int total = prop.multiProcessorCount;
@@ -578,7 +605,7 @@ static int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uin
                              hipHostMallocDefault));
     // k_finalize can write the (few MB of) records straight into this pinned, device-visible buffer:
     // no copy kernel after it.  FFS_DIRECT_RECS=0 keeps the device buffer + copy (A/B).
-    s->direct_recs = !(std::getenv("FFS_DIRECT_RECS") && std::atoi(std::getenv("FFS_DIRECT_RECS")) == 0);
+    s->direct_recs = c->knobs.direct_recs != 0;
     if (s->direct_recs
         && hipHostGetDevicePointer(reinterpret_cast<void**>(&s->h_recs_dev), s->h_recs, 0) != hipSuccess) {
         (void)hipGetLastError();
@@ -626,8 +653,7 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
     // whole number of bands per XCD.  The candidate kernels deal the bands round-robin to the 8 XCDs
     // (band = xcd + 8 k, so that neighbouring strips share an L2); with 29 bands three XCDs had a band
     // less to do than the others and the launch waited for the busy five: 511 us per 32 Eiger frames, against 430-440 us with 48 or 56.
-    long long target_waves = 16384;
-    if (const char* e = std::getenv("FFS_K1_TARGET_WAVES")) target_waves = std::max(1, std::atoi(e));
+    const long long target_waves = c->knobs.target_waves;
     {
         const long long per_band = std::max<long long>(1, (long long)c->n_strips * n_frames);
         // (bands of at least 72 rows keep the 6-row warm-up of every band below 8 %)
@@ -648,15 +674,14 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
     {   // FFS_K1_VARIANT (A/B testing): 0 = signal-test-only candidate kernel + exact kernel, 1 = signal +
         // dispersion screen in the candidate kernel + exact kernel; default 2 (16-bit pixels) = the whole
         // threshold in one streaming kernel (kernels_stream.hpp)
-        const char* v = std::getenv("FFS_K1_VARIANT");
-        a.variant = v ? std::atoi(v) : 2;
+        a.variant = c->knobs.k1_variant;
         if (s->force_variant >= 0) a.variant = std::min(a.variant, s->force_variant);
     }
     a.overflow = s->d_overflow;
     a.bright_n = s->d_tile_counts + tile_counts_bytes(s) / 4 - 1;
     a.bright_list = s->d_bright;
     a.bright_cap = kBrightCap;
-    a.dbg = std::getenv("FFS_K1_DEBUG") ? std::atoi(std::getenv("FFS_K1_DEBUG")) : 0;
+    a.dbg = c->knobs.k1_debug;
     a.ginfo = c->d_ginfo;
     a.mmap = c->d_mmap;
     a.gpitch = (uint32_t)L.pitch_px * (uint32_t)c->pixel_bytes / 4;
@@ -665,14 +690,13 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
     {   // frames side by side in one super row, as many as keep every buffer of the group below 2 GiB
         const uint64_t per_frame = std::max<uint64_t>(fstride, L.bytes_frame_stride);
         a.group_frames = (int)std::max<uint64_t>(1, std::min<uint64_t>(n_frames, ((1ull << 31) - 1) / per_frame));
-        if (const char* e = std::getenv("FFS_K1_GROUP")) a.group_frames = std::max(1, std::min(a.group_frames, std::atoi(e)));
+        a.group_frames = std::min(a.group_frames, c->knobs.k1_group);
         const int n_groups = ((int)n_frames + a.group_frames - 1) / a.group_frames;
         const long long lanes = (long long)a.group_frames * (a.gpf + 1);
         const long long lines = (long long)a.group_frames * (L.bpitch / 128);  // byte-mask lines to zero per row
         const int lines_per_wave = c->pixel_bytes == 2 ? 4 : 2;  // a wave zero-fills 512 / 256 bytes of the byte mask per row
         a.s_strips = (int)std::max<long long>((lanes + kSOwned - 1) / kSOwned, (lines + lines_per_wave - 1) / lines_per_wave);
-        long long tw = 16384;
-        if (const char* e = std::getenv("FFS_K1_TARGET_WAVES")) tw = std::max(1, std::atoi(e));
+        const long long tw = c->knobs.target_waves;
         const long long per_band = std::max<long long>(1, (long long)a.s_strips * n_groups);
         long long nb = std::max<long long>(1, std::min<long long>(tw / per_band, L.H / 72));
         if (nb >= 8) nb = nb / 8 * 8;
@@ -683,8 +707,7 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
     a.eplane = s->d_eplane;
     a.ext_flavour = p.extended_flavour;
     {
-        const char* v = std::getenv("FFS_EXT_VARIANT");
-        a.ext_variant = v ? std::atoi(v) : 1;
+        a.ext_variant = c->knobs.ext_variant;
     }
     a.ext_strips = (L.pitch_px + kExtOwnedPx - 1) / kExtOwnedPx;
     {   // one pixel per lane: bands of 64..256 rows keep the 6-row warm-up below 10 %
@@ -757,7 +780,7 @@ static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_
         (void)hipMemsetAsync(a.tile_counts, 0, tile_counts_bytes(s), s->st);  // + the bright-list count (last word)
         const int bands8s = (b.n_bands + 7) / 8 * 8;
         const unsigned n_groups = (n_frames + (unsigned)a.group_frames - 1) / (unsigned)a.group_frames;
-        const int ahead = std::getenv("FFS_K1_AHEAD") ? std::atoi(std::getenv("FFS_K1_AHEAD")) : 2;
+        const int ahead = s->ctx->knobs.k1_ahead;
         if (s->ctx->pixel_bytes == 4) {
             hipLaunchKernelGGL(k_stream_u32<2>, dim3((unsigned)(b.n_strips * bands8s), n_groups), dim3(64), 0, s->st, b);
             hipLaunchKernelGGL(k_bright_fix<uint32_t>, dim3(32), dim3(256), 0, s->st, b);
@@ -877,7 +900,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     ca.bytes_frame_stride = L.bytes_frame_stride;
     // FFS_CCL (A/B): 1 (default) = accumulators at the root, 4 launches (emit, union, reduce, finalize) and 40-byte
     // records on the wire; 0 = numbered components (count, label, reduce, finalize), 56-byte records
-    static const int ccl_variant = std::getenv("FFS_CCL") ? std::atoi(std::getenv("FFS_CCL")) : 1;
+    const int ccl_variant = c->knobs.ccl_variant;
     const bool root_mode = ccl_variant >= 1 && L.H <= 65535;
     ca.acc2 = root_mode ? s->d_acc2 : nullptr;
     ca.n_comp = s->d_n_comp;
@@ -890,7 +913,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     // offset by a decoupled look-back over the tiles before it -- 263 us against 87 + 4 + 63 us for
     // the then three kernels: tiles that wait for a predecessor's count hold their CU slots.)
     // FFS_EMIT (A/B): 1 (default) = one wave per tile, runs linked in the same pass; 0 = one workgroup per tile + k_link_runs
-    static const int emit_variant = std::getenv("FFS_EMIT") ? std::atoi(std::getenv("FFS_EMIT")) : 1;
+    const int emit_variant = c->knobs.emit_variant;
     if (emit_variant >= 1 || root_mode) {
         if (c->pixel_bytes == 2)
             hipLaunchKernelGGL(k_emit_list_w<uint16_t>, dim3(c->n_tiles, n), dim3(64), 0, s->st2, ca);
@@ -921,10 +944,9 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     sa.max_sep = p.max_peak_centroid_separation;
     sa.recs = s->direct_recs ? s->h_recs_dev : s->d_recs;
     sa.summary = s->d_summary;
-    int gx = 32;
-    if (const char* e = std::getenv("FFS_CCL_GRID")) gx = std::max(1, std::atoi(e));
+    const int gx = c->knobs.ccl_grid;
     const dim3 gseg((unsigned)gx, n), b256(256);
-    static const int link_runs = std::getenv("FFS_LINK_RUNS") ? std::atoi(std::getenv("FFS_LINK_RUNS")) : 1;
+    const int link_runs = c->knobs.link_runs;
     sa.runs_linked = (emit_variant >= 1 || root_mode) ? 2 : link_runs;
     sa.acc2 = s->d_acc2;
     sa.chunk_roots = s->d_chunk_roots;
@@ -1823,6 +1845,8 @@ static RcclApi g_rccl;
 static std::vector<int> g_comm_devices;     // distinct devices, rank = position
 static std::vector<ncclComm_t> g_comms;     // one communicator per rank (ncclCommInitAll)
 static std::string g_multi_transport = "none";
+static std::string g_gather_want = "rccl";  // FFS_GATHER / the transport argument, as given to ffs_multi_init
+static bool g_gather_forced = false;          // ... explicitly (then RCCL is used even between contexts on one GPU)
 
 static int comm_rank_of(int device) {
     for (size_t r = 0; r < g_comm_devices.size(); ++r)
@@ -1837,6 +1861,8 @@ extern "C" int ffs_multi_init(const int* devices, int n_devices, const char* tra
     for (int i = 0; i < n_devices; ++i)
         if (std::find(distinct.begin(), distinct.end(), devices[i]) == distinct.end()) distinct.push_back(devices[i]);
     const std::string want = transport ? transport : (std::getenv("FFS_GATHER") ? std::getenv("FFS_GATHER") : "rccl");
+    g_gather_forced = transport != nullptr || std::getenv("FFS_GATHER") != nullptr;
+    g_gather_want = want;
     if (!g_comms.empty() && distinct == g_comm_devices) return FFS_OK;
     if (!g_comms.empty() && g_rccl.CommDestroy) {
         for (ncclComm_t cm : g_comms) (void)g_rccl.CommDestroy(cm);
@@ -1911,9 +1937,8 @@ static int stack3d_add_batch_remote(ffs_stack3d* st, ffs_stream* s, uint64_t mor
     uint32_t* dst_i = st->a_i.p + st->arrived;
     std::lock_guard<std::mutex> lock(g_multi_mu);
     const int r_src = comm_rank_of(sc->device), r_home = comm_rank_of(c->device);
-    const char* forced = std::getenv("FFS_GATHER");
-    const bool use_rccl = !g_comms.empty() && r_src >= 0 && r_home >= 0 && !(forced && std::string(forced) != "rccl")
-                          && (sc->device != c->device || (forced && std::string(forced) == "rccl"));
+    const bool use_rccl = !g_comms.empty() && r_src >= 0 && r_home >= 0 && g_gather_want == "rccl"
+                          && (sc->device != c->device || g_gather_forced);
     if (more == 0) {
         STK_TRY(c, hipStreamSynchronize(s->st2));
         return FFS_OK;

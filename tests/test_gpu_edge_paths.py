@@ -8,7 +8,7 @@ from util import assert_frame_matches_oracle, make_frame
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant", ["0", "1"])
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
 @pytest.mark.parametrize("kind", ["single_photons", "uniform_noise", "stripes", "saturated_blocks"])
 def test_dense_candidate_frames(ffs, kind, variant, monkeypatch):
     monkeypatch.setenv("FFS_K1_VARIANT", variant)

@@ -120,7 +120,7 @@ def test_config1_plumbing_frames(ffs):
         assert cc.num_strong_pixels > 500
 
 
-@pytest.mark.parametrize("variant", ["0", "1"])
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
 def test_candidate_kernel_variants(ffs, variant, monkeypatch):
     """Both candidate-kernel variants (per-pixel test / group screen + LDS queue) must give the
     oracle's result; frames chosen so the lane-group queue wraps many times per wave."""

@@ -32,29 +32,39 @@ def main():
     W, H, dt, bpp = WORKLOADS[args.workload]
     frames, mask = make_inputs(args.workload, args.unique, 0)
     B = args.batch
-    ctx = ffs_amd.Context(W, H, dt, max_batch=B)
-    ctx.set_mask(mask)
-    ctx.set_params(algorithm=1 if args.algorithm == "dispersion_extended" else 0)
+    def make_ctx():
+        c = ffs_amd.Context(W, H, dt, max_batch=B)
+        c.set_mask(mask)
+        c.set_params(algorithm=1 if args.algorithm == "dispersion_extended" else 0)
+        return c
+
+    ctx = make_ctx()
     pitch, fstride = ctx.device_layout()
     host = np.zeros((B, H, pitch // np.dtype(dt).itemsize), dt)
     for i in range(B):
         host[i, :, :W] = frames[i % len(frames)]
     d = torch.from_numpy(host.view(np.uint8).reshape(-1)).cuda()
-    st = ctx.stream()
     alg = float(W) * H * bpp * B
     variants = [int(v) for v in args.variants.split(",")]
     if args.decode:
         from ffs_amd import bslz4
+        st = ctx.stream()
         uniq = [np.frombuffer(bslz4.compress(f), np.uint8) for f in frames]
         chunks = [uniq[i % len(uniq)] for i in range(B)]
         ms, _ = st.decode_only(chunks, iters=args.iters, want_frames=False)
         raw = float(W) * H * np.dtype(dt).itemsize * B
         print(f"decode: {ms*1e3:.1f} us/launch, {raw/ms/1e6:.0f} GB/s of pixels written, "
               f"{sum(c.size for c in chunks)/ms/1e6:.0f} GB/s of chunks read, batch {B}", flush=True)
+        del st
+    # the knobs are read when a context is created: one context (and stream) per variant
+    streams = {}
+    for v in variants:
+        os.environ["FFS_K1_VARIANT"] = str(v)
+        c = make_ctx()
+        streams[v] = (c, c.stream())
     for rnd in range(args.rounds):          # interleaved A/B rounds in one process
         for v in variants:
-            os.environ["FFS_K1_VARIANT"] = str(v)
-            a, b = st.bench_threshold(d.data_ptr(), pitch, fstride, B, args.iters)
+            a, b = streams[v][1].bench_threshold(d.data_ptr(), pitch, fstride, B, args.iters)
             print(f"round {rnd} variant {v}: k_candidates {a*1e3:.1f} us/launch ({alg/a/1e6:.0f} GB/s algorithmic, "
                   f"{alg/a/1e6/8000:.3f} of 8 TB/s), k_exact {b*1e3:.1f} us/launch, batch {B}", flush=True)
 
