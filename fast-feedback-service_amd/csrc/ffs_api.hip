@@ -53,6 +53,7 @@ struct Knobs {
     int k1_variant = 2, ext_variant = 1, k1_debug = 0, k1_group = 1 << 30, k1_ahead = 2;
     long long target_waves = 16384;
     int emit_variant = 1, ccl_variant = 1, link_runs = 1, ccl_grid = 32, ccl_cus = 0, direct_recs = 1;
+    int bright_cap = 1 << 20;  // FFS_BRIGHT_CAP: entries of the bright-window list actually used (tests shrink it)
     static int env_int(const char* name, int dflt) {
         const char* e = std::getenv(name);
         return e ? std::atoi(e) : dflt;
@@ -70,6 +71,7 @@ struct Knobs {
         ccl_grid = std::max(1, env_int("FFS_CCL_GRID", 32));
         ccl_cus = env_int("FFS_CCL_CUS", 0);
         direct_recs = env_int("FFS_DIRECT_RECS", 1);
+        bright_cap = std::max(0, std::min(1 << 20, env_int("FFS_BRIGHT_CAP", 1 << 20)));
     }
 };
 
@@ -680,7 +682,7 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
     a.overflow = s->d_overflow;
     a.bright_n = s->d_tile_counts + tile_counts_bytes(s) / 4 - 1;
     a.bright_list = s->d_bright;
-    a.bright_cap = kBrightCap;
+    a.bright_cap = std::min<uint32_t>(kBrightCap, (uint32_t)c->knobs.bright_cap);
     a.dbg = c->knobs.k1_debug;
     a.ginfo = c->d_ginfo;
     a.mmap = c->d_mmap;

@@ -169,3 +169,27 @@ def test_default_capacity_overflow_full_size_lists(ffs):
     assert res[1].num_strong_pixels > (1 << 18)
     for fr, img in zip(res, (normal, dense)):
         assert_frame_matches_oracle(fr, img, mask)
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.uint32])
+def test_bright_window_list_overflow_falls_back(ffs, dtype, monkeypatch):
+    """Windows whose sums leave the streaming kernel's exact range (16-bit: sum p >= 65536; 32-bit: a pixel
+    >= 2^24 nearby) go onto a list for the gather kernel.  With the list shrunk to 8 entries it overflows, and
+    the batch must come back right all the same (re-run through the two-kernel path inside ffs_wait)."""
+    monkeypatch.setenv("FFS_BRIGHT_CAP", "8")
+    rng = np.random.default_rng(12)
+    H, W = 240, 400
+    img = rng.poisson(3.0, (H, W)).astype(dtype)
+    top = 65535 if dtype == np.uint16 else (1 << 24) + 1000
+    for _ in range(40):
+        y, x = rng.integers(0, H - 6), rng.integers(0, W - 6)
+        img[y:y + rng.integers(1, 5), x:x + rng.integers(1, 5)] = rng.integers(top // 2, top + 1)
+    mask = (rng.random((H, W)) > 0.01).astype(np.uint8)
+    ctx = ffs.Context(W, H, dtype, max_batch=2)
+    ctx.set_mask(mask)
+    ctx.set_params(want_strong_mask=1, want_strong_list=1)
+    st = ctx.stream()
+    for fr, im in zip(st.process(np.stack([img, img[::-1].copy()])), (img, img[::-1])):
+        assert_frame_matches_oracle(fr, im, mask)
+    quiet = rng.poisson(3.0, (H, W)).astype(dtype)       # and the stream is fine afterwards
+    assert_frame_matches_oracle(st.process(quiet[None])[0], quiet, mask)
