@@ -43,7 +43,7 @@ namespace ffsamd {
 
 constexpr int kSOwned = 62;          // lanes 1..62 own output; lanes 0 and 63 are halo
 constexpr int kSQWords = 32;         // queue entry: 0-7 window sums, 8-11 centre pixels (two per word), 12-13 window counts,
-                                     // 14 result bits, 16-29 column sums of p^2, 30 tag
+                                     // 14 result bits, 15 ginfo, 16-29 column sums of p^2, 30 tag
 constexpr int kInfoExtraRows = 3;    // ginfo row y carries the mask bits of row y and the counts of row y - 3
 
 // ---- tables that depend on the mask alone -------------------------------------------------------------
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     }
 
     const int total = (yb1 - yb0) + 6;  // incoming rows yb0-3 .. yb1+2
-    const float kS = a.kS, kB = a.kB;
+    const float kS = a.kS;
 
     uint32_t ring[7][4];   // masked pixels of the last seven rows, two per register as loaded
     uint32_t col[8], colq[8];
@@ -296,7 +296,13 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
             const int Ge = strip * kSOwned + (int)ln - 1;
             fe = (uint32_t)Ge / (uint32_t)gsep;
             ge = (uint32_t)Ge - fe * (uint32_t)gsep;
-            const uint2 mm = *reinterpret_cast<const uint2*>(a.mmap + (uint64_t)row * a.pitch_px + ge * 8u);
+            // window counts of the eight pixels: one value for the whole group almost everywhere (then ginfo has it);
+            // only groups next to masked pixels fetch their eight counts -- a dependent global round trip at the head
+            // of the drain that most waves now never pay
+            const uint32_t ginf = s_q[15][lane];
+            const uint32_t gmin = (ginf >> 8) & 0xFFu, gmax = (ginf >> 16) & 0xFFu;
+            uint2 mm = make_uint2(gmin * 0x01010101u, gmin * 0x01010101u);
+            if (gmin != gmax) mm = *reinterpret_cast<const uint2*>(a.mmap + (uint64_t)row * a.pitch_px + ge * 8u);
             s_q[12][lane] = mm.x;
             s_q[13][lane] = mm.y;
             s_q[14][lane] = 0u;
@@ -446,6 +452,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                         }
 #pragma unroll
                         for (int w = 0; w < 4; ++w) s_q[8 + w][e] = ring[sc][w];
+                        s_q[15][e] = info;
                         s_q[16][e] = QL5; s_q[17][e] = QL6; s_q[18][e] = QL7;
                         s_q[27][e] = QR0; s_q[28][e] = QR1; s_q[29][e] = QR2;
                         s_q[30][e] = ((uint32_t)yout << 6) | (uint32_t)lane;
