@@ -862,7 +862,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     const bool one_kernel = ta.variant >= 2 && p.algorithm != FFS_ALGO_DISPERSION_EXTENDED;
     if (one_kernel && s->bits_dirty)  // (another algorithm / variant or a failed batch left bits behind)
         HIP_TRY(c, hipMemsetAsync(s->d_bits, 0, (size_t)s->max_batch * L.plane_frame_stride, s->st));
-    s->bits_dirty = !one_kernel;
+    s->bits_dirty = true;  // until every launch of this batch is enqueued (a failure in between leaves bits behind)
     if (p.algorithm == FFS_ALGO_DISPERSION_EXTENDED) {
         launch_extended(s, ta, n);
     } else {
@@ -979,6 +979,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
                                   hipMemcpyDeviceToHost, s->st2));
     }
     HIP_TRY(c, hipEventRecord(s->ev[4], s->st2));
+    s->bits_dirty = !one_kernel;  // the compaction of a one-kernel batch leaves the plane all zero again
     s->busy = true;
     s->n_frames = n;
     return FFS_OK;

@@ -159,7 +159,8 @@ int ffs_submit(ffs_stream *s, const void *host_pixels, uint32_t n_frames,
                int64_t first_frame_id);
 /* Same, frames already in device memory (rows pitch_bytes apart, frames frame_stride_bytes
  * apart; pitch_bytes a multiple of 16).  For producers that decode on the GPU, and for bench.py's
- * resident-in-HBM measurement. */
+ * resident-in-HBM measurement.  The pixels must stay valid and unchanged until ffs_wait() has returned
+ * (a frame that exceeds the stream's list capacity is read a second time there). */
 int ffs_submit_device(ffs_stream *s, const void *device_pixels, size_t pitch_bytes,
                       size_t frame_stride_bytes, uint32_t n_frames, int64_t first_frame_id);
 /* Device layout this context prefers for ffs_submit_device (and uses internally). */

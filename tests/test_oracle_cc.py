@@ -138,3 +138,94 @@ def test_partition_matches_scipy_label_3d(seed):
     assert r.n_calculated == n
     sizes = sorted(int((lab == i).sum()) for i in range(1, n + 1))
     assert sorted(int(x) for x in r.reflections["num_pixels"]) == sizes
+
+
+def _helix_components(vol):
+    """Independent formulation of the reference's graph INCLUDING its row-wrap edge: strong pixels of each slice
+    as a 1D sequence (linear index k = y W + x), edges k -- k+1 (no row-end check, connected_components.cc:62-70),
+    k -- k+W, and the same k in the next slice (:352-370); components by scipy's sparse-graph labelling; numbered
+    in order of their smallest (z, k) vertex (Boost's DFS discovery order over ascending vertex ids)."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    Z, H, W = vol.shape
+    flat = vol.reshape(Z, H * W) != 0
+    ids = -np.ones((Z, H * W), np.int64)
+    n = 0
+    for z in range(Z):
+        on = np.flatnonzero(flat[z])
+        ids[z, on] = np.arange(n, n + len(on))
+        n += len(on)
+    src, dst = [], []
+    for z in range(Z):
+        a = ids[z]
+        for step in (1, W):                        # k+1 joins (W-1, y) with (0, y+1) too
+            both = (a[:-step] >= 0) & (a[step:] >= 0)
+            src.append(a[:-step][both]); dst.append(a[step:][both])
+        if z + 1 < Z:
+            both = (a >= 0) & (ids[z + 1] >= 0)
+            src.append(a[both]); dst.append(ids[z + 1][both])
+    src, dst = np.concatenate(src), np.concatenate(dst)
+    g = coo_matrix((np.ones(len(src), np.int8), (src, dst)), shape=(n, n))
+    _, lab = connected_components(g, directed=False)
+    first = np.full(lab.max() + 1 if n else 0, n, np.int64)
+    np.minimum.at(first, lab, np.arange(n))
+    order = np.argsort(first)                      # label order = order of the smallest vertex
+    rank = np.empty_like(order); rank[order] = np.arange(len(order))
+    return ids, rank[lab] if n else lab
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_row_wrap_edge_and_label_order_against_a_graph_formulation_2d(seed):
+    """The row-wrap quirk and the label order, which the scipy.ndimage comparison above has to leave out, against
+    an independent sparse-graph formulation."""
+    rng = np.random.default_rng(200 + seed)
+    H, W = int(rng.integers(4, 40)), int(rng.integers(3, 40))
+    res = (rng.random((H, W)) < rng.uniform(0.2, 0.6)).astype(np.uint8)
+    res[:, -1] |= (rng.random(H) < 0.7)            # plenty of pixels in the last column ...
+    res[:, 0] |= (rng.random(H) < 0.7)             # ... and the first: many wrap edges
+    img = rng.integers(1, 500, (H, W)).astype(np.uint16)
+    cc = O.cc2d(res, img, 1)
+    ids, lab = _helix_components(res[None])
+    n = int(lab.max()) + 1 if len(lab) else 0
+    assert cc.n_unfiltered_boxes == n == len(cc.boxes)
+    k_on = np.flatnonzero(res.reshape(-1))
+    ys, xs = np.divmod(k_on, W)
+    wrapped = 0
+    for i, b in enumerate(cc.boxes):               # boxes come in label order
+        sel = lab == i
+        assert b["num_pixels"] == int(sel.sum())
+        assert (b["l"], b["r"], b["t"], b["b"]) == (xs[sel].min(), xs[sel].max(), ys[sel].min(), ys[sel].max())
+        wrapped += int(b["l"] == 0 and b["r"] == W - 1)
+    # the same frame WITHOUT the wrap edges has more components whenever a wrap edge joins two of them
+    lab4, n4 = ndimage.label(res, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+    assert n <= n4
+    if seed == 0:
+        assert n < n4 and wrapped > 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_row_wrap_edge_and_label_order_against_a_graph_formulation_3d(seed):
+    rng = np.random.default_rng(300 + seed)
+    Z, H, W = int(rng.integers(2, 7)), int(rng.integers(4, 20)), int(rng.integers(3, 20))
+    vol = (rng.random((Z, H, W)) < 0.3).astype(np.uint8)
+    vol[:, :, -1] |= (rng.random((Z, H)) < 0.5)
+    vol[:, :, 0] |= (rng.random((Z, H)) < 0.5)
+    slices = []
+    for z in range(Z):
+        k = np.flatnonzero(vol[z]).astype(np.uint64)
+        slices.append((k, (1 + (k % 7)).astype(np.uint32)))
+    r = O.cc3d(slices, W, H, 1, 0.0)
+    ids, lab = _helix_components(vol)
+    n = int(lab.max()) + 1
+    assert r.n_calculated == n == len(r.reflections)
+    zz = np.concatenate([np.full(len(k), z) for z, (k, _) in enumerate(slices)])
+    kk = np.concatenate([k for k, _ in slices]).astype(np.int64)
+    inten = np.concatenate([i for _, i in slices]).astype(np.float64)
+    for i, rf in enumerate(r.reflections):          # reflections come in label order
+        sel = lab == i
+        assert rf["num_pixels"] == int(sel.sum())
+        assert (rf["z_min"], rf["z_max"]) == (zz[sel].min(), zz[sel].max())
+        assert (rf["x_min"], rf["x_max"]) == ((kk[sel] % W).min(), (kk[sel] % W).max())
+        w = inten[sel]
+        assert abs(rf["com_z"] - ((zz[sel] + 0.5) * w).sum() / w.sum()) < 1e-4
+    assert np.array_equal(O.cc3d_signals(slices, W, H, 1, 0.0), lab)   # every signal's reflection
