@@ -50,7 +50,7 @@ struct ThreadError {
 // Environment knobs (A/B switches of the measurements in DESIGN.md) are read ONCE, when a context is created:
 // nothing on the submit path calls getenv (which is not safe against a setenv in another thread of the host).
 struct Knobs {
-    int k1_variant = 2, ext_variant = 1, k1_debug = 0, k1_group = 1 << 30, k1_ahead = 2;
+    int k1_variant = 2, ext_variant = 2, k1_debug = 0, k1_group = 1 << 30, k1_ahead = 2;
     long long target_waves = 16384;
     int emit_variant = 1, ccl_variant = 1, link_runs = 1, ccl_grid = 32, ccl_cus = 0, direct_recs = 1;
     int bright_cap = 1 << 20;  // FFS_BRIGHT_CAP: entries of the bright-window list actually used (tests shrink it)
@@ -60,7 +60,7 @@ struct Knobs {
     }
     void read() {
         k1_variant = env_int("FFS_K1_VARIANT", 2);
-        ext_variant = env_int("FFS_EXT_VARIANT", 1);
+        ext_variant = env_int("FFS_EXT_VARIANT", 2);
         k1_debug = env_int("FFS_K1_DEBUG", 0);
         k1_group = std::max(1, env_int("FFS_K1_GROUP", 1 << 30));
         k1_ahead = env_int("FFS_K1_AHEAD", 2);
@@ -728,9 +728,28 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
 // dispersion test on its candidates (ext_variant 1, default); k_ext_first is the plain one-pixel-
 // per-lane kernel that computes the same plane directly (32-bit pixels, and FFS_EXT_VARIANT=0).
 static bool ext_fast_first(const ffs_stream* s, const ThresholdArgs& a) {
-    return s->ctx->pixel_bytes == 2 && a.ext_variant == 1;
+    return s->ctx->pixel_bytes == 2 && a.ext_variant >= 1;
+}
+// FFS_EXT_VARIANT (16-bit pixels): 2 (default) = k_stream_u16<.., true>, the streaming kernel deciding the first pass
+// exactly in its drain; 1 = round 1's candidate kernel in extended mode + exact kernel; 0 = k_ext_first.
+static bool ext_stream_first(const ffs_stream* s, const ThresholdArgs& a) {
+    return s->ctx->pixel_bytes == 2 && a.ext_variant >= 2;
 }
 static void launch_ext_first(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
+    if (ext_stream_first(s, a)) {
+        ThresholdArgs b = a;
+        b.n_strips = a.s_strips;
+        b.band_rows = a.s_band_rows;
+        b.n_bands = a.s_bands;
+        // the kernel writes the non-zero bytes of the first-pass plane; the bright-list count sits behind the tile counts
+        (void)hipMemsetAsync(a.dplane, 0, (size_t)n_frames * a.plane_frame_stride, s->st);
+        (void)hipMemsetAsync(a.tile_counts, 0, tile_counts_bytes(s), s->st);
+        const int bands8s = (b.n_bands + 7) / 8 * 8;
+        const unsigned n_groups = (n_frames + (unsigned)a.group_frames - 1) / (unsigned)a.group_frames;
+        hipLaunchKernelGGL((k_stream_u16<2, true>), dim3((unsigned)(b.n_strips * bands8s), n_groups), dim3(64), 0, s->st, b);
+        hipLaunchKernelGGL((k_bright_fix<uint16_t, true>), dim3(32), dim3(256), 0, s->st, b);
+        return;
+    }
     if (ext_fast_first(s, a)) {
         // a.bits collects the positives the streaming kernel could not settle: zero it, the drain fills it
         (void)hipMemsetAsync(a.bits, 0, (size_t)n_frames * a.plane_frame_stride, s->st);
@@ -745,7 +764,9 @@ static void launch_ext_first(ffs_stream* s, const ThresholdArgs& a, uint32_t n_f
 }
 static void launch_ext_rest(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
     const bool u16 = s->ctx->pixel_bytes == 2;
-    if (ext_fast_first(s, a))  // (the candidate kernel also zero-filled the byte mask)
+    if (ext_stream_first(s, a)) {
+        // (the streaming kernel zero-filled the byte mask and left the exact first-pass plane)
+    } else if (ext_fast_first(s, a))  // (the candidate kernel also zero-filled the byte mask)
         hipLaunchKernelGGL(k_exact_disp<uint16_t>, dim3((unsigned)a.n_tiles, n_frames), dim3(256), 0, s->st, a);
     else
         (void)hipMemsetAsync(a.strong_bytes, 0, (size_t)n_frames * a.bytes_frame_stride, s->st);

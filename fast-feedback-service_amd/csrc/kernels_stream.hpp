@@ -157,6 +157,31 @@ __device__ __forceinline__ bool exact_predicate_nosqrt(const ThresholdArgs& a, u
     return disp_yes && sig_yes;
 }
 
+// First pass of the extended algorithm (baseline.cpp:468-473): the dispersion half alone, a > c, for a valid
+// centre with at least min_count pixels in its window (and, with the device kernels' rule, a centre pixel not
+// above max_valid).  Square-root-free with the same certification as above; dispersion_only() is the fall-back.
+__device__ __forceinline__ bool dispersion_only(const ThresholdArgs& a, uint32_t m, unsigned long long sx, unsigned long long sy) {
+    const double md = (double)m, xd = (double)sx, yd = (double)sy;
+    const double t0 = md * yd;
+    const double t1 = xd * xd;
+    const double t2 = xd * (md - 1.0);
+    const double av = (t0 - t1) - t2;
+    const double cv = (xd * a.nsig_b) * __builtin_sqrt(2.0 * (md - 1.0));
+    return av > cv;
+}
+__device__ __forceinline__ bool dispersion_only_nosqrt(const ThresholdArgs& a, uint32_t m, unsigned long long sx, unsigned long long sy,
+                                                       bool& certain) {
+    certain = true;
+    const double md = (double)m, xd = (double)sx, yd = (double)sy;
+    const double av = (md * yd - xd * xd) - xd * (md - 1.0);
+    if (!(av > 0.0)) return false;  // c >= 0
+    const double a2 = av * av, c2 = (a.nsig_b2 * (xd * xd)) * (2.0 * (md - 1.0));
+    constexpr double kEps = 9.094947017729282e-13;  // 2^-40
+    const bool yes = a2 > c2 + c2 * kEps, no = a2 < c2 - c2 * kEps;
+    certain = yes || no;
+    return yes;
+}
+
 __device__ __forceinline__ uint32_t dpp_shr_add(uint32_t from_neighbour, uint32_t addend) {
     // addend + (value of lane - 1); lane 0 adds 0
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)from_neighbour, 0x138, 0xf, 0xf, true) + addend;
@@ -170,7 +195,11 @@ struct RowRegsS {
     uint32_t info;  // ginfo dword
 };
 
-template <int KAHEAD>
+// EXT = true: the first pass of the extended algorithm.  Same stream, ring, sums and queue; the group screen is a
+// float32 upper bound of a = m y - x^2 - x (m - 1) against a lower bound of c (largest sum p^2 and smallest sum p of
+// the group's eight windows), the drain decides "dispersion above background" exactly for every valid pixel of a
+// queued group, and the plane written (its non-zero bytes; the host zeroes it before the launch) is a.dplane.
+template <int KAHEAD, bool EXT = false>
 __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     __shared__ uint32_t s_q[kSQWords][kQCap];
     __shared__ uint16_t s_list[kQCap * 8];  // drain: (queue entry << 3 | pixel) of every candidate pixel
@@ -199,7 +228,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     const rsrc_t r_info = make_rsrc(a.ginfo, (uint32_t)(a.H + kInfoExtraRows) * a.gpitch);
     const rsrc_t r_sb = make_rsrc(a.strong_bytes + (uint64_t)f0 * a.bytes_frame_stride,
                                   (uint32_t)((uint64_t)nf * a.bytes_frame_stride));
-    const rsrc_t r_cb = make_rsrc(a.bits + (uint64_t)f0 * a.plane_frame_stride, (uint32_t)((uint64_t)nf * a.plane_frame_stride));
+    const rsrc_t r_cb = make_rsrc((EXT ? a.dplane : a.bits) + (uint64_t)f0 * a.plane_frame_stride, (uint32_t)((uint64_t)nf * a.plane_frame_stride));
     constexpr uint32_t kOob = 0x80000000u;  // offsets with bit 31 set are out of range for every resource (all < 2 GiB)
     const uint32_t off_px = active ? (uint32_t)((uint64_t)fl * a.frame_stride) + (uint32_t)g * 16u : kOob;
     const uint32_t off_info = active ? (uint32_t)g * 4u : kOob;
@@ -306,16 +335,42 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
             s_q[12][lane] = mm.x;
             s_q[13][lane] = mm.y;
             s_q[14][lane] = 0u;
+            if constexpr (EXT) {
+                // every VALID pixel of the group with enough pixels in its window (and a centre not above max_valid,
+                // the device kernels' rule) takes the exact test: the screen already was the dispersion bound
+                const uint32_t valid = ginf >> 24;
+                uint32_t wq = 0;  // window j sums cq[j .. j+6]
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t x = s_q[j][lane];
-                const uint32_t pw = s_q[8 + (j >> 1)][lane];
-                const uint32_t pv = (j & 1) ? pw >> 16 : pw & 0xFFFFu;
-                const uint32_t m = ((j < 4 ? mm.x : mm.y) >> (8 * (j & 3))) & 0xFFu;
-                //   oracle: b = m p - x > nsig_s sqrt(x m);  here: b |b| > nsig_s^2 (1 - 2^-16) x m in float32
-                const int32_t b = (int32_t)__umul24(m, pv) - (int32_t)x;
-                const float bf = (float)b, tf = (float)__umul24(x, m);
-                todo |= (bf * __builtin_fabsf(bf) > kS * tf) ? (1u << j) : 0u;
+                for (int t = 0; t < 7; ++t) wq += s_q[16 + t][lane];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t x = s_q[j][lane];
+                    const uint32_t pw = s_q[8 + (j >> 1)][lane];
+                    const uint32_t pv = (j & 1) ? pw >> 16 : pw & 0xFFFFu;
+                    const uint32_t m = ((j < 4 ? mm.x : mm.y) >> (8 * (j & 3))) & 0xFFu;
+                    // the pixel's own conservative float32 form first (its count this time, not the group's bounds):
+                    // only what it cannot reject takes the float64 test
+                    const float mf = (float)m, xf = (float)x, yf = (float)wq;
+                    const float t0 = mf * yf;
+                    const float af = t0 - xf * (xf + (mf - 1.0f));
+                    const float cf = xf * (a.kB * __builtin_amdgcn_sqrtf(2.0f * (mf - 1.0f)));
+                    const bool maybe = (af + t0 * 9.5367431640625e-07f >= cf) || x >= 65536u;
+                    const bool ok = ((valid >> j) & 1u) && (int)m >= a.min_count && !(a.max_valid >= 0 && (long long)pv > a.max_valid);
+                    todo |= (ok && maybe) ? (1u << j) : 0u;
+                    if (j < 7) wq = wq - s_q[16 + j][lane] + s_q[23 + j][lane];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t x = s_q[j][lane];
+                    const uint32_t pw = s_q[8 + (j >> 1)][lane];
+                    const uint32_t pv = (j & 1) ? pw >> 16 : pw & 0xFFFFu;
+                    const uint32_t m = ((j < 4 ? mm.x : mm.y) >> (8 * (j & 3))) & 0xFFu;
+                    //   oracle: b = m p - x > nsig_s sqrt(x m);  here: b |b| > nsig_s^2 (1 - 2^-16) x m in float32
+                    const int32_t b = (int32_t)__umul24(m, pv) - (int32_t)x;
+                    const float bf = (float)b, tf = (float)__umul24(x, m);
+                    todo |= (bf * __builtin_fabsf(bf) > kS * tf) ? (1u << j) : 0u;
+                }
             }
             if (a.dbg & 4) todo = 0;
         }
@@ -343,8 +398,14 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
 #pragma unroll
                     for (uint32_t t = 0; t < 7; ++t) y += s_q[16 + j + t][e];
                     bool certain;
-                    bool strong = exact_predicate_nosqrt(a, m, x, y, pv, certain);
-                    if (!certain) strong = exact_predicate(a, m, x, y, pv);
+                    bool strong;
+                    if constexpr (EXT) {
+                        strong = dispersion_only_nosqrt(a, m, x, y, certain);
+                        if (!certain) strong = dispersion_only(a, m, x, y);
+                    } else {
+                        strong = exact_predicate_nosqrt(a, m, x, y, pv, certain);
+                        if (!certain) strong = exact_predicate(a, m, x, y, pv);
+                    }
                     if (strong) atomicOr(&s_q[14][e], 1u << j);
                 } else {
                     // sum p^2 may not fit 32 bits: k_bright_fix gathers the window and decides (rare)
@@ -362,7 +423,8 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
             const uint32_t cb = s_q[14][lane];
             if (cb) {  // the plane is all zero when the kernel starts (the compaction clears what it consumed)
                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)cb, r_cb, (uint32_t)((uint64_t)fe * a.plane_frame_stride) + ge, row * a.mpitch, 0);
-                atomicAdd(a.tile_counts + (uint64_t)(f0 + (int)fe) * a.n_tiles + (row / (uint32_t)kTileRows), (uint32_t)__popc(cb));
+                if constexpr (!EXT)  // (the extended algorithm's final pass counts its own strong pixels)
+                    atomicAdd(a.tile_counts + (uint64_t)(f0 + (int)fe) * a.n_tiles + (row / (uint32_t)kTileRows), (uint32_t)__popc(cb));
             }
         }
         qn = 0;
@@ -420,19 +482,49 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                 // candidate (kS = nsig_s^2 (1 - 2^-16): float32 rounding cannot turn a true pass into a fail)
                 // (three-operand chains: four v_min3 / v_max3 class instructions each instead of five)
                 const uint32_t xmin = min(min(min(min(Wn[0], Wn[1]), Wn[2]), min(min(Wn[3], Wn[4]), Wn[5])), min(Wn[6], Wn[7]));
-                uint32_t pmax;
-                {
-                    typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
-                    const u16x2 a01 = __builtin_bit_cast(u16x2, ring[sc][0]), a23 = __builtin_bit_cast(u16x2, ring[sc][1]);
-                    const u16x2 a45 = __builtin_bit_cast(u16x2, ring[sc][2]), a67 = __builtin_bit_cast(u16x2, ring[sc][3]);
-                    const u16x2 mx = __builtin_elementwise_max(__builtin_elementwise_max(a01, a23), __builtin_elementwise_max(a45, a67));  // v_pk_max_u16
-                    const uint32_t mw = __builtin_bit_cast(uint32_t, mx);
-                    pmax = max(mw & 0xFFFFu, mw >> 16);
-                }
                 const uint32_t mmin = (info >> 8) & 0xFFu, mmax = (info >> 16) & 0xFFu;
-                const int32_t B = (int32_t)__umul24(mmax, pmax) - (int32_t)xmin;
-                const float bf = (float)B, tf = (float)__umul24(xmin, mmin);
-                const bool pass = bf * __builtin_fabsf(bf) > kS * tf;
+                bool pass;
+                if constexpr (EXT) {
+                    // For every valid pixel j of the group:  a_j = m_j y_j - x_j^2 - x_j (m_j - 1) <= mmax y_j - x_j (x_j + mmin - 1)  and
+                    // c_j = nsig_b x_j sqrt(2 (m_j - 1)) >= nsig_b x_j sqrt(2 (mmin - 1)).  The eight windows of sum p^2 slide over
+                    // the 14 column sums as the sums of p do; float32 with the allowances of group_tests8 (|fl(a) - a| < 2^-21 m y;
+                    // 2^-20 m y granted, kB = nsig_b (1 - 2^-20)).  The 32-bit sums of p^2 are the true ones while every window
+                    // sum is below 65536; brighter groups pass.
+                    const uint32_t q01 = colq[0] + colq[1], q23 = colq[2] + colq[3], q45 = colq[4] + colq[5], q67 = colq[6] + colq[7];
+                    const uint32_t qa = q01 + q23, qb = q45 + q67;
+                    const uint32_t U0 = dpp_shr_add(q67, qa), U1 = qa + q45, U2 = qb + q23, U3 = dpp_shl_add(q01, qb);
+                    const uint32_t y0 = dpp_shr_add(colq[5], U0), y1 = U0 + colq[4], y2 = dpp_shr_add(colq[7], U1), y3 = U1 + colq[6];
+                    const uint32_t y4 = U2 + colq[1], y5 = dpp_shl_add(colq[0], U2), y6 = U3 + colq[3], y7 = dpp_shl_add(colq[2], U3);
+                    // per pixel (a bound per GROUP pairs the largest sum p^2 with the smallest sum p and lets most of the
+                    // background through): d_j = [mmax y_j - x_j (x_j + mmin - 1)] (1 + 2^-20) - kB x_j sqrt(2 (mmin - 1)),
+                    // a pixel can only pass the first pass where d_j >= 0; the lane keeps the largest d_j
+                    const uint32_t ys[8] = {y0, y1, y2, y3, y4, y5, y6, y7};
+                    const float mxf = (float)mmax, mm1 = (float)mmin - 1.0f;
+                    const float kq = a.kB * __builtin_amdgcn_sqrtf(2.0f * mm1);
+                    float dmax = -1.0f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float xf = (float)Wn[j], yf = (float)ys[j];
+                        const float t0 = mxf * yf;
+                        const float af = t0 - xf * (xf + mm1);
+                        dmax = __builtin_fmaxf(dmax, (af + t0 * 9.5367431640625e-07f) - kq * xf);
+                    }
+                    const uint32_t xmax = max(max(max(max(Wn[0], Wn[1]), Wn[2]), max(max(Wn[3], Wn[4]), Wn[5])), max(Wn[6], Wn[7]));
+                    pass = mmax != 0u && (dmax >= 0.0f || xmax >= 65536u);
+                } else {
+                    uint32_t pmax;
+                    {
+                        typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+                        const u16x2 a01 = __builtin_bit_cast(u16x2, ring[sc][0]), a23 = __builtin_bit_cast(u16x2, ring[sc][1]);
+                        const u16x2 a45 = __builtin_bit_cast(u16x2, ring[sc][2]), a67 = __builtin_bit_cast(u16x2, ring[sc][3]);
+                        const u16x2 mx = __builtin_elementwise_max(__builtin_elementwise_max(a01, a23), __builtin_elementwise_max(a45, a67));  // v_pk_max_u16
+                        const uint32_t mw = __builtin_bit_cast(uint32_t, mx);
+                        pmax = max(mw & 0xFFFFu, mw >> 16);
+                    }
+                    const int32_t B = (int32_t)__umul24(mmax, pmax) - (int32_t)xmin;
+                    const float bf = (float)B, tf = (float)__umul24(xmin, mmin);
+                    pass = bf * __builtin_fabsf(bf) > kS * tf;
+                }
                 const bool flag = owned && pass && !(a.dbg & 1);
                 if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, so_bytes, 2 /* nt: written once, read much later */);
                 const unsigned long long fm = __builtin_amdgcn_ballot_w64(flag);
@@ -467,7 +559,7 @@ rows_done:
 }
 // Pixels whose window holds sum p >= 65536 (k_stream_u16 cannot vouch for its 32-bit sum of p^2): exact
 // 64-bit sums gathered from memory, then the same predicate.  A handful per frame at most.
-template <typename PixelT>
+template <typename PixelT, bool EXT = false>
 __global__ __launch_bounds__(256) void k_bright_fix(const ThresholdArgs a) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && *a.bright_n > a.bright_cap) atomicOr(a.overflow, 8u);  // the host re-runs the batch
     const uint32_t n = min(*a.bright_n, a.bright_cap);
@@ -475,10 +567,10 @@ __global__ __launch_bounds__(256) void k_bright_fix(const ThresholdArgs a) {
         const uint2 r = a.bright_list[e];
         const uint32_t frame = r.x >> 16, x = r.x & 0xFFFFu, y = r.y;
         const uint8_t* img = (const uint8_t*)a.image + (uint64_t)frame * a.frame_stride;
-        if (exact_strong<PixelT>(a, img, (int)x, (int)y)) {
-            uint8_t* plane = a.bits + (uint64_t)frame * a.plane_frame_stride + (uint64_t)y * a.mpitch;
+        if (exact_strong<PixelT, EXT>(a, img, (int)x, (int)y)) {  // EXT: the dispersion half alone, into the first-pass plane
+            uint8_t* plane = (EXT ? a.dplane : a.bits) + (uint64_t)frame * a.plane_frame_stride + (uint64_t)y * a.mpitch;
             atomicOr(reinterpret_cast<uint32_t*>(plane) + (x >> 5), 1u << (x & 31u));  // rows start on 4-byte boundaries
-            atomicAdd(a.tile_counts + (uint64_t)frame * a.n_tiles + y / (uint32_t)kTileRows, 1u);
+            if (!EXT) atomicAdd(a.tile_counts + (uint64_t)frame * a.n_tiles + y / (uint32_t)kTileRows, 1u);
         }
     }
 }
@@ -751,9 +843,11 @@ rows_done:
 }
 
 template __global__ void k_bright_fix<uint16_t>(const ThresholdArgs);
+template __global__ void k_bright_fix<uint16_t, true>(const ThresholdArgs);
 template __global__ void k_bright_fix<uint32_t>(const ThresholdArgs);
 
 template __global__ void k_stream_u16<2>(const ThresholdArgs);
+template __global__ void k_stream_u16<2, true>(const ThresholdArgs);
 template __global__ void k_stream_u16<3>(const ThresholdArgs);
 template __global__ void k_stream_u32<2>(const ThresholdArgs);
 
