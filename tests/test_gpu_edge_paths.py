@@ -193,3 +193,25 @@ def test_bright_window_list_overflow_falls_back(ffs, dtype, monkeypatch):
         assert_frame_matches_oracle(fr, im, mask)
     quiet = rng.poisson(3.0, (H, W)).astype(dtype)       # and the stream is fine afterwards
     assert_frame_matches_oracle(st.process(quiet[None])[0], quiet, mask)
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.uint32])
+@pytest.mark.parametrize("group", ["1", "3"])
+def test_super_row_groups(ffs, dtype, group, monkeypatch):
+    """The streaming kernels lay the frames of a batch side by side in one super row, as many as keep a group's
+    buffers below 2 GiB (58 Eiger-16M frames); a batch beyond that is cut into several groups.  FFS_K1_GROUP
+    forces small groups so that the cut (3 + 3 + 2 frames, and one frame per group) is exercised on small frames."""
+    monkeypatch.setenv("FFS_K1_GROUP", group)
+    W, H, B = 333, 77, 8
+    frames, mask = [], None
+    for i in range(B):
+        img, mask = make_frame(W=W, H=H, dtype=dtype, seed=40 + i, n_spots=12, masked=True)
+        frames.append(img)
+    ctx = ffs.Context(W, H, dtype, max_batch=B)
+    ctx.set_mask(mask)
+    ctx.set_params(want_strong_mask=1, want_strong_list=1)
+    st = ctx.stream()
+    for fr, img in zip(st.process(np.stack(frames)), frames):
+        assert_frame_matches_oracle(fr, img, mask)
+    for fr, img in zip(st.process(np.stack(frames[:5])), frames[:5]):      # a partial last group
+        assert_frame_matches_oracle(fr, img, mask)
