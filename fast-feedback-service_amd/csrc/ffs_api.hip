@@ -175,6 +175,7 @@ struct ffs_stream {
     bool direct_recs = false;
     bool bits_cleared = false;  // the last batch's compaction zeroed the strong plane again (k_stream_u16's invariant)
     bool bits_dirty = false;    // the strong plane may hold bits: k_stream_u16 needs it zeroed first
+    bool counts_dirty = true;   // the per-tile counts (+ bright-list count) may be non-zero: the streaming kernels add into them
     uint32_t *h_list_k = nullptr, *h_list_i = nullptr;
     uint8_t* h_mask = nullptr;
     // state of the batch in flight
@@ -800,7 +801,7 @@ static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_
         b.n_strips = a.s_strips;
         b.band_rows = a.s_band_rows;
         b.n_bands = a.s_bands;
-        (void)hipMemsetAsync(a.tile_counts, 0, tile_counts_bytes(s), s->st);  // + the bright-list count (last word)
+        // (per-tile counts and the bright-list count are zero here: k_union of the previous batch cleared them, or enqueue_batch did)
         const int bands8s = (b.n_bands + 7) / 8 * 8;
         const unsigned n_groups = (n_frames + (unsigned)a.group_frames - 1) / (unsigned)a.group_frames;
         const int ahead = s->ctx->knobs.k1_ahead;
@@ -883,6 +884,9 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     const bool one_kernel = ta.variant >= 2 && p.algorithm != FFS_ALGO_DISPERSION_EXTENDED;
     if (one_kernel && s->bits_dirty)  // (another algorithm / variant or a failed batch left bits behind)
         HIP_TRY(c, hipMemsetAsync(s->d_bits, 0, (size_t)s->max_batch * L.plane_frame_stride, s->st));
+    if (one_kernel && s->counts_dirty)
+        HIP_TRY(c, hipMemsetAsync(s->d_tile_counts, 0, tile_counts_bytes(s), s->st));
+    s->counts_dirty = true;
     s->bits_dirty = true;  // until every launch of this batch is enqueued (a failure in between leaves bits behind)
     if (p.algorithm == FFS_ALGO_DISPERSION_EXTENDED) {
         launch_extended(s, ta, n);
@@ -974,6 +978,9 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     sa.acc2 = s->d_acc2;
     sa.chunk_roots = s->d_chunk_roots;
     sa.chunks_max = s->cap / kRootChunk + 1;
+    sa.zero_counts = s->d_tile_counts;
+    sa.zero_per_seg = (uint32_t)c->n_tiles;
+    sa.zero_word = s->d_tile_counts + tile_counts_bytes(s) / 4 - 1;
     if (emit_variant < 1 && !root_mode && link_runs) hipLaunchKernelGGL(k_link_runs, gseg, b256, 0, s->st2, sa);
     hipLaunchKernelGGL(k_union<false>, gseg, b256, 0, s->st2, sa);
     if (root_mode) {
@@ -1001,6 +1008,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     }
     HIP_TRY(c, hipEventRecord(s->ev[4], s->st2));
     s->bits_dirty = !one_kernel;  // the compaction of a one-kernel batch leaves the plane all zero again
+    s->counts_dirty = false;      // k_union cleared the counts of the frames of this batch (all the streaming kernel touched)
     s->busy = true;
     s->n_frames = n;
     return FFS_OK;
@@ -1686,6 +1694,7 @@ extern "C" int ffs_bench_threshold(ffs_stream* s, const void* device_pixels, siz
     if (ms_candidate) *ms_candidate = t1 / iters;
     if (ms_exact) *ms_exact = std::max(0.0f, (t2 - t1) / iters);
     s->bits_dirty = true;  // no compaction ran: the strong plane still holds this batch's bits
+    s->counts_dirty = true;
     return FFS_OK;
 }
 

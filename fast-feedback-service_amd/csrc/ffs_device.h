@@ -172,6 +172,11 @@ struct SegArgs {
     CompAcc2* acc2;           // [n_seg][seg_stride]
     uint32_t* chunk_roots;    // [n_seg][chunks_max] roots per chunk of kRootChunk list entries
     uint32_t chunks_max;
+    // 2D: the compaction has consumed the per-tile counts; k_union zeroes them (and the bright-list count) again, which
+    // is what the next batch's streaming kernel adds into
+    uint32_t* zero_counts;    // [n_seg][zero_per_seg], or null
+    uint32_t zero_per_seg;
+    uint32_t* zero_word;      // one more word to clear, or null
 };
 
 

@@ -338,6 +338,11 @@ __global__ __launch_bounds__(256) void k_union(const SegArgs a) {
     const uint32_t n = min(a.seg_n[seg], (uint32_t)a.seg_stride);
     const uint32_t* k = a.list_k + (uint64_t)seg * a.seg_stride;
     uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
+    if (!IS3D && a.zero_counts) {
+        for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < a.zero_per_seg; t += gridDim.x * 256)
+            a.zero_counts[(uint64_t)seg * a.zero_per_seg + t] = 0;
+        if (seg == 0 && blockIdx.x == 0 && threadIdx.x == 0 && a.zero_word) *a.zero_word = 0;
+    }
     uint32_t z = 0;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         uint32_t s_end = n, nb = 0, ne = 0;
