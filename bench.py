@@ -350,7 +350,7 @@ def main():
     alg_bytes = float(W) * H * bytes_per_px * B
     achieved = alg_bytes / (ms_cand * 1e-3) / 1e9
     tm = streams[0].timings()
-    traffic, traffic_src = (None, None) if ext else pmc_traffic(args.workload, B)
+    traffic, traffic_src = pmc_traffic(args.workload + ("_extended" if ext else ""), B)
     # ceiling measured on this box beside the nominal 8 TB/s
     peak_read, peak_mix = streams[0].bench_hbm(iters=5)
 
@@ -444,7 +444,7 @@ def main():
                                            "probe": "ffs_bench_hbm: linear 16 B/lane reads of the batch's pixel buffer; the same with an "
                                                     "8 B zero store per 16 B read (the kernel's read/write mix)"},
                          "frac_of_measured_mix": round((traffic if traffic else alg_bytes) / (ms_cand * 1e-3) / 1e9 / max(peak_mix, 1.0), 4),
-                         "kernel": ("k_candidates_u16<ext>" if ext else
+                         "kernel": ("k_stream_u16<2,true> (extended first pass)" if ext else
                                     "k_stream_u16 (whole threshold stage)" if dt == np.uint16 else "k_stream_u32 (whole threshold stage)"),
                          "ms_per_launch": round(ms_cand, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),

@@ -33,10 +33,14 @@ def main():
             m["valu_busy_frac"] = m["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (m["GRBM_GUI_ACTIVE"] / 8)
         out[k] = {c: round(x, 3) for c, x in m.items()}
         out[k]["launches_averaged"] = len(next(iter(v.values())))
-    try:
+    import os
+    if os.environ.get("FFS_COMMIT"):
+        out["_commit"] = os.environ["FFS_COMMIT"]
+    else:
+      try:
         import subprocess
         out["_commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
-    except Exception:
+      except Exception:
         pass
     json.dump(out, sys.stdout, indent=1, sort_keys=True)
     print()
