@@ -24,6 +24,7 @@
 #include "kernels_extended.hpp"
 #include "kernels_stream.hpp"
 #include "kernels_stack3d.hpp"
+#include "kernels_chain.hpp"
 #include "kernels_decode.hpp"
 
 using namespace ffsamd;
@@ -52,7 +53,9 @@ struct ThreadError {
 struct Knobs {
     int k1_variant = 2, ext_variant = 2, k1_debug = 0, k1_group = 1 << 30, k1_ahead = 2;
     long long target_waves = 16384;
-    int emit_variant = 1, ccl_variant = 1, link_runs = 1, ccl_grid = 32, ccl_cus = 0, direct_recs = 1;
+    int emit_variant = 1, ccl_variant = 2, link_runs = 1, ccl_grid = 32, ccl_cus = 0, direct_recs = 1;
+    int sched = 0;             // FFS_SCHED (experiment): 1 = sparse chain on a high-priority stream of its own; 2 = also every dense kernel of the context on ONE stream
+    int chain_skip = 0;        // FFS_CHAIN_SKIP (timing experiments only; results are then meaningless): 1 = no sparse chain, 2 = stop after emit, 4 = after union, 8 = after reduce
     int bright_cap = 1 << 20;  // FFS_BRIGHT_CAP: entries of the bright-window list actually used (tests shrink it)
     static int env_int(const char* name, int dflt) {
         const char* e = std::getenv(name);
@@ -66,11 +69,13 @@ struct Knobs {
         k1_ahead = env_int("FFS_K1_AHEAD", 2);
         target_waves = std::max(1, env_int("FFS_K1_TARGET_WAVES", 16384));
         emit_variant = env_int("FFS_EMIT", 1);
-        ccl_variant = env_int("FFS_CCL", 1);
+        ccl_variant = env_int("FFS_CCL", 2);
         link_runs = env_int("FFS_LINK_RUNS", 1);
         ccl_grid = std::max(1, env_int("FFS_CCL_GRID", 32));
         ccl_cus = env_int("FFS_CCL_CUS", 0);
         direct_recs = env_int("FFS_DIRECT_RECS", 1);
+        chain_skip = env_int("FFS_CHAIN_SKIP", 0);
+        sched = env_int("FFS_SCHED", 0);
         bright_cap = std::max(0, std::min(1 << 20, env_int("FFS_BRIGHT_CAP", 1 << 20)));
     }
 };
@@ -88,6 +93,9 @@ struct ffs_ctx {
     uint8_t* d_maskbits = nullptr;
     uint8_t* d_ginfo = nullptr;  // per-group mask bits + window-count bounds (kernels_stream.hpp)
     uint8_t* d_mmap = nullptr;   // per-pixel window counts
+    hipStream_t dense_st = nullptr;  // FFS_SCHED=2: the one stream of the dense kernels
+    hipStream_t sparse_st[2] = {nullptr, nullptr};  // FFS_SCHED=3: the sparse chains of the context's streams, alternating
+    int n_streams_made = 0;
     ThreadError err;  // the calling thread's most recent error on any context
 };
 
@@ -139,6 +147,8 @@ struct ffs_stream {
     uint32_t *d_pack_k = nullptr, *d_pack_i = nullptr;  // a batch's lists packed end to end for another device's 3D stack
     StackSlice *d_pack_tab = nullptr, *h_pack_tab = nullptr;
     hipStream_t st = nullptr;    // threshold kernels (+ H2D)
+    bool st2_shared = false;
+    bool st_shared = false;      // st is the context's dense stream (not ours to destroy)
     hipStream_t st2 = nullptr;   // compaction + connected components + D2H; == st unless the CUs are split
     hipEvent_t ev[6] = {};
     // device
@@ -171,6 +181,8 @@ struct ffs_stream {
     size_t h_img_bytes = 0;
     uint32_t* h_counts = nullptr;  // [max_batch] num_strong | [max_batch] n_comp | [max_batch*8] summary | [1] overflow
     ReflOut* h_recs = nullptr;
+    uint32_t* h_counts_dev = nullptr;  // device-side address of h_counts (k_frame_chain writes the counters itself)
+    bool chain_mode = false;       // this batch went through k_frame_chain: records at frame * max_comp, flags per frame
     ReflOut* h_recs_dev = nullptr;  // device-side address of h_recs when the records are written straight to the host
     bool direct_recs = false;
     bool bits_cleared = false;  // the last batch's compaction zeroed the strong plane again (k_stream_u16's invariant)
@@ -383,6 +395,8 @@ extern "C" void ffs_ctx_destroy(ffs_ctx* c) {
     if (c->d_maskbits) (void)hipFree(c->d_maskbits);
     if (c->d_ginfo) (void)hipFree(c->d_ginfo);
     if (c->d_mmap) (void)hipFree(c->d_mmap);
+    if (c->dense_st) (void)hipStreamDestroy(c->dense_st);
+    for (auto st : c->sparse_st) if (st) (void)hipStreamDestroy(st);
     delete c;
 }
 
@@ -507,7 +521,7 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     if (s->job.joinable()) s->job.join();
     if (s->big) ffs_stream_destroy(s->big);
     if (s->st) (void)hipStreamSynchronize(s->st);
-    if (s->st2 && s->st2 != s->st) { (void)hipStreamSynchronize(s->st2); (void)hipStreamDestroy(s->st2); }
+    if (s->st2 && s->st2 != s->st) { (void)hipStreamSynchronize(s->st2); if (!s->st2_shared) (void)hipStreamDestroy(s->st2); }
     // (d_n_comp, d_summary and d_overflow live inside the d_num_strong allocation)
     if (s->h_pack_tab) (void)hipHostFree(s->h_pack_tab);
     void* dev[] = {s->d_pack_k, s->d_pack_i, s->d_pack_tab, s->d_acc2, s->d_chunk_roots, s->d_bright, s->d_comp, s->d_tab, s->d_dplane, s->d_eplane, s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_num_strong,
@@ -520,7 +534,7 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
 
-    if (s->st) (void)hipStreamDestroy(s->st);
+    if (s->st && !s->st_shared) (void)hipStreamDestroy(s->st);
     delete s;
 }
 
@@ -572,6 +586,24 @@ static int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uin
             }
             STREAM_TRY(hipExtStreamCreateWithCUMask(&s->st, (uint32_t)words, m_thr.data()));
             STREAM_TRY(hipExtStreamCreateWithCUMask(&s->st2, (uint32_t)words, m_ccl.data()));
+        } else if (c->knobs.sched >= 1) {
+            int lo = 0, hi = 0;
+            STREAM_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (least, greatest)
+            if (c->knobs.sched >= 2) {
+                if (!c->dense_st) STREAM_TRY(hipStreamCreateWithPriority(&c->dense_st, hipStreamNonBlocking, c->knobs.sched >= 3 ? (lo + hi) / 2 : lo));
+                s->st = c->dense_st;
+                s->st_shared = true;
+            } else {
+                STREAM_TRY(hipStreamCreateWithPriority(&s->st, hipStreamNonBlocking, lo));
+            }
+            if (c->knobs.sched >= 3) {
+                const int j = c->n_streams_made++ & 1;
+                if (!c->sparse_st[j]) STREAM_TRY(hipStreamCreateWithPriority(&c->sparse_st[j], hipStreamNonBlocking, hi));
+                s->st2 = c->sparse_st[j];
+                s->st2_shared = true;
+            } else {
+                STREAM_TRY(hipStreamCreateWithPriority(&s->st2, hipStreamNonBlocking, hi));
+            }
         } else {
             STREAM_TRY(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
             s->st2 = s->st;
@@ -603,7 +635,8 @@ static int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uin
     // raw frames, or bitshuffle-LZ4 chunks (which can exceed the raw size by < 1 % when incompressible)
     s->h_img_bytes = B * ((size_t)L.W * L.H * c->pixel_bytes + (size_t)L.W * L.H * c->pixel_bytes / 128 + 4096);
     STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_img), s->h_img_bytes, hipHostMallocDefault));
-    STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), (B * 10 + 1) * 4, hipHostMallocDefault));
+    STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), (B * 11 + 1) * 4, hipHostMallocDefault));  // (+ [B] per-frame flags, k_frame_chain)
+    std::memset(s->h_counts, 0, (B * 11 + 1) * 4);
     STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_recs), B * (size_t)s->max_comp * sizeof(ReflOut),
                              hipHostMallocDefault));
     // k_finalize can write the (few MB of) records straight into this pinned, device-visible buffer:
@@ -613,6 +646,10 @@ static int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uin
         && hipHostGetDevicePointer(reinterpret_cast<void**>(&s->h_recs_dev), s->h_recs, 0) != hipSuccess) {
         (void)hipGetLastError();
         s->direct_recs = false;
+    }
+    if (s->direct_recs && hipHostGetDevicePointer(reinterpret_cast<void**>(&s->h_counts_dev), s->h_counts, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        s->h_counts_dev = nullptr;
     }
     STREAM_TRY(hipMemsetAsync(s->d_overflow, 0, 4, s->st));
     // bits beyond the image width (x >= W up to the row pitch) are never written by the threshold kernels and must read 0
@@ -861,6 +898,15 @@ static int check_layout(ffs_stream* s, size_t pitch, size_t fstride, uint32_t n_
     return FFS_OK;
 }
 
+// (experiment) occupies slots for a given time without touching memory
+__global__ void k_dummy_spin(uint32_t ticks, uint32_t* sink) {
+    extern __shared__ uint32_t s_dummy[];
+    const uint64_t t0 = wall_clock64();
+    uint32_t it = 0;
+    while (wall_clock64() - t0 < ticks && it < (1u << 20)) { __builtin_amdgcn_s_sleep(20); ++it; }
+    if (it == 0xFFFFFFFFu) { s_dummy[threadIdx.x] = it; *sink = s_dummy[0]; }
+}
+
 static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride, uint32_t n,
                          const ffs_params* snapshot = nullptr) {
     ffs_ctx* c = s->ctx;
@@ -941,7 +987,62 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     // the then three kernels: tiles that wait for a predecessor's count hold their CU slots.)
     // FFS_EMIT (A/B): 1 (default) = one wave per tile, runs linked in the same pass; 0 = one workgroup per tile + k_link_runs
     const int emit_variant = c->knobs.emit_variant;
-    if (emit_variant >= 1 || root_mode) {
+    const int skip = c->knobs.chain_skip;
+    ca.dense_bytes = 1;
+    // FFS_CCL = 2 (default): the whole sparse stage in one launch, one workgroup per frame (kernels_chain.hpp)
+    s->chain_mode = root_mode && ccl_variant >= 2 && s->direct_recs && s->h_counts_dev && c->n_tiles <= kChainMaxTiles && L.H <= kChainMaxRows && !skip;
+    if (s->chain_mode) {
+        ChainArgs A{};
+        A.c = ca;
+        SegArgs& sa = A.s;
+        sa.list_k = s->d_list_k;
+        sa.list_i = s->d_list_i;
+        sa.parent = s->d_parent;
+        sa.seg_n = s->d_num_strong;
+        sa.seg_stride = s->cap;
+        sa.n_comp = s->d_n_comp;
+        sa.max_comp = s->max_comp;
+        sa.overflow = s->d_overflow;
+        sa.W = (uint32_t)L.W;
+        sa.H = (uint32_t)L.H;
+        sa.row_off = s->d_row_off;
+        sa.n_slices = 1;
+        sa.min_spot_size = p.min_spot_size;
+        sa.max_sep = p.max_peak_centroid_separation;
+        sa.recs = s->h_recs_dev;
+        sa.summary = s->d_summary;
+        sa.runs_linked = 2;
+        sa.acc2 = s->d_acc2;
+        sa.zero_counts = s->d_tile_counts;
+        sa.zero_per_seg = (uint32_t)c->n_tiles;
+        sa.zero_word = s->d_tile_counts + tile_counts_bytes(s) / 4 - 1;
+        A.h_counts = s->h_counts_dev;
+        A.max_batch = (uint32_t)s->max_batch;
+        A.rec_stride = s->max_comp;
+        A.stop_after = Knobs::env_int("FFS_CHAIN_STOP", 0);
+        static std::once_flag chain_attr;   // (more than 64 KB of dynamic LDS has to be asked for)
+        std::call_once(chain_attr, [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
+        });
+        if (c->pixel_bytes == 2) hipLaunchKernelGGL(k_frame_chain<uint16_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, A);
+        else hipLaunchKernelGGL(k_frame_chain<uint32_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, A);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(s->ev[3], s->st2));
+        HIP_TRY(c, hipEventRecord(s->ev[4], s->st2));
+        s->spec_recs_copied = (uint64_t)s->max_batch * s->max_comp;
+        s->bits_dirty = !one_kernel;
+        s->counts_dirty = false;
+        s->busy = true;
+        s->n_frames = n;
+        return FFS_OK;
+    }
+    if (skip & 1) {
+        const int us = Knobs::env_int("FFS_DUMMY_US", 0);
+        if (us > 0)
+            hipLaunchKernelGGL(k_dummy_spin, dim3(Knobs::env_int("FFS_DUMMY_WG", 32)), dim3(Knobs::env_int("FFS_DUMMY_THREADS", 1024)),
+                               (size_t)Knobs::env_int("FFS_DUMMY_LDS", 0), s->st2, (uint32_t)us * 100u, s->d_tile_counts);
+    } else if (emit_variant >= 1 || root_mode) {
         if (c->pixel_bytes == 2)
             hipLaunchKernelGGL(k_emit_list_w<uint16_t>, dim3(c->n_tiles, n), dim3(64), 0, s->st2, ca);
         else
@@ -982,8 +1083,10 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     sa.zero_per_seg = (uint32_t)c->n_tiles;
     sa.zero_word = s->d_tile_counts + tile_counts_bytes(s) / 4 - 1;
     if (emit_variant < 1 && !root_mode && link_runs) hipLaunchKernelGGL(k_link_runs, gseg, b256, 0, s->st2, sa);
-    hipLaunchKernelGGL(k_union<false>, gseg, b256, 0, s->st2, sa);
-    if (root_mode) {
+    if (!(skip & 3)) hipLaunchKernelGGL(k_union<false>, gseg, b256, 0, s->st2, sa);
+    if (skip) {
+        if (!(skip & 7)) hipLaunchKernelGGL(k_reduce_roots, gseg, b256, 0, s->st2, sa);
+    } else if (root_mode) {
         hipLaunchKernelGGL(k_reduce_roots, gseg, b256, 0, s->st2, sa);
         hipLaunchKernelGGL(k_finalize_roots, gseg, b256, 0, s->st2, sa);
     } else {
@@ -1008,7 +1111,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     }
     HIP_TRY(c, hipEventRecord(s->ev[4], s->st2));
     s->bits_dirty = !one_kernel;  // the compaction of a one-kernel batch leaves the plane all zero again
-    s->counts_dirty = false;      // k_union cleared the counts of the frames of this batch (all the streaming kernel touched)
+    s->counts_dirty = (skip & 3) != 0;  // k_union cleared the counts of the frames of this batch (all the streaming kernel touched)
     s->busy = true;
     s->n_frames = n;
     return FFS_OK;
@@ -1347,7 +1450,11 @@ static int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32
     const uint32_t* h_ns = s->h_counts;
     const uint32_t* h_nc = s->h_counts + B;
     const uint32_t* h_sm = s->h_counts + 2 * B;
-    const uint32_t overflow = s->h_counts[10 * B];
+    uint32_t overflow = s->h_counts[10 * B];
+    if (s->chain_mode) {  // k_frame_chain: one flag word per frame
+        overflow = 0;
+        for (uint32_t f = 0; f < n; ++f) overflow |= s->h_counts[10 * B + 1 + f];
+    }
     s->busy = false;
     s->ovf.clear();
     if (overflow) {
@@ -1396,7 +1503,7 @@ static int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32
                 int rc = enqueue_batch(b, img, s->cur_pitch, s->cur_fstride, 1, &s->batch_params);
                 if (rc != FFS_OK) return rc;
                 HIP_TRY(c, hipEventSynchronize(b->ev[4]));
-                const uint32_t b_ovf = b->h_counts[10 * (size_t)b->max_batch];
+                const uint32_t b_ovf = b->chain_mode ? b->h_counts[10 * (size_t)b->max_batch + 1] : b->h_counts[10 * (size_t)b->max_batch];
                 if (b_ovf & 3u) {  // only the component count can still be short (it was a guess while the list was cut)
                     (void)hipMemsetAsync(b->d_overflow, 0, 4, b->st2);
                     (void)hipStreamSynchronize(b->st2);
@@ -1492,6 +1599,7 @@ static int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32
         box_at[f] = s->boxes.size();
         refl_at[f] = s->refls.size();
         const uint32_t nc = std::min<uint32_t>(h_nc[f], s->max_comp);
+        if (s->chain_mode) wrec = reinterpret_cast<const WireRec2*>(s->h_recs) + (size_t)f * s->max_comp;  // k_frame_chain: every frame has its own record area
         if (const OverflowFrame* o = overflow_frame(f)) {  // re-run on the one-frame stream: skip the cut records
             if (s->wire2) wrec += nc;
             else rec += nc;

@@ -126,6 +126,7 @@ struct CclArgs {
     uint8_t* strong_bytes;     // byte masks [n][H][bpitch]: the compaction sets the 1s (the threshold kernels zero-fill)
     uint32_t bpitch;
     uint64_t bytes_frame_stride;
+    int dense_bytes;           // write the byte mask at all (only when somebody asked for it)
 };
 
 // Per-component accumulator (device) -- reduced with 64-bit integer atomics so the result

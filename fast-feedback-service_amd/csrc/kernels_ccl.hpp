@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_emit_list(const CclArgs a) {
                                                            + (uint64_t)x * sizeof(PixelT));
                 par[at] = at;
             }
-            sbytes[(uint64_t)y * a.bpitch + (uint32_t)x] = 1;  // the reference kernel's result_strong byte
+            if (a.dense_bytes) sbytes[(uint64_t)y * a.bpitch + (uint32_t)x] = 1;  // the reference kernel's result_strong byte
             ++at;
         }
     }
@@ -132,49 +132,36 @@ template __global__ void k_emit_list<uint32_t>(const CclArgs);
 // Sets the 1s of the byte mask and, for k_stream_u16, clears every plane word it has consumed (that kernel
 // needs an all-zero plane).
 constexpr int kEmitListCap = 256;  // non-zero plane words staged per flush
+constexpr int kEmitInFlight = 8;   // plane words a lane has in flight
 
+// the first kEmitInFlight * 64 plane words of a tile (the caller issues these loads as early as it can)
+__device__ __forceinline__ void emit_preload(const CclArgs& a, int frame, int tile, int lane, uint32_t (&wv)[kEmitInFlight]) {
+    const int y0 = tile * kTileRows;
+    const int ndw = min(kTileRows, a.H - y0) * (int)(a.mpitch >> 2);
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(a.bits + (uint64_t)frame * a.plane_frame_stride + (uint64_t)y0 * a.mpitch);
+#pragma unroll
+    for (int q = 0; q < kEmitInFlight; ++q) {
+        const int g = q * 64 + lane;
+        wv[q] = g < ndw ? words[g] : 0u;
+    }
+}
+
+// One wave compacts one tile: list entries from tile_base on, row offsets, run links, fresh accumulators, the 1s
+// of the byte mask, the plane words cleared.  s_g / s_w: kEmitListCap words each, s_rows: kTileRows words (this wave's).
 template <typename PixelT>
-__global__ __launch_bounds__(64) void k_emit_list_w(const CclArgs a) {
-    __shared__ uint32_t s_g[kEmitListCap], s_w[kEmitListCap];
-    __shared__ uint32_t s_rows[kTileRows];
-    const int lane = threadIdx.x;
-    const int tile = blockIdx.x, frame = blockIdx.y;
-    const uint32_t* counts = a.tile_counts + (uint64_t)frame * a.n_tiles;
+__device__ __forceinline__ void emit_tile_w(const CclArgs& a, int frame, int tile, uint32_t tile_base, uint32_t count,
+                                            uint32_t (&wv)[kEmitInFlight], uint32_t* s_g, uint32_t* s_w, uint32_t* s_rows, int lane) {
     const int y0 = tile * kTileRows;
     const int rows = min(kTileRows, a.H - y0);
     const int dpr = a.mpitch >> 2;
     const int ndw = rows * dpr;
     uint32_t* words = reinterpret_cast<uint32_t*>(a.bits + (uint64_t)frame * a.plane_frame_stride + (uint64_t)y0 * a.mpitch);
-    constexpr int kInFlight = 8;
-    // first round trip: this tile's count, the counts of the tiles before it, and the first plane words
-    const uint32_t count = counts[tile];
-    uint32_t part = 0;
-    for (int t = lane; t < tile; t += 64) part += counts[t];
-    uint32_t wv[kInFlight];
-#pragma unroll
-    for (int q = 0; q < kInFlight; ++q) {
-        const int g = q * 64 + lane;
-        wv[q] = g < ndw ? words[g] : 0u;
-    }
-    if (lane < kTileRows) s_rows[lane] = 0;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
-    const uint32_t tile_base = part;
     uint32_t* row_off = a.row_off + (uint64_t)frame * (a.H + 1);
-    if (tile == a.n_tiles - 1 && lane == 0) {  // the last tile knows the frame's total
-        const uint32_t total = tile_base + count;
-        a.num_strong[frame] = total;
-        row_off[a.H] = min(total, a.cap);
-        if (total > a.cap) atomicOr(a.overflow, 1u);
-    }
-    if (tile == 0 && a.acc2) {  // counters the root-indexed reduction adds into
-        if (lane == 0) a.n_comp[frame] = 0;
-        if (lane < 8) a.summary[(uint64_t)frame * 8 + lane] = 0;
-    }
     if (count == 0) {  // wave-uniform: empty rows all start where the tile starts
         if (lane < rows) row_off[y0 + lane] = min(tile_base, a.cap);
         return;
     }
+    if (lane < kTileRows) s_rows[lane] = 0;
     const uint8_t* img = (const uint8_t*)a.image + (uint64_t)frame * a.frame_stride;
     uint32_t* lk = a.list_k + (uint64_t)frame * a.cap;
     uint32_t* li = a.list_i + (uint64_t)frame * a.cap;
@@ -231,7 +218,7 @@ __global__ __launch_bounds__(64) void k_emit_list_w(const CclArgs a) {
                             acc2[at] = z;
                         }
                     }
-                    sbytes[(uint64_t)y * a.bpitch + (uint32_t)x] = 1;  // the reference kernel's result_strong byte
+                    if (a.dense_bytes) sbytes[(uint64_t)y * a.bpitch + (uint32_t)x] = 1;  // the reference kernel's result_strong byte
                     ++at;
                     prev = bit;
                 }
@@ -244,16 +231,16 @@ __global__ __launch_bounds__(64) void k_emit_list_w(const CclArgs a) {
         n_list = 0;
     };
 
-    for (int c0 = 0; c0 * 64 < ndw; c0 += kInFlight) {
+    for (int c0 = 0; c0 * 64 < ndw; c0 += kEmitInFlight) {
         if (c0 > 0) {
 #pragma unroll
-            for (int q = 0; q < kInFlight; ++q) {
+            for (int q = 0; q < kEmitInFlight; ++q) {
                 const int g = (c0 + q) * 64 + lane;
                 wv[q] = g < ndw ? words[g] : 0u;
             }
         }
 #pragma unroll
-        for (int q = 0; q < kInFlight; ++q) {
+        for (int q = 0; q < kEmitInFlight; ++q) {
             if ((c0 + q) * 64 >= ndw) break;  // wave-uniform
             const uint32_t w = wv[q];
             const unsigned long long nz = __builtin_amdgcn_ballot_w64(w != 0u);
@@ -276,6 +263,35 @@ __global__ __launch_bounds__(64) void k_emit_list_w(const CclArgs a) {
         for (int r = 0; r < lane; ++r) before += s_rows[r];
         row_off[y0 + lane] = min(tile_base + before, a.cap);
     }
+}
+
+template <typename PixelT>
+__global__ __launch_bounds__(64) void k_emit_list_w(const CclArgs a) {
+    __shared__ uint32_t s_g[kEmitListCap], s_w[kEmitListCap];
+    __shared__ uint32_t s_rows[kTileRows];
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x, frame = blockIdx.y;
+    const uint32_t* counts = a.tile_counts + (uint64_t)frame * a.n_tiles;
+    // first round trip: this tile's count, the counts of the tiles before it, and the first plane words
+    const uint32_t count = counts[tile];
+    uint32_t part = 0;
+    for (int t = lane; t < tile; t += 64) part += counts[t];
+    uint32_t wv[kEmitInFlight];
+    emit_preload(a, frame, tile, lane, wv);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+    const uint32_t tile_base = part;
+    if (tile == a.n_tiles - 1 && lane == 0) {  // the last tile knows the frame's total
+        const uint32_t total = tile_base + count;
+        a.num_strong[frame] = total;
+        (a.row_off + (uint64_t)frame * (a.H + 1))[a.H] = min(total, a.cap);
+        if (total > a.cap) atomicOr(a.overflow, 1u);
+    }
+    if (tile == 0 && a.acc2) {  // counters the root-indexed reduction adds into
+        if (lane == 0) a.n_comp[frame] = 0;
+        if (lane < 8) a.summary[(uint64_t)frame * 8 + lane] = 0;
+    }
+    emit_tile_w<PixelT>(a, frame, tile, tile_base, count, wv, s_g, s_w, s_rows, lane);
 }
 template __global__ void k_emit_list_w<uint16_t>(const CclArgs);
 template __global__ void k_emit_list_w<uint32_t>(const CclArgs);

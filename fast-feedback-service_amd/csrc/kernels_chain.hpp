@@ -1,0 +1,648 @@
+// kernels_chain.hpp (included by ffs_api.hip) -- the whole sparse stage of a frame in ONE workgroup.
+//
+// Why: the sparse stage (compaction -> union-find -> reduction -> records) is a chain of dependent memory round
+// trips over ~10^4 strong pixels per frame.  As four grid-wide kernels it cost the batch their full durations
+// (~130 us of a 500 us step) although they keep a few per cent of the machine busy: a kernel that becomes ready
+// while another queue's 15 000-workgroup streaming kernel is being dispatched gets no CU until that dispatch has
+// drained, so each of the four waited for a tail of its own.  ONE launch per batch needs
+// one tail, and then runs beside the next batches' streaming kernels for as long as it likes: what it costs the
+// machine is the slots it holds (one workgroup per frame), not its duration.
+//
+// With a whole frame in one workgroup the round trips can stay on the CU.  A dependent access costs ~1 us at the
+// L2 and ~0.1 us in LDS, so the frame's union-find forest and the per-row list offsets live in LDS (frames up to
+// kChainLdsEntries strong pixels; denser frames run the stages on the global arrays), the accumulators of 512
+// components at a time do too, and where the list itself (global) has to be searched a thread keeps ten searches
+// in flight.
+//
+// Phases (separated by __syncthreads(), which also orders the block's global writes):
+//   A  exclusive scan of the frame's per-tile counts (the streaming kernel's atomics) -> tile offsets in LDS; the
+//      counts are zeroed for the next batch
+//   E  compaction: each wave streams a contiguous range of tiles (16-byte plane loads, the next batch of loads in
+//      flight while this one is looked at, tiles without strong pixels skipped), stages the non-zero words of
+//      several tiles and places their pixels 64 words at a time; nothing here waits for a load it just issued
+//      (the pixel VALUES are fetched in phase P)
+//   S  per-row counts -> per-row list offsets (block scan, in LDS)
+//   U  union-find: vertical edges + the reference's row-wrap edge (the body of k_union<false>)
+//   then, for frames held in LDS:
+//   P  pixel values (twenty independent loads per thread); every entry finds its root; roots are numbered in list order (= label order, connected_components.cc:91,242)
+//   R  512 components at a time: entries add into LDS accumulators (integer atomics: order-independent), one thread
+//      per component writes its 40-byte record, the records leave as consecutive dwords
+//   and for denser frames: R' accumulators at the root's list index in global memory, F' records chunk by chunk
+//   (the bodies of k_reduce_roots / k_finalize_roots).
+// Frame f's records start at f * max_comp of the (host) record buffer -- no frame waits for another's count -- and
+// counters and flags go straight into the pinned block ffs_wait() reads: no copy follows the kernel.
+// Results are those of the four-kernel chain bit for bit (same edges, same integer accumulators, same order).
+#pragma once
+#include "kernels_ccl.hpp"
+
+namespace ffsamd {
+
+constexpr int kChainThreads = 1024;
+constexpr int kChainWaves = kChainThreads / 64;
+constexpr int kChainMaxRows = 4480;     // per-row offsets kept in LDS; taller frames take the four kernels
+constexpr int kChainMaxTiles = kChainMaxRows / kTileRows;
+constexpr int kChainListCap = 448;      // non-zero plane words a wave stages (a round of loads adds at most 256)
+constexpr int kChainQuads = 4;          // 16-byte plane loads a lane has in flight per batch (two batches are live)
+constexpr int kChainLdsEntries = 20480; // strong pixels of a frame whose union-find forest fits LDS
+constexpr int kChainPer = kChainLdsEntries / kChainThreads;   // consecutive entries per thread in phases U / P / R
+constexpr int kChainGroup = 10;         // entries a thread searches side by side in phase U (kChainPer = 2 groups)
+constexpr int kChainSlots = 512;        // components accumulated in LDS at a time
+
+// LDS accumulator of one component: sum I, sum (2x+1) I, sum (2y+1) I, peak = I << 32 | ~k
+struct ChainAcc {
+    unsigned long long sum_i, sum_xi, sum_yi, peak;
+    uint32_t x_min, x_max, y_min, y_max;
+    uint32_t num_pixels, pad;
+};
+
+// dynamic LDS: tile offsets | row offsets | forest (k, parent) later accumulators + record staging | word staging
+constexpr int kChainForestBytes = kChainLdsEntries * 4;
+constexpr int kChainAccBytes = kChainSlots * ((int)sizeof(ChainAcc) + (int)sizeof(WireRec2));
+constexpr int kChainOutGlobalBytes = kChainThreads * (int)sizeof(WireRec2);
+static_assert(kChainAccBytes <= kChainForestBytes && kChainOutGlobalBytes <= kChainForestBytes, "LDS plan");
+constexpr int kChainStageOff = (kChainMaxTiles + 1) * 4 + (kChainMaxRows + 1) * 4 + kChainForestBytes;
+constexpr int kChainDynBytes = kChainStageOff + kChainWaves * 2 * kChainListCap * 4;
+static_assert(kChainStageOff % 8 == 0 && kChainDynBytes <= 160 * 1024 - 256, "LDS plan");
+
+// Inclusive prefix sum over the 64 lanes in six DPP adds (row_shr 1/2/4/8 inside the rows of 16, then row_bcast:15 and
+// row_bcast:31 carry the row totals on) instead of six ds_bpermute round trips.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
+struct ChainArgs {
+    CclArgs c;
+    SegArgs s;
+    uint32_t* h_counts;     // pinned host block (device address): [B] strong pixels, [B] components, [B][8] summary, [1] unused, [B] flags
+    uint32_t max_batch;     // B
+    uint32_t rec_stride;    // records between the frames' record areas (= max_comp)
+    int stop_after;         // (timing experiments) 1..4: return after phase A / E / U / P
+};
+
+__device__ __forceinline__ void chain_record(const SegArgs& sa, uint32_t W, uint32_t num_pixels, unsigned long long sum_i,
+                                             unsigned long long sum_xi, unsigned long long sum_yi, uint32_t x_min, uint32_t x_max,
+                                             uint32_t y_min, uint32_t y_max, uint32_t peak_k, uint32_t peak_i, uint32_t* s_sm, WireRec2& o) {
+    // center_of_mass(): double sums of (c + 0.5) * I, quotient narrowed to float
+    // (connected_components.hpp:81-100).  sum (2c+1) I is an exact integer; * 0.5 is exact.
+    const double tot = (double)sum_i;
+    const float com_x = (float)((double)sum_xi * 0.5 / tot), com_y = (float)((double)sum_yi * 0.5 / tot);
+    const float com_z = (float)(0.5 * tot / tot);  // z = 0 for 2D (:247)
+    const uint32_t peak_y = peak_k / W, peak_x = peak_k - peak_y * W;
+    // peak_centroid_distance(): float arithmetic, connected_components.hpp:194-198; one rounding per
+    // operation (no contraction in this library), float sqrt through the correctly rounded double sqrt
+    const float dx = ((float)peak_x + 0.5f) - com_x;
+    const float dy = ((float)peak_y + 0.5f) - com_y;
+    const float dz = ((float)0 + 0.5f) - com_z;
+    const float s2 = (dx * dx + dy * dy) + dz * dz;
+    const float pcd = (float)__builtin_sqrt((double)s2);
+    uint32_t flags = 0;
+    // filter_reflections(): size first, then separation (connected_components.cc:207-236)
+    if (sa.min_spot_size > 0 && num_pixels < sa.min_spot_size) flags |= 1u;
+    else if (sa.max_sep > 0.0f && pcd > sa.max_sep) flags |= 2u;
+    o.x_min = (uint16_t)x_min; o.x_max = (uint16_t)x_max; o.y_min = (uint16_t)y_min; o.y_max = (uint16_t)y_max;
+    o.npx_flags = num_pixels | (flags << 30);
+    o.com_x = com_x; o.com_y = com_y;
+    o.peak_x = (uint16_t)peak_x; o.peak_y = (uint16_t)peak_y;
+    o.peak_intensity = peak_i;
+    o.peak_centroid_distance = pcd;
+    o.sum_intensity = sum_i;
+    // generate_boxes() filter (connected_components.cc:122-138)
+    if (sa.min_spot_size == 0 || num_pixels >= sa.min_spot_size) {
+        atomicAdd(&s_sm[0], 1u);
+        atomicAdd(&s_sm[1], num_pixels);
+    }
+    if (flags == 0) atomicAdd(&s_sm[2], 1u);
+    if (flags & 1u) atomicAdd(&s_sm[3], 1u);
+    if (flags & 2u) atomicAdd(&s_sm[4], 1u);
+}
+
+template <typename PixelT>
+__global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A) {
+    const CclArgs& a = A.c;
+    const SegArgs& sa = A.s;
+    extern __shared__ __align__(16) uint8_t s_dyn[];
+    uint32_t* s_toff = reinterpret_cast<uint32_t*>(s_dyn);              // [n_tiles + 1]
+    uint32_t* s_row = s_toff + (kChainMaxTiles + 1);                     // [H + 1] per-row counts, then offsets
+    uint8_t* s_big = reinterpret_cast<uint8_t*>(s_row + (kChainMaxRows + 1));
+    __shared__ uint32_t s_wave[kChainWaves];
+    __shared__ uint32_t s_sm[8];
+
+    const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_tiles = a.n_tiles;
+    const uint32_t W = (uint32_t)a.W, H = (uint32_t)a.H;
+    const int dpr = a.mpitch >> 2;
+
+    // ---- A: tile offsets ------------------------------------------------------------------------------
+    uint32_t total;
+    {
+        uint32_t* counts = sa.zero_counts + (uint64_t)frame * sa.zero_per_seg;   // (= a.tile_counts, writable)
+        const uint32_t mine = tid < n_tiles ? counts[tid] : 0u;                  // (n_tiles <= kChainMaxTiles < kChainThreads)
+        const uint32_t at = block_exclusive_scan<kChainThreads>(mine, s_wave, total);
+        if (tid < n_tiles) {
+            s_toff[tid] = at;
+            counts[tid] = 0;   // consumed: the next batch's streaming kernel adds into zeros
+        }
+        if (tid == 0) {
+            s_toff[n_tiles] = total;
+            if (frame == 0 && sa.zero_word) *sa.zero_word = 0;
+        }
+        if (tid < 8) s_sm[tid] = 0;
+        for (int y = tid; y <= a.H; y += kChainThreads) s_row[y] = 0;
+    }
+    __syncthreads();
+    const uint32_t n = min(total, a.cap);
+    const bool in_lds = n <= (uint32_t)kChainLdsEntries;
+    if (A.stop_after == 1) return;
+
+    uint32_t* gk = a.list_k + (uint64_t)frame * a.cap;
+    uint32_t* gi = a.list_i + (uint64_t)frame * a.cap;
+    uint32_t* gpar = a.parent + (uint64_t)frame * a.cap;
+    CompAcc2* gacc = a.acc2 + (uint64_t)frame * a.cap;
+    const uint8_t* img = (const uint8_t*)a.image + (uint64_t)frame * a.frame_stride;
+    // the forest as the later phases see it (generic pointer: LDS or global)
+    uint32_t* lpar = in_lds ? reinterpret_cast<uint32_t*>(s_big) : gpar;
+    auto pixel_at = [&](uint32_t kv) -> uint32_t {
+        const uint32_t y = kv / W, x = kv - y * W;
+        return (uint32_t)*reinterpret_cast<const PixelT*>(img + (uint64_t)y * a.pitch + (uint64_t)x * sizeof(PixelT));
+    };
+
+    // ---- E: compaction --------------------------------------------------------------------------------
+    // Nothing in this phase waits for a load it has just issued: the plane words come two batches ahead, and the
+    // pixel VALUES are not fetched here at all (phase P loads them, twenty independent loads per thread).
+    if (total != 0) {
+        const int tpw = (n_tiles + kChainWaves - 1) / kChainWaves;
+        const int tb = min(wave * tpw, n_tiles), te = min(tb + tpw, n_tiles);
+        const int yb = tb * kTileRows, ye = min(te * kTileRows, a.H);
+        const int nw = (ye - yb) * dpr;                       // plane words of this wave's rows (contiguous)
+        if (te > tb && s_toff[te] != s_toff[tb]) {            // wave-uniform
+            uint32_t* words = reinterpret_cast<uint32_t*>(a.bits + (uint64_t)frame * a.plane_frame_stride + (uint64_t)yb * a.mpitch);
+            uint8_t* sbytes = a.strong_bytes + (uint64_t)frame * a.bytes_frame_stride;
+            uint32_t* s_g = reinterpret_cast<uint32_t*>(s_dyn + kChainStageOff) + wave * 2 * kChainListCap;
+            uint32_t* s_w = s_g + kChainListCap;
+
+            uint32_t run = s_toff[tb];             // list position of the next strong pixel (wave-uniform)
+            int n_list = 0;                        // staged non-zero words (wave-uniform)
+            uint32_t last_g = 0xFFFFFFFFu, last_w = 0;  // the word before the staged ones (for the link to the left)
+            // places the pixels of `cnt` (<= 64) staged words from `first` on, one word per lane
+            auto place = [&](int first, int cnt) {
+                const bool valid = lane < cnt;
+                const int e = first + lane;
+                const uint32_t g = valid ? s_g[e] : 0u;
+                uint32_t w = valid ? s_w[e] : 0u;
+                const uint32_t pg = e > 0 ? s_g[valid ? e - 1 : 0] : last_g, pw = e > 0 ? s_w[valid ? e - 1 : 0] : last_w;
+                const uint32_t pc = (uint32_t)__popc(w);
+                const uint32_t inc = wave_inclusive_scan(pc);
+                uint32_t at = run + inc - pc;
+                run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                if (valid) {
+                    if (a.clear_bits) words[g] = 0;   // (the streaming kernel needs an all-zero plane)
+                    const int row = (int)g / dpr;
+                    const int col = (int)g - row * dpr;
+                    const int xb = col * 32;
+                    const int y = yb + row;
+                    atomicAdd(&s_row[y], pc);
+                    // the pixel left of this word's bit 0: bit 31 of the word before it, same row
+                    const bool left = col != 0 && pg + 1 == g && (pw >> 31) != 0u;
+                    int prev = -2;  // bit index of this word's previous strong pixel
+                    uint32_t run_first = at;  // list index of the first pixel of the current run inside this word
+                    while (w) {
+                        const int b = __ffs((int)w) - 1;
+                        w &= w - 1;
+                        const bool linked = b == 0 ? left : prev == b - 1;
+                        if (!linked || b == 0) run_first = at;
+                        if (at < a.cap) {
+                            // a run's pixels point at its first pixel in this word; a run that continues from
+                            // the previous word hooks on to that word's last pixel (see emit_tile_w)
+                            const uint32_t pv = !linked ? at : (b == 0 ? at - 1 : run_first);
+                            gk[at] = (uint32_t)y * W + (uint32_t)(xb + b);
+                            if (in_lds) {
+                                if (at < (uint32_t)kChainLdsEntries) lpar[at] = pv;
+                            } else {
+                                gpar[at] = pv;
+                                if (!linked) {  // a run start may end up a root: fresh accumulator
+                                    CompAcc2 z;
+                                    z.sum_i = z.sum_xi = z.sum_yi = z.peak = 0ull;
+                                    z.x_min = 0xFFFFFFFFu; z.x_max = 0u; z.y_min = 0xFFFFFFFFu; z.y_max = 0u;
+                                    z.num_pixels = 0u; z.pad = 0u;
+                                    gacc[at] = z;
+                                }
+                            }
+                        }
+                        if (a.dense_bytes) sbytes[(uint64_t)y * a.bpitch + (uint32_t)(xb + b)] = 1;  // the reference kernel's result_strong byte
+                        ++at;
+                        prev = b;
+                    }
+                }
+            };
+            // places every full group of 64 staged words (all of them at the end of the range); what is left (< 64)
+            // moves to the front
+            auto drain = [&](bool all) {
+                int done = 0;
+                while (n_list - done >= 64) {
+                    place(done, 64);
+                    done += 64;
+                }
+                if (all && n_list > done) {
+                    place(done, n_list - done);
+                    done = n_list;
+                }
+                if (done == 0) return;
+                last_g = s_g[done - 1];
+                last_w = s_w[done - 1];
+                const int rem = n_list - done;
+                const uint32_t mg = lane < rem ? s_g[done + lane] : 0u, mw = lane < rem ? s_w[done + lane] : 0u;
+                if (lane < rem) {
+                    s_g[lane] = mg;
+                    s_w[lane] = mw;
+                }
+                n_list = rem;
+            };
+
+            const int nrounds = (nw + 255) / 256;   // a round = 64 lanes x 4 words
+            // rounds whose rows lie in tiles without a strong pixel are not loaded at all (wave-uniform test)
+            auto round_live = [&](int r) {
+                if (r >= nrounds) return false;
+                const int r0 = (r * 256) / dpr, r1 = min(r * 256 + 255, nw - 1) / dpr;
+                return s_toff[(yb + r1) / kTileRows + 1] != s_toff[(yb + r0) / kTileRows];
+            };
+            auto load_batch = [&](int b, uint4 (&buf)[kChainQuads]) {
+#pragma unroll
+                for (int q = 0; q < kChainQuads; ++q) {
+                    const int r = b * kChainQuads + q;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (round_live(r)) {
+                        const int g = (r * 64 + lane) * 4;
+                        if (g + 3 < nw) v = *reinterpret_cast<const uint4*>(words + g);   // (8 rows of a 4-byte-multiple pitch: 32-byte multiples)
+                        else if (g < nw) {
+                            v.x = words[g];
+                            if (g + 1 < nw) v.y = words[g + 1];
+                            if (g + 2 < nw) v.z = words[g + 2];
+                        }
+                    }
+                    buf[q] = v;
+                }
+            };
+            auto stage_batch = [&](int b, const uint4 (&buf)[kChainQuads]) {
+#pragma unroll
+                for (int q = 0; q < kChainQuads; ++q) {
+                    const int r = b * kChainQuads + q;
+                    const uint4 v = buf[q];
+                    const uint32_t cnt = (v.x != 0u) + (v.y != 0u) + (v.z != 0u) + (v.w != 0u);
+                    if (__builtin_amdgcn_ballot_w64(cnt != 0u) == 0ull) continue;  // wave-uniform
+                    // (no global store in this loop: the loads in flight are waited for by count, not all together)
+                    if (n_list + 256 > kChainListCap) drain(false);
+                    // the lanes' non-zero words keep their order: exclusive scan of the per-lane counts
+                    const uint32_t inc = wave_inclusive_scan(cnt);
+                    int e = n_list + (int)(inc - cnt);
+                    const int g = (r * 64 + lane) * 4;
+                    const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (vv[c]) {
+                            s_g[e] = (uint32_t)(g + c);
+                            s_w[e] = vv[c];
+                            ++e;
+                        }
+                    }
+                    n_list += __builtin_amdgcn_readlane((int)inc, 63);
+                }
+            };
+            // three batches of loads live: the one being staged and two in flight
+            uint4 b0[kChainQuads], b1[kChainQuads], b2[kChainQuads];
+            const int nbatches = (nrounds + kChainQuads - 1) / kChainQuads;
+            load_batch(0, b0);
+            load_batch(1, b1);
+            for (int b = 0; b < nbatches; b += 3) {   // (beyond the last batch nothing is live: no load is issued)
+                load_batch(b + 2, b2);
+                stage_batch(b, b0);
+                load_batch(b + 3, b0);
+                stage_batch(b + 1, b1);
+                load_batch(b + 4, b1);
+                stage_batch(b + 2, b2);
+            }
+            drain(true);
+        }
+    }
+    __syncthreads();
+    if (A.stop_after == 2) return;
+
+    // ---- S: per-row counts -> list offset of the first strong pixel of every row (and of "row H" = n) ------
+    {
+        constexpr int kPerRow = (kChainMaxRows + 1 + kChainThreads - 1) / kChainThreads;   // consecutive rows per thread
+        const int y0 = min(tid * kPerRow, a.H + 1), y1 = min(y0 + kPerRow, a.H + 1);
+        uint32_t loc[kPerRow];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int q = 0; q < kPerRow; ++q) {
+            loc[q] = y0 + q < y1 ? s_row[y0 + q] : 0u;
+            mine += loc[q];
+        }
+        uint32_t tot;
+        uint32_t run = block_exclusive_scan<kChainThreads>(mine, s_wave, tot);
+#pragma unroll
+        for (int q = 0; q < kPerRow; ++q) {
+            if (y0 + q < y1) {
+                s_row[y0 + q] = min(run, a.cap);
+                run += loc[q];
+            }
+        }
+    }
+    __syncthreads();
+
+    WireRec2* recs = reinterpret_cast<WireRec2*>(sa.recs) + (uint64_t)frame * A.rec_stride;
+    uint32_t before = 0;  // components numbered so far (block-uniform)
+
+    if (in_lds) {
+        // every thread owns `per` consecutive list entries (<= kChainPer) through phases U, P and R
+        const uint32_t per = (n + kChainThreads - 1) / kChainThreads;
+        const uint32_t i0 = min((uint32_t)tid * per, n), i1 = min(i0 + per, n);
+
+        // ---- U: vertical edges + row wrap (k_union<false> with the runs linked by the compaction) ----------------
+        // The list stays in global memory (a dependent access ~1 us), so a thread runs the binary searches of
+        // kChainGroup entries side by side: a step of all of them costs one round trip.
+        {
+            uint32_t kprev = i0 > 0 && i0 < i1 ? gk[i0 - 1] : 0xFFFFFFF0u;
+#pragma unroll
+            for (int h = 0; h < kChainPer / kChainGroup; ++h) {
+                const uint32_t ib = i0 + (uint32_t)(h * kChainGroup);
+                if (ib >= i1) break;
+                uint32_t ek[kChainGroup], lo[kChainGroup], hi[kChainGroup];
+                uint32_t starts = 0;
+#pragma unroll
+                for (int q = 0; q < kChainGroup; ++q) ek[q] = ib + q < i1 ? gk[ib + q] : 0u;
+#pragma unroll
+                for (int q = 0; q < kChainGroup; ++q) {
+                    const uint32_t i = ib + q;
+                    lo[q] = hi[q] = 0;
+                    if (i >= i1) continue;
+                    const uint32_t ki = ek[q];
+                    const uint32_t y = ki / W;
+                    const uint32_t kp = q > 0 ? ek[q - 1] : kprev;
+                    const bool st = i == 0 || kp + 1 != ki;
+                    starts |= st ? 1u << q : 0u;
+                    // the reference's k + 1 edge has no row-end check (connected_components.cc:62-70)
+                    if (!st && ki - y * W == 0) uf_union(lpar, i - 1, i);
+                    if (y + 1 < H) {
+                        lo[q] = max(i + 1, s_row[y + 1]);
+                        hi[q] = max(lo[q], min(min(n, i + 1 + W), s_row[y + 2]));
+                    }
+                }
+                for (;;) {   // lower bound of k + W in the next row's list range, all entries of the group in step
+                    uint32_t km[kChainGroup];
+                    bool any = false;
+#pragma unroll
+                    for (int q = 0; q < kChainGroup; ++q) {
+                        km[q] = 0;
+                        if (lo[q] < hi[q]) {
+                            km[q] = gk[lo[q] + ((hi[q] - lo[q]) >> 1)];
+                            any = true;
+                        }
+                    }
+                    if (!any) break;
+#pragma unroll
+                    for (int q = 0; q < kChainGroup; ++q) {
+                        if (lo[q] < hi[q]) {
+                            const uint32_t mid = lo[q] + ((hi[q] - lo[q]) >> 1);
+                            if (km[q] < ek[q] + W) lo[q] = mid + 1; else hi[q] = mid;
+                        }
+                    }
+                }
+                uint32_t kb[kChainGroup], kbp[kChainGroup];   // the entry found and the one before it
+#pragma unroll
+                for (int q = 0; q < kChainGroup; ++q) {
+                    const bool look = ib + q < i1 && ek[q] / W + 1 < H && lo[q] < n;
+                    kb[q] = look ? gk[lo[q]] : 0u;
+                    kbp[q] = look && lo[q] > 0 ? gk[lo[q] - 1] : 0xFFFFFFF0u;
+                }
+#pragma unroll
+                for (int q = 0; q < kChainGroup; ++q) {
+                    const uint32_t i = ib + q;
+                    if (i >= i1 || ek[q] / W + 1 >= H || lo[q] >= n) continue;
+                    const uint32_t key = ek[q] + W;
+                    // one edge per pair of overlapping runs is enough (see k_union)
+                    if (kb[q] == key && (((starts >> q) & 1u) || kbp[q] + 1 != key)) uf_union(lpar, i, lo[q]);
+                }
+                kprev = ek[kChainGroup - 1];
+            }
+        }
+        __syncthreads();
+        if (A.stop_after == 3) return;
+
+        // ---- P: pixel values; roots, numbered in list order ---------------------------------------------------------
+        // This thread's entries stay in registers through phase R: k, intensity and a 16-bit id (first the root's list
+        // index, then the component's number; both < kChainLdsEntries < 0xFFFF = none).  16-bit pixels share a register
+        // with the id, 32-bit pixels keep their ids two to a register.
+        constexpr bool kPack = sizeof(PixelT) == 2;
+        uint32_t exy[kChainPer], ew[kChainPer], eid[kPack ? 1 : kChainPer / 2];   // (y << 16 | x: H <= kChainMaxRows, W <= 65535)
+        auto get_id = [&](int q) -> uint32_t {
+            if constexpr (kPack) return ew[q] >> 16;
+            else return (eid[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+        };
+        auto set_id = [&](int q, uint32_t v) {
+            if constexpr (kPack) ew[q] = (ew[q] & 0xFFFFu) | (v << 16);
+            else eid[q >> 1] = (eid[q >> 1] & ~(0xFFFFu << (16 * (q & 1)))) | (v << (16 * (q & 1)));
+        };
+        auto get_i = [&](int q) -> uint32_t { return kPack ? ew[q] & 0xFFFFu : ew[q]; };
+        if constexpr (!kPack) {
+#pragma unroll
+            for (int q = 0; q < kChainPer / 2; ++q) eid[q] = 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int q = 0; q < kChainPer; ++q) exy[q] = i0 + q < i1 ? gk[i0 + q] : 0u;
+#pragma unroll
+        for (int q = 0; q < kChainPer; ++q) {
+            const uint32_t y = exy[q] / W, x = exy[q] - y * W;
+            exy[q] = (y << 16) | x;
+            ew[q] = (i0 + q < i1 ? (uint32_t)*reinterpret_cast<const PixelT*>(img + (uint64_t)y * a.pitch + (uint64_t)x * sizeof(PixelT)) : 0u)
+                    | (kPack ? 0xFFFF0000u : 0u);
+        }
+        uint32_t mine = 0;
+#pragma unroll
+        for (int q = 0; q < kChainPer; ++q) {
+            if (i0 + q < i1) {
+                const uint32_t root = uf_find(lpar, i0 + q);
+                set_id(q, root);
+                mine += root == i0 + q ? 1u : 0u;
+                gi[i0 + q] = get_i(q);
+            }
+        }
+        __syncthreads();   // every find is done: the forest's root slots now take the component numbers
+        {
+            uint32_t slot = block_exclusive_scan<kChainThreads>(mine, s_wave, before);
+#pragma unroll
+            for (int q = 0; q < kChainPer; ++q)
+                if (i0 + q < i1 && get_id(q) == i0 + q) lpar[i0 + q] = slot++;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kChainPer; ++q)
+            if (i0 + q < i1) set_id(q, lpar[get_id(q)]);
+        __syncthreads();   // the forest is dead from here on: its LDS becomes accumulators + record staging
+        if (A.stop_after == 4) return;
+
+        // ---- R: kChainSlots components at a time --------------------------------------------------------------
+        ChainAcc* s_acc = reinterpret_cast<ChainAcc*>(s_big);
+        uint32_t* s_out = reinterpret_cast<uint32_t*>(s_big + kChainSlots * sizeof(ChainAcc));
+        const uint32_t ncomp = min(before, sa.max_comp);
+        for (uint32_t c0 = 0; c0 < ncomp; c0 += kChainSlots) {
+            if (tid < kChainSlots) {
+                ChainAcc z;
+                z.sum_i = z.sum_xi = z.sum_yi = z.peak = 0ull;
+                z.x_min = 0xFFFFFFFFu; z.x_max = 0u; z.y_min = 0xFFFFFFFFu; z.y_max = 0u;
+                z.num_pixels = 0u; z.pad = 0u;
+                s_acc[tid] = z;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < kChainPer; ++q) {
+                const uint32_t c = get_id(q) - c0;    // (an unused slot's 0xFFFF - c0 is never below kChainSlots: c0 < kChainLdsEntries)
+                if (c < (uint32_t)kChainSlots) {
+                    uint32_t yx = exy[q];
+                    // (opaque: or the compiler computes every entry's products once, ahead of this loop over c0, and
+                    // spills a hundred registers to hold them)
+                    asm volatile("" : "+v"(yx));
+                    const uint32_t y = yx >> 16, x = yx & 0xFFFFu;
+                    const uint32_t ki = y * W + x;
+                    const unsigned long long I = get_i(q);
+                    ChainAcc* r = &s_acc[c];
+                    atomicMin(&r->x_min, x); atomicMax(&r->x_max, x);
+                    atomicMin(&r->y_min, y); atomicMax(&r->y_max, y);
+                    atomicAdd(&r->num_pixels, 1u);
+                    atomicAdd(&r->sum_i, I);
+                    atomicAdd(&r->sum_xi, (2ull * x + 1ull) * I);
+                    atomicAdd(&r->sum_yi, (2ull * y + 1ull) * I);
+                    // highest intensity, ties -> smallest (y, x) = smallest k
+                    // (connected_components.hpp:125-170, connected_components.cc:143-157)
+                    atomicMax(&r->peak, (I << 32) | (unsigned long long)(0xFFFFFFFFu - ki));
+                }
+            }
+            __syncthreads();
+            const uint32_t here = min((uint32_t)kChainSlots, ncomp - c0);
+            if ((uint32_t)tid < here) {
+                const ChainAcc r = s_acc[tid];
+                WireRec2 o;
+                chain_record(sa, W, r.num_pixels, r.sum_i, r.sum_xi, r.sum_yi, r.x_min, r.x_max, r.y_min, r.y_max,
+                             0xFFFFFFFFu - (uint32_t)(r.peak & 0xFFFFFFFFull), (uint32_t)(r.peak >> 32), s_sm, o);
+                *reinterpret_cast<WireRec2*>(&s_out[tid * (sizeof(WireRec2) / 4)]) = o;
+            }
+            __syncthreads();
+            {
+                uint32_t* dst = reinterpret_cast<uint32_t*>(recs + c0);
+                const uint32_t ndw = here * (uint32_t)(sizeof(WireRec2) / 4);
+                for (uint32_t w = tid; w < ndw; w += kChainThreads) dst[w] = s_out[w];
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---- denser frames: the same stages on the global arrays (the bodies of k_union / k_reduce_roots / k_finalize_roots)
+        for (uint32_t i = tid; i < n; i += kChainThreads) gi[i] = pixel_at(gk[i]);
+        for (uint32_t i = tid; i < n; i += kChainThreads) {
+            const uint32_t ki = gk[i];
+            const uint32_t y = ki / W;
+            const bool starts = i == 0 || gk[i - 1] + 1 != ki;
+            if (!starts && ki - y * W == 0) uf_union(gpar, i - 1, i);
+            if (y + 1 >= H) continue;
+            uint32_t lo = max(i + 1, s_row[y + 1]), hi = min(min(n, i + 1 + W), s_row[y + 2]);
+            const uint32_t key = ki + W;
+            while (lo < hi) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (gk[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            if (lo < n && gk[lo] == key) {
+                if (starts || lo == 0 || gk[lo - 1] + 1 != key) uf_union(gpar, i, lo);
+            }
+        }
+        __syncthreads();
+        if (A.stop_after == 3) return;
+        for (uint32_t i0 = tid; i0 < n; i0 += kChainThreads) {
+            // the thread of a run's first entry (runs are also cut every 32 entries) sums the run in registers
+            const uint32_t k0 = gk[i0];
+            const uint32_t y = k0 / W, x0 = k0 - y * W;
+            // (consecutive k across a row end -- the reference's row-wrap edge -- is one component but two rows: cut there)
+            const bool owner = (i0 & 31u) == 0u || x0 == 0u || gk[i0 - 1] + 1 != k0;
+            if (!owner) continue;
+            const uint32_t ri = uf_find(gpar, i0);
+            uint32_t npx = 0u, x_max = x0;
+            unsigned long long s_i = 0, s_xi = 0, pk = 0;
+            uint32_t j = i0;
+            for (;;) {
+                const unsigned long long I = gi[j];
+                const uint32_t x = x0 + (j - i0);
+                ++npx;
+                x_max = x;
+                s_i += I;
+                s_xi += (2ull * x + 1ull) * I;
+                pk = max(pk, (I << 32) | (unsigned long long)(0xFFFFFFFFu - j));   // ties -> smallest list index
+                ++j;
+                if (j >= n || (j & 31u) == 0u || x + 1 >= W || gk[j] != k0 + (j - i0)) break;
+            }
+            CompAcc2* r = gacc + ri;
+            atomicMin(&r->x_min, x0); atomicMax(&r->x_max, x_max);
+            atomicMin(&r->y_min, y); atomicMax(&r->y_max, y);
+            atomicAdd(&r->num_pixels, npx);
+            atomicAdd(&r->sum_i, s_i);
+            atomicAdd(&r->sum_xi, s_xi);
+            atomicAdd(&r->sum_yi, (2ull * y + 1ull) * s_i);
+            atomicMax(&r->peak, pk);
+        }
+        __threadfence();
+        __syncthreads();
+        uint32_t* s_out = reinterpret_cast<uint32_t*>(s_big);
+        for (uint32_t base = 0; base < n; base += kChainThreads) {
+            const uint32_t i = base + (uint32_t)tid;
+            const bool root = i < n && ld_parent(gpar + i) == i;
+            uint32_t nroots;
+            const uint32_t slot = block_exclusive_scan<kChainThreads>(root ? 1u : 0u, s_wave, nroots);
+            if (root && before + slot < sa.max_comp) {
+                // agent-scope loads: the accumulator was built by atomics at the L2
+                const unsigned long long* p = reinterpret_cast<const unsigned long long*>(gacc + i);
+                unsigned long long q[6];
+#pragma unroll
+                for (int w = 0; w < 6; ++w) q[w] = __hip_atomic_load(p + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t npx = __hip_atomic_load(&(gacc + i)->num_pixels, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t pi = min(0xFFFFFFFFu - (uint32_t)(q[3] & 0xFFFFFFFFull), n - 1);  // (never clamps: every root owns a pixel)
+                WireRec2 o;
+                chain_record(sa, W, npx, q[0], q[1], q[2], (uint32_t)q[4], (uint32_t)(q[4] >> 32), (uint32_t)q[5], (uint32_t)(q[5] >> 32),
+                             gk[pi], (uint32_t)(q[3] >> 32), s_sm, o);
+                *reinterpret_cast<WireRec2*>(&s_out[slot * (sizeof(WireRec2) / 4)]) = o;
+            }
+            __syncthreads();
+            {
+                const uint32_t first = min(before, sa.max_comp), last = min(before + nroots, sa.max_comp);
+                uint32_t* dst = reinterpret_cast<uint32_t*>(recs + first);
+                const uint32_t ndw = (last - first) * (uint32_t)(sizeof(WireRec2) / 4);
+                for (uint32_t w = tid; w < ndw; w += kChainThreads) dst[w] = s_out[w];
+            }
+            before += nroots;
+            __syncthreads();
+        }
+    }
+
+    // ---- counters: device copies for the other consumers of the lists, host copies for ffs_wait() --------------
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t flags = *a.overflow;   // what the dense stages raised (bright-list overflow, corrupt chunk)
+        if (total > a.cap) flags |= 1u;
+        if (before > sa.max_comp) flags |= 2u;
+        a.num_strong[frame] = total;
+        a.n_comp[frame] = before;
+        const size_t B = A.max_batch;
+        A.h_counts[frame] = total;
+        A.h_counts[B + frame] = before;
+        A.h_counts[10 * B + 1 + frame] = flags;
+    }
+    if (tid < 8) {
+        a.summary[(uint64_t)frame * 8 + tid] = s_sm[tid];
+        A.h_counts[2 * (size_t)A.max_batch + (size_t)frame * 8 + tid] = s_sm[tid];
+    }
+}
+template __global__ void k_frame_chain<uint16_t>(const ChainArgs);
+template __global__ void k_frame_chain<uint32_t>(const ChainArgs);
+
+}  // namespace ffsamd
