@@ -55,6 +55,7 @@ struct Knobs {
     long long target_waves = 16384;
     int emit_variant = 1, ccl_variant = 2, link_runs = 1, ccl_grid = 32, ccl_cus = 0, direct_recs = 1;
     int sched = 0;             // FFS_SCHED (experiment): 1 = sparse chain on a high-priority stream of its own; 2 = also every dense kernel of the context on ONE stream
+    int dense_mask = 0;        // FFS_DENSE_MASK=1: always produce the dense byte mask
     int chain_skip = 0;        // FFS_CHAIN_SKIP (timing experiments only; results are then meaningless): 1 = no sparse chain, 2 = stop after emit, 4 = after union, 8 = after reduce
     int bright_cap = 1 << 20;  // FFS_BRIGHT_CAP: entries of the bright-window list actually used (tests shrink it)
     static int env_int(const char* name, int dflt) {
@@ -76,6 +77,7 @@ struct Knobs {
         direct_recs = env_int("FFS_DIRECT_RECS", 1);
         chain_skip = env_int("FFS_CHAIN_SKIP", 0);
         sched = env_int("FFS_SCHED", 0);
+        dense_mask = env_int("FFS_DENSE_MASK", 0);
         bright_cap = std::max(0, std::min(1 << 20, env_int("FFS_BRIGHT_CAP", 1 << 20)));
     }
 };
@@ -182,6 +184,7 @@ struct ffs_stream {
     uint32_t* h_counts = nullptr;  // [max_batch] num_strong | [max_batch] n_comp | [max_batch*8] summary | [1] overflow
     ReflOut* h_recs = nullptr;
     uint32_t* h_counts_dev = nullptr;  // device-side address of h_counts (k_frame_chain writes the counters itself)
+    bool dense_valid = false;      // the byte masks of the last batch were produced
     bool chain_mode = false;       // this batch went through k_frame_chain: records at frame * max_comp, flags per frame
     ReflOut* h_recs_dev = nullptr;  // device-side address of h_recs when the records are written straight to the host
     bool direct_recs = false;
@@ -722,6 +725,10 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
     a.bright_list = s->d_bright;
     a.bright_cap = std::min<uint32_t>(kBrightCap, (uint32_t)c->knobs.bright_cap);
     a.dbg = c->knobs.k1_debug;
+    // The byte mask (the reference kernel's result_strong, 1 byte per pixel) is an OUTPUT only when it was asked for
+    // (want_strong_mask: --writeout, parity tests): the hot path's own strong mask is the bit plane, and the 0.58 GB of
+    // zeros per 32 Eiger frames cost the streaming kernel 15 % (FFS_DENSE_MASK=1 forces them, for A/B and the roofline leg)
+    a.dense_mask = (p.want_strong_mask || c->knobs.dense_mask || (a.dbg & 16)) && !(a.dbg & 8) ? 1 : 0;
     a.ginfo = c->d_ginfo;
     a.mmap = c->d_mmap;
     a.gpitch = (uint32_t)L.pitch_px * (uint32_t)c->pixel_bytes / 4;
@@ -988,7 +995,10 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     // FFS_EMIT (A/B): 1 (default) = one wave per tile, runs linked in the same pass; 0 = one workgroup per tile + k_link_runs
     const int emit_variant = c->knobs.emit_variant;
     const int skip = c->knobs.chain_skip;
-    ca.dense_bytes = 1;
+    // (the kernels that zero-fill the mask: streaming kernels only when asked; the older threshold kernels and the
+    // extended algorithm's last pass always do)
+    ca.dense_bytes = (!one_kernel || ta.dense_mask) ? 1 : 0;
+    s->dense_valid = ca.dense_bytes != 0;
     // FFS_CCL = 2 (default): the whole sparse stage in one launch, one workgroup per frame (kernels_chain.hpp)
     s->chain_mode = root_mode && ccl_variant >= 2 && s->direct_recs && s->h_counts_dev && c->n_tiles <= kChainMaxTiles && L.H <= kChainMaxRows && !skip;
     if (s->chain_mode) {
@@ -1746,6 +1756,15 @@ extern "C" int ffs_stream_debug_bitplane(ffs_stream* s, uint32_t frame, int whic
         return FFS_ERR_INVALID;
     }
     HIP_TRY(c, hipSetDevice(c->device));
+    if (which == 0 && s->bits_cleared && !s->dense_valid) {
+        // the compaction consumed (and cleared) the plane and nobody asked for the byte mask: the strong-pixel list has them
+        const uint32_t ns = std::min<uint32_t>(s->h_counts[frame], s->cap);
+        std::vector<uint32_t> ks(ns);
+        if (ns) HIP_TRY(c, hipMemcpy(ks.data(), s->d_list_k + (size_t)frame * s->cap, (size_t)ns * 4, hipMemcpyDeviceToHost));
+        std::memset(host_out, 0, (size_t)L.W * L.H);
+        for (uint32_t k : ks) host_out[k] = 1;
+        return FFS_OK;
+    }
     if (which == 0 && s->bits_cleared) {
         // the compaction consumed (and cleared) the plane; the byte mask holds the same pixels
         HIP_TRY(c, hipMemcpy2D(host_out, L.W, s->d_sbytes + (size_t)frame * L.bytes_frame_stride, L.bpitch, L.W, L.H,

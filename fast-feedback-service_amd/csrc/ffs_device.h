@@ -74,6 +74,7 @@ struct ThresholdArgs {
     uint2* bright_list;        // [bright_cap] (frame << 16 | x, y)
     uint32_t bright_cap;
     uint32_t* overflow;        // status word: 8 = the bright-window list overflowed
+    int dense_mask;            // the streaming kernels zero-fill the byte mask (somebody wants it); else they leave it alone
     int dbg;                   // FFS_K1_DEBUG: timing experiments only (results are wrong when set)
 };
 

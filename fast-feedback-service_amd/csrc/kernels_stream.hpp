@@ -526,7 +526,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                     pass = bf * __builtin_fabsf(bf) > kS * tf;
                 }
                 const bool flag = owned && pass && !(a.dbg & 1);
-                if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, so_bytes, 2 /* nt: written once, read much later */);
+                if (a.dense_mask) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, so_bytes, 2 /* nt: written once, read much later */);
                 const unsigned long long fm = __builtin_amdgcn_ballot_w64(flag);
                 if (fm) {  // wave-uniform
                     const int nfl = __popcll(fm);
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
                 Wn[3] = dpp_shl_add(col[2], TR);
 
                 const int yout = __builtin_amdgcn_readfirstlane(yb0 + (i - 6));
-                if (!(a.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, (uint32_t)yout * a.bpitch, 2);
+                if (a.dense_mask) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, (uint32_t)yout * a.bpitch, 2);
 
                 const uint32_t xmin = min(min(min(Wn[0], Wn[1]), Wn[2]), Wn[3]);
                 const uint32_t pmax = max(max(max(ring[sc][0], ring[sc][1]), ring[sc][2]), ring[sc][3]);
