@@ -54,7 +54,9 @@ struct Knobs {
     int k1_variant = 2, ext_variant = 2, k1_debug = 0, k1_group = 1 << 30, k1_ahead = 2;
     long long target_waves = 16384;
     int emit_variant = 1, ccl_variant = 2, link_runs = 1, ccl_grid = 32, ccl_cus = 0, direct_recs = 1;
-    int sched = 0;             // FFS_SCHED (experiment): 1 = sparse chain on a high-priority stream of its own; 2 = also every dense kernel of the context on ONE stream
+    int sched = 3;             // FFS_SCHED: 1 = sparse chain on a high-priority stream of its own; 2 = also every dense kernel of the context on ONE stream
+    int fix_aside = 1;         // FFS_FIX_ASIDE: k_bright_fix in the sparse stream (SCHED >= 1)
+    int decode_dense = 0;      // FFS_DECODE_DENSE: the decode kernel runs in the dense kernels' stream (0: in the upload stream)
     int dense_mask = 0;        // FFS_DENSE_MASK=1: always produce the dense byte mask
     int chain_skip = 0;        // FFS_CHAIN_SKIP (timing experiments only; results are then meaningless): 1 = no sparse chain, 2 = stop after emit, 4 = after union, 8 = after reduce
     int bright_cap = 1 << 20;  // FFS_BRIGHT_CAP: entries of the bright-window list actually used (tests shrink it)
@@ -76,8 +78,10 @@ struct Knobs {
         ccl_cus = env_int("FFS_CCL_CUS", 0);
         direct_recs = env_int("FFS_DIRECT_RECS", 1);
         chain_skip = env_int("FFS_CHAIN_SKIP", 0);
-        sched = env_int("FFS_SCHED", 0);
+        sched = env_int("FFS_SCHED", 3);
         dense_mask = env_int("FFS_DENSE_MASK", 0);
+        decode_dense = env_int("FFS_DECODE_DENSE", 0);
+        fix_aside = env_int("FFS_FIX_ASIDE", 1);
         bright_cap = std::max(0, std::min(1 << 20, env_int("FFS_BRIGHT_CAP", 1 << 20)));
     }
 };
@@ -96,8 +100,11 @@ struct ffs_ctx {
     uint8_t* d_ginfo = nullptr;  // per-group mask bits + window-count bounds (kernels_stream.hpp)
     uint8_t* d_mmap = nullptr;   // per-pixel window counts
     hipStream_t dense_st = nullptr;  // FFS_SCHED=2: the one stream of the dense kernels
+    hipStream_t dense_st_b = nullptr;
+    hipStream_t up_st = nullptr;     // ... and the one stream of uploads and decoding
     hipStream_t sparse_st[2] = {nullptr, nullptr};  // FFS_SCHED=3: the sparse chains of the context's streams, alternating
     int n_streams_made = 0;
+    std::mutex stream_mu;            // guards the lazy creation of the shared streams
     ThreadError err;  // the calling thread's most recent error on any context
 };
 
@@ -149,10 +156,11 @@ struct ffs_stream {
     uint32_t *d_pack_k = nullptr, *d_pack_i = nullptr;  // a batch's lists packed end to end for another device's 3D stack
     StackSlice *d_pack_tab = nullptr, *h_pack_tab = nullptr;
     hipStream_t st = nullptr;    // threshold kernels (+ H2D)
+    hipStream_t st_up = nullptr; // uploads + decode; == st unless the dense kernels of the context share one stream
     bool st2_shared = false;
     bool st_shared = false;      // st is the context's dense stream (not ours to destroy)
     hipStream_t st2 = nullptr;   // compaction + connected components + D2H; == st unless the CUs are split
-    hipEvent_t ev[6] = {};
+    hipEvent_t ev[7] = {};   // [6]: the compressed chunks and their block table are on the device
     // device
     uint8_t* d_img = nullptr;
     uint8_t* d_bits = nullptr;
@@ -399,6 +407,8 @@ extern "C" void ffs_ctx_destroy(ffs_ctx* c) {
     if (c->d_ginfo) (void)hipFree(c->d_ginfo);
     if (c->d_mmap) (void)hipFree(c->d_mmap);
     if (c->dense_st) (void)hipStreamDestroy(c->dense_st);
+    if (c->up_st) (void)hipStreamDestroy(c->up_st);
+    if (c->dense_st_b) (void)hipStreamDestroy(c->dense_st_b);
     for (auto st : c->sparse_st) if (st) (void)hipStreamDestroy(st);
     delete c;
 }
@@ -523,6 +533,7 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     (void)hipSetDevice(s->ctx->device);
     if (s->job.joinable()) s->job.join();
     if (s->big) ffs_stream_destroy(s->big);
+    if (s->st_up && s->st_up != s->st) (void)hipStreamSynchronize(s->st_up);
     if (s->st) (void)hipStreamSynchronize(s->st);
     if (s->st2 && s->st2 != s->st) { (void)hipStreamSynchronize(s->st2); if (!s->st2_shared) (void)hipStreamDestroy(s->st2); }
     // (d_n_comp, d_summary and d_overflow live inside the d_num_strong allocation)
@@ -590,14 +601,23 @@ static int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uin
             STREAM_TRY(hipExtStreamCreateWithCUMask(&s->st, (uint32_t)words, m_thr.data()));
             STREAM_TRY(hipExtStreamCreateWithCUMask(&s->st2, (uint32_t)words, m_ccl.data()));
         } else if (c->knobs.sched >= 1) {
+            std::lock_guard<std::mutex> lock(c->stream_mu);
             int lo = 0, hi = 0;
             STREAM_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (least, greatest)
             if (c->knobs.sched >= 2) {
                 if (!c->dense_st) STREAM_TRY(hipStreamCreateWithPriority(&c->dense_st, hipStreamNonBlocking, c->knobs.sched >= 3 ? (lo + hi) / 2 : lo));
                 s->st = c->dense_st;
+                if (c->knobs.sched >= 4 && (c->n_streams_made & 1)) {   // (experiment) two dense streams, alternating
+                    if (!c->dense_st_b) STREAM_TRY(hipStreamCreateWithPriority(&c->dense_st_b, hipStreamNonBlocking, (lo + hi) / 2));
+                    s->st = c->dense_st_b;
+                }
                 s->st_shared = true;
             } else {
                 STREAM_TRY(hipStreamCreateWithPriority(&s->st, hipStreamNonBlocking, lo));
+            }
+            if (c->knobs.sched >= 2) {
+                if (!c->up_st) STREAM_TRY(hipStreamCreateWithFlags(&c->up_st, hipStreamNonBlocking));
+                s->st_up = c->up_st;
             }
             if (c->knobs.sched >= 3) {
                 const int j = c->n_streams_made++ & 1;
@@ -612,6 +632,7 @@ static int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uin
             s->st2 = s->st;
         }
     }
+    if (!s->st_up) s->st_up = s->st;
     for (auto& e : s->ev) STREAM_TRY(hipEventCreate(&e));
     STREAM_TRY(dmalloc(&s->d_img, B * L.frame_stride));
     STREAM_TRY(dmalloc(&s->d_bits, B * L.plane_frame_stride));
@@ -838,7 +859,8 @@ static int ensure_extended_buffers(ffs_stream* s) {
     return FFS_OK;
 }
 
-static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
+// fix_st: the stream of the bright-window fix-up that follows a streaming kernel (nullptr: the dense stream itself)
+static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames, hipStream_t fix_st = nullptr, hipEvent_t fix_after = nullptr) {
     if (a.variant >= 2) {
         // the whole threshold in one kernel: final strong plane + per-tile counts (atomics into zeroed counters)
         ThresholdArgs b = a;
@@ -851,14 +873,22 @@ static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_
         const int ahead = s->ctx->knobs.k1_ahead;
         if (s->ctx->pixel_bytes == 4) {
             hipLaunchKernelGGL(k_stream_u32<2>, dim3((unsigned)(b.n_strips * bands8s), n_groups), dim3(64), 0, s->st, b);
-            hipLaunchKernelGGL(k_bright_fix<uint32_t>, dim3(32), dim3(256), 0, s->st, b);
+            if (fix_st) {
+                (void)hipEventRecord(fix_after, s->st);
+                (void)hipStreamWaitEvent(fix_st, fix_after, 0);
+            }
+            hipLaunchKernelGGL(k_bright_fix<uint32_t>, dim3(32), dim3(256), 0, fix_st ? fix_st : s->st, b);
             return;
         }
         if (ahead >= 3)
             hipLaunchKernelGGL(k_stream_u16<3>, dim3((unsigned)(b.n_strips * bands8s), n_groups), dim3(64), 0, s->st, b);
         else
             hipLaunchKernelGGL(k_stream_u16<2>, dim3((unsigned)(b.n_strips * bands8s), n_groups), dim3(64), 0, s->st, b);
-        hipLaunchKernelGGL(k_bright_fix<uint16_t>, dim3(32), dim3(256), 0, s->st, b);
+        if (fix_st) {
+            (void)hipEventRecord(fix_after, s->st);
+            (void)hipStreamWaitEvent(fix_st, fix_after, 0);
+        }
+        hipLaunchKernelGGL(k_bright_fix<uint16_t>, dim3(32), dim3(256), 0, fix_st ? fix_st : s->st, b);
         return;
     }
     const int bands8 = (a.n_bands + 7) / 8 * 8;  // XCD-aware mapping wants a multiple of 8 bands
@@ -925,6 +955,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     s->cur_fstride = fstride;
 
     (void)hipGetLastError();  // drop any stale error state: the check below is for OUR launches
+    if (s->st_up != s->st) HIP_TRY(c, hipStreamWaitEvent(s->st, s->ev[1], 0));   // the frames are in place (upload / decode stream)
     if (p.algorithm == FFS_ALGO_DISPERSION_EXTENDED) {
         const int rc = ensure_extended_buffers(s);
         if (rc != FFS_OK) return rc;
@@ -944,11 +975,19 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     if (p.algorithm == FFS_ALGO_DISPERSION_EXTENDED) {
         launch_extended(s, ta, n);
     } else {
-        launch_candidates(s, ta, n);
+        // with a sparse stream of its own, the bright-window fix-up goes there: the dense stream holds streaming
+        // kernels only, back to back
+        const bool fix_aside = one_kernel && s->st2 != s->st && c->knobs.fix_aside;
+        launch_candidates(s, ta, n, fix_aside ? s->st2 : nullptr, s->ev[2]);
         launch_exact(s, ta, n);
+        if (fix_aside) {   // (ev[2] was recorded behind the streaming kernel, and st2 waits for it already)
+            HIP_TRY(c, hipGetLastError());
+            goto dense_done;
+        }
     }
     HIP_TRY(c, hipEventRecord(s->ev[2], s->st));
     if (s->st2 != s->st) HIP_TRY(c, hipStreamWaitEvent(s->st2, s->ev[2], 0));
+dense_done:
 
     CclArgs ca{};
     ca.image = d_img;
@@ -1157,12 +1196,12 @@ extern "C" int ffs_submit(ffs_stream* s, const void* host_pixels, uint32_t n_fra
     }
     const Layout& L = c->L;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipEventRecord(s->ev[0], s->st));
+    HIP_TRY(c, hipEventRecord(s->ev[0], s->st_up));
     // one 2D copy: the default device layout keeps frames contiguous (frame_stride = H * pitch)
     const size_t row = (size_t)L.W * c->pixel_bytes;
     HIP_TRY(c, hipMemcpy2DAsync(s->d_img, L.pitch, host_pixels, row, row, (size_t)L.H * n_frames,
-                                hipMemcpyHostToDevice, s->st));
-    HIP_TRY(c, hipEventRecord(s->ev[1], s->st));
+                                hipMemcpyHostToDevice, s->st_up));
+    HIP_TRY(c, hipEventRecord(s->ev[1], s->st_up));
     s->first_id = first_frame_id;
     return enqueue_batch(s, s->d_img, L.pitch, L.frame_stride, n_frames);
 }
@@ -1252,7 +1291,7 @@ static int stage_chunks(ffs_stream* s, const void* const* chunks, const size_t* 
         c->err = "ffs_submit_compressed: more than 4 GiB of chunks in one batch";
         return FFS_ERR_INVALID;
     }
-    HIP_TRY(c, hipMemcpyAsync(s->d_comp + lo, s->h_img + lo, hi - lo, hipMemcpyHostToDevice, s->st));
+    HIP_TRY(c, hipMemcpyAsync(s->d_comp + lo, s->h_img + lo, hi - lo, hipMemcpyHostToDevice, s->st_up));
     return FFS_OK;
 }
 
@@ -1300,7 +1339,7 @@ static int index_blocks(ffs_stream* s, const std::vector<size_t>& base, const st
         err = "ffs_submit_compressed: block lengths run past the end of a chunk";
         return FFS_ERR_INVALID;
     }
-    const hipError_t e = hipMemcpyAsync(s->d_tab, s->h_tab, (size_t)n * stride * sizeof(uint2), hipMemcpyHostToDevice, s->st);
+    const hipError_t e = hipMemcpyAsync(s->d_tab, s->h_tab, (size_t)n * stride * sizeof(uint2), hipMemcpyHostToDevice, s->st_up);
     if (e != hipSuccess) {
         err = std::string("hipMemcpyAsync(block table): ") + hipGetErrorString(e);
         return FFS_ERR_DEVICE;
@@ -1308,7 +1347,7 @@ static int index_blocks(ffs_stream* s, const std::vector<size_t>& base, const st
     return FFS_OK;
 }
 
-static void launch_decode(ffs_stream* s, uint32_t n) {
+static void launch_decode(ffs_stream* s, uint32_t n, hipStream_t st) {
     ffs_ctx* c = s->ctx;
     DecodeArgs da{};
     da.comp = s->d_comp;
@@ -1325,8 +1364,8 @@ static void launch_decode(ffs_stream* s, uint32_t n) {
     da.tail_elems = s->dec_tail;
     da.error = s->d_overflow;
     const dim3 grid(s->dec_blocks + 1, n);
-    if (c->pixel_bytes == 2) hipLaunchKernelGGL(k_bshuf_lz4_decode<2>, grid, dim3(64), 0, s->st, da);
-    else hipLaunchKernelGGL(k_bshuf_lz4_decode<4>, grid, dim3(64), 0, s->st, da);
+    if (c->pixel_bytes == 2) hipLaunchKernelGGL(k_bshuf_lz4_decode<2>, grid, dim3(64), 0, st, da);
+    else hipLaunchKernelGGL(k_bshuf_lz4_decode<4>, grid, dim3(64), 0, st, da);
 }
 
 static int ffs_submit_compressed_impl(ffs_stream* s, const void* const* chunks, const size_t* chunk_bytes,
@@ -1342,7 +1381,7 @@ static int ffs_submit_compressed_impl(ffs_stream* s, const void* const* chunks, 
         return FFS_ERR_INVALID;
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipEventRecord(s->ev[0], s->st));
+    HIP_TRY(c, hipEventRecord(s->ev[0], s->st_up));
     std::vector<size_t> base;
     int rc = stage_chunks(s, chunks, chunk_bytes, n_frames, base);
     if (rc != FFS_OK) return rc;
@@ -1364,9 +1403,16 @@ static int ffs_submit_compressed_impl(ffs_stream* s, const void* const* chunks, 
         int r = index_blocks(s, base, sizes, s->job_err);
         if (r == FFS_OK) {
             (void)hipGetLastError();
-            launch_decode(s, n_frames);
-            hipError_t e = hipGetLastError();
-            if (e == hipSuccess) e = hipEventRecord(s->ev[1], s->st);
+            // the decode kernel runs with the dense kernels (in their order), behind the copies of its input
+            hipError_t e = hipSuccess;
+            hipStream_t dst = c->knobs.decode_dense ? s->st : s->st_up;
+            if (dst != s->st_up) {
+                e = hipEventRecord(s->ev[6], s->st_up);
+                if (e == hipSuccess) e = hipStreamWaitEvent(dst, s->ev[6], 0);
+            }
+            launch_decode(s, n_frames, dst);
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipEventRecord(s->ev[1], dst);
             if (e != hipSuccess) {
                 s->job_err = std::string("decode launch: ") + hipGetErrorString(e);
                 r = FFS_ERR_DEVICE;
@@ -1399,17 +1445,17 @@ extern "C" int ffs_decode_only(ffs_stream* s, const void* const* chunks, const s
         if (rc != FFS_OK) c->err = err;
     }
     if (rc != FFS_OK) {
-        (void)hipStreamSynchronize(s->st);
+        (void)hipStreamSynchronize(s->st_up);
         return rc;
     }
     (void)hipGetLastError();
-    HIP_TRY(c, hipEventRecord(s->ev[0], s->st));
-    for (uint32_t i = 0; i < iters; ++i) launch_decode(s, n_frames);
-    HIP_TRY(c, hipEventRecord(s->ev[1], s->st));
+    HIP_TRY(c, hipEventRecord(s->ev[0], s->st_up));
+    for (uint32_t i = 0; i < iters; ++i) launch_decode(s, n_frames, s->st_up);
+    HIP_TRY(c, hipEventRecord(s->ev[1], s->st_up));
     HIP_TRY(c, hipGetLastError());
     uint32_t flag = 0;
-    HIP_TRY(c, hipMemcpyAsync(&flag, s->d_overflow, 4, hipMemcpyDeviceToHost, s->st));
-    HIP_TRY(c, hipStreamSynchronize(s->st));
+    HIP_TRY(c, hipMemcpyAsync(&flag, s->d_overflow, 4, hipMemcpyDeviceToHost, s->st_up));
+    HIP_TRY(c, hipStreamSynchronize(s->st_up));
     float ms = 0;
     HIP_TRY(c, hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
     if (ms_decode) *ms_decode = ms / iters;
@@ -1446,7 +1492,7 @@ static int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32
     if (s->job.joinable()) {
         s->job.join();
         if (s->job_rc != FFS_OK) {
-            (void)hipStreamSynchronize(s->st);
+            (void)hipStreamSynchronize(s->st_up);
             s->busy = false;
             c->err = s->job_err;
             return s->job_rc;
