@@ -42,7 +42,7 @@ constexpr int kChainWaves = kChainThreads / 64;
 constexpr int kChainMaxRows = 4480;     // per-row offsets kept in LDS; taller frames take the four kernels
 constexpr int kChainMaxTiles = kChainMaxRows / kTileRows;
 constexpr int kChainListCap = 448;      // non-zero plane words a wave stages (a round of loads adds at most 256)
-constexpr int kChainQuads = 4;          // 16-byte plane loads a lane has in flight per batch (two batches are live)
+constexpr int kChainQuads = 4;          // rounds (4 words per lane each) per batch of plane loads; three batches are live
 constexpr int kChainLdsEntries = 20480; // strong pixels of a frame whose union-find forest fits LDS
 constexpr int kChainPer = kChainLdsEntries / kChainThreads;   // consecutive entries per thread in phases U / P / R
 constexpr int kChainGroup = 10;         // entries a thread searches side by side in phase U (kChainPer = 2 groups)
@@ -165,8 +165,10 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
     uint32_t* gpar = a.parent + (uint64_t)frame * a.cap;
     CompAcc2* gacc = a.acc2 + (uint64_t)frame * a.cap;
     const uint8_t* img = (const uint8_t*)a.image + (uint64_t)frame * a.frame_stride;
-    // the forest as the later phases see it (generic pointer: LDS or global)
-    uint32_t* lpar = in_lds ? reinterpret_cast<uint32_t*>(s_big) : gpar;
+    // the forest of a frame held in LDS.  (Never through a pointer that might also be global: a FLAT access may complete
+    // out of order with the global ones, so every wait after it has to be for ALL outstanding memory operations, and the
+    // loads this kernel keeps in flight would be waited for one by one.)
+    uint32_t* spar = reinterpret_cast<uint32_t*>(s_big);
     auto pixel_at = [&](uint32_t kv) -> uint32_t {
         const uint32_t y = kv / W, x = kv - y * W;
         return (uint32_t)*reinterpret_cast<const PixelT*>(img + (uint64_t)y * a.pitch + (uint64_t)x * sizeof(PixelT));
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                             const uint32_t pv = !linked ? at : (b == 0 ? at - 1 : run_first);
                             gk[at] = (uint32_t)y * W + (uint32_t)(xb + b);
                             if (in_lds) {
-                                if (at < (uint32_t)kChainLdsEntries) lpar[at] = pv;
+                                if (at < (uint32_t)kChainLdsEntries) spar[at] = pv;
                             } else {
                                 gpar[at] = pv;
                                 if (!linked) {  // a run start may end up a root: fresh accumulator
@@ -244,13 +246,10 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
             // moves to the front
             auto drain = [&](bool all) {
                 int done = 0;
-                while (n_list - done >= 64) {
-                    place(done, 64);
-                    done += 64;
-                }
-                if (all && n_list > done) {
-                    place(done, n_list - done);
-                    done = n_list;
+                while (n_list - done >= (all ? 1 : 64)) {
+                    const int cnt = min(64, n_list - done);
+                    place(done, cnt);
+                    done += cnt;
                 }
                 if (done == 0) return;
                 last_g = s_g[done - 1];
@@ -264,57 +263,58 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                 n_list = rem;
             };
 
-            const int nrounds = (nw + 255) / 256;   // a round = 64 lanes x 4 words
-            // rounds whose rows lie in tiles without a strong pixel are not loaded at all (wave-uniform test)
+            const int nrounds = (nw + 255) / 256;   // a round = 4 x 64 consecutive words: lane L holds words 256 r + 64 c + L
+            // Rounds whose words lie in tiles without a strong pixel are not loaded at all (wave-uniform test).  Rounds are
+            // visited in increasing order, so the tile of a round's first word is tracked, not divided for.
+            const int wpt = kTileRows * dpr;        // plane words per tile
+            int lt = 0;                             // tile (relative to tb) of the first word of the next round to load
             auto round_live = [&](int r) {
                 if (r >= nrounds) return false;
-                const int r0 = (r * 256) / dpr, r1 = min(r * 256 + 255, nw - 1) / dpr;
-                return s_toff[(yb + r1) / kTileRows + 1] != s_toff[(yb + r0) / kTileRows];
+                const int w0 = r * 256, w1 = min(w0 + 255, nw - 1);
+                while ((lt + 1) * wpt <= w0) ++lt;
+                int t1 = lt;
+                while ((t1 + 1) * wpt <= w1) ++t1;
+                return s_toff[tb + t1 + 1] != s_toff[tb + lt];
             };
-            auto load_batch = [&](int b, uint4 (&buf)[kChainQuads]) {
+            // (buffer loads: out of range -- beyond the wave's words, or switched off -- reads 0, so the loads are not
+            // wrapped in branches and the waits below can count them)
+            const rsrc_t r_words = make_rsrc(words, (uint32_t)nw * 4u);
+            // (buffer loads: out of range -- beyond the wave's words, or switched off -- reads 0, so the loads are not
+            // wrapped in branches and the waits below can count them)
+            auto load_batch = [&](int b, uint32_t (&buf)[kChainQuads][4]) {
 #pragma unroll
                 for (int q = 0; q < kChainQuads; ++q) {
                     const int r = b * kChainQuads + q;
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (round_live(r)) {
-                        const int g = (r * 64 + lane) * 4;
-                        if (g + 3 < nw) v = *reinterpret_cast<const uint4*>(words + g);   // (8 rows of a 4-byte-multiple pitch: 32-byte multiples)
-                        else if (g < nw) {
-                            v.x = words[g];
-                            if (g + 1 < nw) v.y = words[g + 1];
-                            if (g + 2 < nw) v.z = words[g + 2];
-                        }
-                    }
-                    buf[q] = v;
+                    const uint32_t off = round_live(r) ? (uint32_t)(r * 256 + lane) * 4u : 0x80000000u;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        buf[q][c] = __builtin_amdgcn_raw_buffer_load_b32(r_words, off, (uint32_t)c * 256u, 0);
                 }
             };
-            auto stage_batch = [&](int b, const uint4 (&buf)[kChainQuads]) {
+            // (no scan here: the 64 words of a quarter round are consecutive, so ballot + mbcnt keeps the order;
+            // and no global store, so the loads in flight are waited for by count, not all together)
+            auto stage_batch = [&](int b, const uint32_t (&buf)[kChainQuads][4]) {
 #pragma unroll
                 for (int q = 0; q < kChainQuads; ++q) {
                     const int r = b * kChainQuads + q;
-                    const uint4 v = buf[q];
-                    const uint32_t cnt = (v.x != 0u) + (v.y != 0u) + (v.z != 0u) + (v.w != 0u);
-                    if (__builtin_amdgcn_ballot_w64(cnt != 0u) == 0ull) continue;  // wave-uniform
-                    // (no global store in this loop: the loads in flight are waited for by count, not all together)
+                    if (__builtin_amdgcn_ballot_w64((buf[q][0] | buf[q][1] | buf[q][2] | buf[q][3]) != 0u) == 0ull) continue;  // wave-uniform
                     if (n_list + 256 > kChainListCap) drain(false);
-                    // the lanes' non-zero words keep their order: exclusive scan of the per-lane counts
-                    const uint32_t inc = wave_inclusive_scan(cnt);
-                    int e = n_list + (int)(inc - cnt);
-                    const int g = (r * 64 + lane) * 4;
-                    const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        if (vv[c]) {
-                            s_g[e] = (uint32_t)(g + c);
-                            s_w[e] = vv[c];
-                            ++e;
+                        const uint32_t w = buf[q][c];
+                        const unsigned long long nz = __builtin_amdgcn_ballot_w64(w != 0u);
+                        if (nz == 0ull) continue;  // wave-uniform
+                        if (w) {
+                            const int e = n_list + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));
+                            s_g[e] = (uint32_t)(r * 256 + c * 64 + lane);
+                            s_w[e] = w;
                         }
+                        n_list += __popcll(nz);
                     }
-                    n_list += __builtin_amdgcn_readlane((int)inc, 63);
                 }
             };
             // three batches of loads live: the one being staged and two in flight
-            uint4 b0[kChainQuads], b1[kChainQuads], b2[kChainQuads];
+            uint32_t b0[kChainQuads][4], b1[kChainQuads][4], b2[kChainQuads][4];
             const int nbatches = (nrounds + kChainQuads - 1) / kChainQuads;
             load_batch(0, b0);
             load_batch(1, b1);
@@ -366,6 +366,8 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
         // ---- U: vertical edges + row wrap (k_union<false> with the runs linked by the compaction) ----------------
         // The list stays in global memory (a dependent access ~1 us), so a thread runs the binary searches of
         // kChainGroup entries side by side: a step of all of them costs one round trip.
+        const rsrc_t r_gk = make_rsrc(gk, n * 4u);
+        constexpr uint32_t kOob = 0x80000000u;   // (an offset no resource reaches: the load returns 0)
         {
             uint32_t kprev = i0 > 0 && i0 < i1 ? gk[i0 - 1] : 0xFFFFFFF0u;
 #pragma unroll
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                 uint32_t ek[kChainGroup], lo[kChainGroup], hi[kChainGroup];
                 uint32_t starts = 0;
 #pragma unroll
-                for (int q = 0; q < kChainGroup; ++q) ek[q] = ib + q < i1 ? gk[ib + q] : 0u;
+                for (int q = 0; q < kChainGroup; ++q) ek[q] = __builtin_amdgcn_raw_buffer_load_b32(r_gk, ib + q < i1 ? (ib + q) * 4u : kOob, 0, 0);
 #pragma unroll
                 for (int q = 0; q < kChainGroup; ++q) {
                     const uint32_t i = ib + q;
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                     const bool st = i == 0 || kp + 1 != ki;
                     starts |= st ? 1u << q : 0u;
                     // the reference's k + 1 edge has no row-end check (connected_components.cc:62-70)
-                    if (!st && ki - y * W == 0) uf_union(lpar, i - 1, i);
+                    if (!st && ki - y * W == 0) uf_union(spar, i - 1, i);
                     if (y + 1 < H) {
                         lo[q] = max(i + 1, s_row[y + 1]);
                         hi[q] = max(lo[q], min(min(n, i + 1 + W), s_row[y + 2]));
@@ -398,11 +400,9 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                     bool any = false;
 #pragma unroll
                     for (int q = 0; q < kChainGroup; ++q) {
-                        km[q] = 0;
-                        if (lo[q] < hi[q]) {
-                            km[q] = gk[lo[q] + ((hi[q] - lo[q]) >> 1)];
-                            any = true;
-                        }
+                        const bool open = lo[q] < hi[q];
+                        km[q] = __builtin_amdgcn_raw_buffer_load_b32(r_gk, open ? (lo[q] + ((hi[q] - lo[q]) >> 1)) * 4u : kOob, 0, 0);
+                        any |= open;
                     }
                     if (!any) break;
 #pragma unroll
@@ -417,8 +417,9 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
 #pragma unroll
                 for (int q = 0; q < kChainGroup; ++q) {
                     const bool look = ib + q < i1 && ek[q] / W + 1 < H && lo[q] < n;
-                    kb[q] = look ? gk[lo[q]] : 0u;
-                    kbp[q] = look && lo[q] > 0 ? gk[lo[q] - 1] : 0xFFFFFFF0u;
+                    kb[q] = __builtin_amdgcn_raw_buffer_load_b32(r_gk, look ? lo[q] * 4u : kOob, 0, 0);
+                    kbp[q] = __builtin_amdgcn_raw_buffer_load_b32(r_gk, look && lo[q] > 0 ? (lo[q] - 1) * 4u : kOob, 0, 0);
+                    if (!(look && lo[q] > 0)) kbp[q] = 0xFFFFFFF0u;
                 }
 #pragma unroll
                 for (int q = 0; q < kChainGroup; ++q) {
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                     if (i >= i1 || ek[q] / W + 1 >= H || lo[q] >= n) continue;
                     const uint32_t key = ek[q] + W;
                     // one edge per pair of overlapping runs is enough (see k_union)
-                    if (kb[q] == key && (((starts >> q) & 1u) || kbp[q] + 1 != key)) uf_union(lpar, i, lo[q]);
+                    if (kb[q] == key && (((starts >> q) & 1u) || kbp[q] + 1 != key)) uf_union(spar, i, lo[q]);
                 }
                 kprev = ek[kChainGroup - 1];
             }
@@ -454,19 +455,23 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
             for (int q = 0; q < kChainPer / 2; ++q) eid[q] = 0xFFFFFFFFu;
         }
 #pragma unroll
-        for (int q = 0; q < kChainPer; ++q) exy[q] = i0 + q < i1 ? gk[i0 + q] : 0u;
+        for (int q = 0; q < kChainPer; ++q) exy[q] = __builtin_amdgcn_raw_buffer_load_b32(r_gk, i0 + q < i1 ? (i0 + q) * 4u : kOob, 0, 0);
+        const rsrc_t r_img = make_rsrc(img, (uint32_t)a.H * a.pitch);
 #pragma unroll
         for (int q = 0; q < kChainPer; ++q) {
             const uint32_t y = exy[q] / W, x = exy[q] - y * W;
             exy[q] = (y << 16) | x;
-            ew[q] = (i0 + q < i1 ? (uint32_t)*reinterpret_cast<const PixelT*>(img + (uint64_t)y * a.pitch + (uint64_t)x * sizeof(PixelT)) : 0u)
-                    | (kPack ? 0xFFFF0000u : 0u);
+            const uint32_t off = i0 + q < i1 ? y * a.pitch + x * (uint32_t)sizeof(PixelT) : kOob;
+            uint32_t v;
+            if constexpr (kPack) v = ((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r_img, off, 0, 0) & 0xFFFFu) | 0xFFFF0000u;
+            else v = __builtin_amdgcn_raw_buffer_load_b32(r_img, off, 0, 0);
+            ew[q] = v;
         }
         uint32_t mine = 0;
 #pragma unroll
         for (int q = 0; q < kChainPer; ++q) {
             if (i0 + q < i1) {
-                const uint32_t root = uf_find(lpar, i0 + q);
+                const uint32_t root = uf_find(spar, i0 + q);
                 set_id(q, root);
                 mine += root == i0 + q ? 1u : 0u;
                 gi[i0 + q] = get_i(q);
@@ -477,12 +482,12 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
             uint32_t slot = block_exclusive_scan<kChainThreads>(mine, s_wave, before);
 #pragma unroll
             for (int q = 0; q < kChainPer; ++q)
-                if (i0 + q < i1 && get_id(q) == i0 + q) lpar[i0 + q] = slot++;
+                if (i0 + q < i1 && get_id(q) == i0 + q) spar[i0 + q] = slot++;
         }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < kChainPer; ++q)
-            if (i0 + q < i1) set_id(q, lpar[get_id(q)]);
+            if (i0 + q < i1) set_id(q, spar[get_id(q)]);
         __syncthreads();   // the forest is dead from here on: its LDS becomes accumulators + record staging
         if (A.stop_after == 4) return;
 
