@@ -358,6 +358,7 @@ def main():
     achieved = alg_bytes / (ms_cand * 1e-3) / 1e9
     tm = streams[0].timings()
     traffic, traffic_src = pmc_traffic(args.workload + ("_extended" if ext else ""), B)
+    traffic_dense, traffic_dense_src = pmc_traffic(args.workload + "_dense", B)
     # ceiling measured on this box beside the nominal 8 TB/s
     peak_read, peak_mix = streams[0].bench_hbm(iters=5)
 
@@ -369,7 +370,7 @@ def main():
             hb = st.host_buffer()
             hb[:B] = frames[:B]
             bufs.append(hb)
-        n_st = max(4, min(12, args.steps // 2))   # short legs: ~0.25 s raw, ~0.1 s compressed
+        n_st = max(4, min(24, args.steps // 2))   # short legs: ~0.5 s raw, ~0.2 s compressed
         barrier()
         ts = time.perf_counter()
         inflight = []
@@ -465,7 +466,8 @@ def main():
                          "with_dense_mask": ({"ms_per_launch": round(ms_dense, 4),
                                               "achieved": round(alg_bytes / (ms_dense * 1e-3) / 1e9, 1),
                                               "frac": round(alg_bytes / (ms_dense * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                              "frac_of_measured_mix": round(alg_bytes / (ms_dense * 1e-3) / 1e9 / max(peak_mix, 1.0), 4)}
+                                              "traffic": traffic_dense, "traffic_source": traffic_dense_src,
+                                              "frac_of_measured_mix": round((traffic_dense or alg_bytes) / (ms_dense * 1e-3) / 1e9 / max(peak_mix, 1.0), 4)}
                                              if ms_dense else None)},
             "stage_ms_last_batch": {k: round(v, 4) for k, v in tm.items()},
         }
