@@ -228,7 +228,17 @@ def main():
     if world > 1 or os.environ.get("FFS_BENCH_FORCE_DIST"):  # the env var rehearses the RCCL path on one GPU
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on stdout when its first communicator comes up; stdout carries the one JSON line
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
     elif args.gpus > 1:
         print("bench.py --gpus N>1 must be launched with torch.distributed.run", file=sys.stderr)
         sys.exit(2)

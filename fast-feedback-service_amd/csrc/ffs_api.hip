@@ -1036,7 +1036,7 @@ dense_done:
     const int skip = c->knobs.chain_skip;
     // (the kernels that zero-fill the mask: streaming kernels only when asked; the older threshold kernels and the
     // extended algorithm's last pass always do)
-    ca.dense_bytes = (!one_kernel || ta.dense_mask) ? 1 : 0;
+    ca.dense_bytes = ((one_kernel || (p.algorithm == FFS_ALGO_DISPERSION_EXTENDED && ext_stream_first(s, ta))) ? ta.dense_mask : 1) ? 1 : 0;
     s->dense_valid = ca.dense_bytes != 0;
     // FFS_CCL = 2 (default): the whole sparse stage in one launch, one workgroup per frame (kernels_chain.hpp)
     s->chain_mode = root_mode && ccl_variant >= 2 && s->direct_recs && s->h_counts_dev && c->n_tiles <= kChainMaxTiles && L.H <= kChainMaxRows && !skip;

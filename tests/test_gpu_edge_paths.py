@@ -56,7 +56,7 @@ def test_capacity_overflow_is_absorbed(ffs):
     assert_frame_matches_oracle(fr, quiet, mask)
 
 
-@pytest.mark.parametrize("H,W", [(1, 1), (3, 5), (7, 9), (6, 700), (2000, 8), (40, 4097), (16, 10240)])
+@pytest.mark.parametrize("H,W", [(1, 1), (3, 5), (7, 9), (6, 700), (2000, 8), (40, 4097), (16, 10240), (5000, 48)])
 def test_extreme_shapes(ffs, H, W):
     rng = np.random.default_rng(H * 31 + W)
     img = rng.poisson(2.0, (H, W)).astype(np.uint16)
@@ -215,3 +215,38 @@ def test_super_row_groups(ffs, dtype, group, monkeypatch):
         assert_frame_matches_oracle(fr, img, mask)
     for fr, img in zip(st.process(np.stack(frames[:5])), frames[:5]):      # a partial last group
         assert_frame_matches_oracle(fr, img, mask)
+
+
+@pytest.mark.parametrize("ccl", ["0", "1", "2"])
+@pytest.mark.parametrize("sched", ["0", "3"])
+def test_sparse_stage_variants_agree(ffs, ccl, sched, monkeypatch):
+    """FFS_CCL: 2 = one launch per batch, a workgroup per frame (k_frame_chain: forest in LDS up to 20480 strong
+    pixels, global arrays beyond), 1 = four grid-wide kernels, 0 = round 1's numbered components; FFS_SCHED: shared
+    dense / sparse / upload streams per context (3) or one stream per ffs_stream (0).  Every combination must give
+    the oracle's result: a sparse frame, a frame beyond the LDS forest, an empty frame and a frame with a row-wrap pair."""
+    monkeypatch.setenv("FFS_CCL", ccl)
+    monkeypatch.setenv("FFS_SCHED", sched)
+    rng = np.random.default_rng(21)
+    W, H = 640, 480
+    sparse, mask = make_frame(W=W, H=H, seed=31, n_spots=40)
+    dense = rng.poisson(1.0, (H, W)).astype(np.uint16)
+    dense[rng.random((H, W)) < 0.09] += 60                      # ~27 k strong pixels: beyond kChainLdsEntries
+    empty = np.zeros((H, W), np.uint16)
+    wrap = rng.poisson(1.0, (H, W)).astype(np.uint16)
+    wrap[100, W - 1] = 500
+    wrap[101, 0] = 400                                             # (W-1, y) -- (0, y+1): one component for the reference
+    wrap[200:203, 300:303] = 300
+    frames = np.stack([sparse, dense, empty, wrap])
+    ones = np.ones((H, W), np.uint8)
+    ctx = ffs.Context(W, H, np.uint16, max_batch=4, max_strong_per_frame=60000)
+    ctx.set_params(want_strong_mask=1, want_strong_list=1, min_spot_size=1, max_peak_centroid_separation=3.0)
+    st = ctx.stream()
+    for rep in range(2):                                           # (second pass: every buffer has been used once)
+        res = st.process(frames, first_frame_id=10 * rep)
+        assert res[1].num_strong_pixels > 20480 and res[2].num_strong_pixels == 0
+        for fr, img in zip(res, frames):
+            assert_frame_matches_oracle(fr, img, ones, min_spot_size=1, max_sep=3.0)
+    # and without the dense mask asked for (the default of the hot path)
+    ctx.set_params(want_strong_mask=0, want_strong_list=1, min_spot_size=1, max_peak_centroid_separation=3.0)
+    for fr, img in zip(st.process(frames), frames):
+        assert_frame_matches_oracle(fr, img, ones, min_spot_size=1, max_sep=3.0)
