@@ -53,7 +53,8 @@ typedef struct {
     float max_peak_centroid_separation; /* :330-336 (default 2.0) */
     int32_t want_reflections; /* compute find_2d_components output per frame (spotfinder.cc:919-933) */
     int32_t want_strong_list; /* return the sparse strong-pixel list (k, intensity) per frame */
-    int32_t want_strong_mask; /* return the dense W*H byte mask per frame (reference D2H, :887-897) */
+    int32_t want_strong_mask; /* produce and return the dense W*H byte mask per frame (reference D2H, :887-897); 0 (default): the
+                               * strong mask stays a bit plane on the device and only lists / boxes / reflections come back */
     int32_t algorithm;        /* FFS_ALGO_DISPERSION (default) or FFS_ALGO_DISPERSION_EXTENDED:
                                  `--algorithm`, spotfinder.cc:338-342, 572-590 */
     int32_t extended_flavour; /* extended only.  0 = baseline.cpp:730-761 rules (default); 1 = where the
@@ -221,7 +222,8 @@ int ffs_bench_threshold(ffs_stream *s, const void *device_pixels, size_t pitch_b
  * (The reference prints GBps per image, spotfinder/spotfinder.cc:1056-1076, against no ceiling.) */
 int ffs_bench_hbm(ffs_stream *s, uint32_t iters, float *read_gbps, float *mix_gbps);
 /* Device pointers of the last batch's dense planes (strong byte mask rows are
- * mask_pitch apart) -- for parity tests that want the raw kernel output. */
+ * mask_pitch apart) -- for parity tests that want the raw kernel output.  The byte masks hold the last batch's
+ * result only if that batch ran with want_strong_mask = 1. */
 int ffs_stream_debug_planes(ffs_stream *s, const uint8_t **device_strong_bytes,
                             size_t *mask_pitch, size_t *mask_frame_stride);
 /* Copies one frame's bit plane of the last completed batch to host memory, unpacked to W*H
