@@ -56,7 +56,7 @@ struct Knobs {
     int emit_variant = 1, ccl_variant = 2, link_runs = 1, ccl_grid = 32, ccl_cus = 0, direct_recs = 1;
     int sched = 3;             // FFS_SCHED: 1 = sparse chain on a high-priority stream of its own; 2 = also every dense kernel of the context on ONE stream
     int fix_aside = 1;         // FFS_FIX_ASIDE: k_bright_fix in the sparse stream (SCHED >= 1)
-    int decode_dense = 0;      // FFS_DECODE_DENSE: the decode kernel runs in the dense kernels' stream (0: in the upload stream)
+    int decode_dense = 1;      // FFS_DECODE_DENSE: the decode kernel runs in the dense kernels' stream (0: in the upload stream)
     int dense_mask = 0;        // FFS_DENSE_MASK=1: always produce the dense byte mask
     int chain_skip = 0;        // FFS_CHAIN_SKIP (timing experiments only; results are then meaningless): 1 = no sparse chain, 2 = stop after emit, 4 = after union, 8 = after reduce
     int bright_cap = 1 << 20;  // FFS_BRIGHT_CAP: entries of the bright-window list actually used (tests shrink it)
@@ -80,7 +80,7 @@ struct Knobs {
         chain_skip = env_int("FFS_CHAIN_SKIP", 0);
         sched = env_int("FFS_SCHED", 3);
         dense_mask = env_int("FFS_DENSE_MASK", 0);
-        decode_dense = env_int("FFS_DECODE_DENSE", 0);
+        decode_dense = env_int("FFS_DECODE_DENSE", 1);
         fix_aside = env_int("FFS_FIX_ASIDE", 1);
         bright_cap = std::max(0, std::min(1 << 20, env_int("FFS_BRIGHT_CAP", 1 << 20)));
     }
