@@ -17,10 +17,10 @@
 // Phases (separated by __syncthreads(), which also orders the block's global writes):
 //   A  exclusive scan of the frame's per-tile counts (the streaming kernel's atomics) -> tile offsets in LDS; the
 //      counts are zeroed for the next batch
-//   E  compaction: each wave streams a contiguous range of tiles (16-byte plane loads, the next batch of loads in
-//      flight while this one is looked at, tiles without strong pixels skipped), stages the non-zero words of
-//      several tiles and places their pixels 64 words at a time; nothing here waits for a load it just issued
-//      (the pixel VALUES are fetched in phase P)
+//   E  compaction: each wave streams a contiguous range of tiles (buffer loads, twelve rounds of 256 words in flight,
+//      tiles without strong pixels skipped), stages the non-zero words of several tiles (ballot + mbcnt) and
+//      places their pixels 64 words at a time; nothing here waits for a load it just issued (the pixel VALUES
+//      are fetched in phase P)
 //   S  per-row counts -> per-row list offsets (block scan, in LDS)
 //   U  union-find: vertical edges + the reference's row-wrap edge (the body of k_union<false>)
 //   then, for frames held in LDS:
@@ -176,7 +176,8 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
 
     // ---- E: compaction --------------------------------------------------------------------------------
     // Nothing in this phase waits for a load it has just issued: the plane words come two batches ahead, and the
-    // pixel VALUES are not fetched here at all (phase P loads them, twenty independent loads per thread).
+    // pixel VALUES are not fetched here at all (phase P loads them, twenty independent loads per thread).  What bounds
+    // it is one CU's share of the memory system: the frame's 2.3 MB plane at ~20 GB/s.
     if (total != 0) {
         const int tpw = (n_tiles + kChainWaves - 1) / kChainWaves;
         const int tb = min(wave * tpw, n_tiles), te = min(tb + tpw, n_tiles);
@@ -279,8 +280,6 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
             // (buffer loads: out of range -- beyond the wave's words, or switched off -- reads 0, so the loads are not
             // wrapped in branches and the waits below can count them)
             const rsrc_t r_words = make_rsrc(words, (uint32_t)nw * 4u);
-            // (buffer loads: out of range -- beyond the wave's words, or switched off -- reads 0, so the loads are not
-            // wrapped in branches and the waits below can count them)
             auto load_batch = [&](int b, uint32_t (&buf)[kChainQuads][4]) {
 #pragma unroll
                 for (int q = 0; q < kChainQuads; ++q) {
