@@ -105,6 +105,7 @@ struct ffs_ctx {
     hipStream_t sparse_st[2] = {nullptr, nullptr};  // FFS_SCHED=3: the sparse chains of the context's streams, alternating
     int n_streams_made = 0;
     std::mutex stream_mu;            // guards the lazy creation of the shared streams
+    bool chain_ok = false;           // k_frame_chain may use its 140 KB of dynamic LDS on this device
     ThreadError err;  // the calling thread's most recent error on any context
 };
 
@@ -633,6 +634,15 @@ static int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uin
         }
     }
     if (!s->st_up) s->st_up = s->st;
+    {   // more than 64 KB of dynamic LDS has to be asked for, per device
+        std::lock_guard<std::mutex> lock(c->stream_mu);
+        if (!c->chain_ok) {
+            const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
+            const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
+            c->chain_ok = e1 == hipSuccess && e2 == hipSuccess;   // (else: the four grid-wide kernels)
+            (void)hipGetLastError();
+        }
+    }
     for (auto& e : s->ev) STREAM_TRY(hipEventCreate(&e));
     STREAM_TRY(dmalloc(&s->d_img, B * L.frame_stride));
     STREAM_TRY(dmalloc(&s->d_bits, B * L.plane_frame_stride));
@@ -1039,7 +1049,7 @@ dense_done:
     ca.dense_bytes = ((one_kernel || (p.algorithm == FFS_ALGO_DISPERSION_EXTENDED && ext_stream_first(s, ta))) ? ta.dense_mask : 1) ? 1 : 0;
     s->dense_valid = ca.dense_bytes != 0;
     // FFS_CCL = 2 (default): the whole sparse stage in one launch, one workgroup per frame (kernels_chain.hpp)
-    s->chain_mode = root_mode && ccl_variant >= 2 && s->direct_recs && s->h_counts_dev && c->n_tiles <= kChainMaxTiles && L.H <= kChainMaxRows && !skip;
+    s->chain_mode = root_mode && ccl_variant >= 2 && c->chain_ok && s->direct_recs && s->h_counts_dev && c->n_tiles <= kChainMaxTiles && L.H <= kChainMaxRows && !skip;
     if (s->chain_mode) {
         ChainArgs A{};
         A.c = ca;
@@ -1069,11 +1079,6 @@ dense_done:
         A.max_batch = (uint32_t)s->max_batch;
         A.rec_stride = s->max_comp;
         A.stop_after = Knobs::env_int("FFS_CHAIN_STOP", 0);
-        static std::once_flag chain_attr;   // (more than 64 KB of dynamic LDS has to be asked for)
-        std::call_once(chain_attr, [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
-        });
         if (c->pixel_bytes == 2) hipLaunchKernelGGL(k_frame_chain<uint16_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, A);
         else hipLaunchKernelGGL(k_frame_chain<uint32_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, A);
         HIP_TRY(c, hipGetLastError());

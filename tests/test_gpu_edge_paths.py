@@ -250,3 +250,44 @@ def test_sparse_stage_variants_agree(ffs, ccl, sched, monkeypatch):
     ctx.set_params(want_strong_mask=0, want_strong_list=1, min_spot_size=1, max_peak_centroid_separation=3.0)
     for fr, img in zip(st.process(frames), frames):
         assert_frame_matches_oracle(fr, img, ones, min_spot_size=1, max_sep=3.0)
+
+
+def test_streams_of_one_context_from_several_threads(ffs):
+    """The reference runs one worker thread per CUDA stream (spotfinder.cc:725-752).  Here the streams of a context
+    share its HIP streams (one for the dense kernels, two for the sparse launches, one for uploads): four threads,
+    each with its own ffs_stream, submit raw, device-resident-style and compressed batches at the same time and
+    every result must be the oracle's."""
+    import threading
+    from ffs_amd import bslz4
+    W, H, B = 320, 240, 3
+    frames, mask = [], None
+    for i in range(12):
+        img, mask = make_frame(W=W, H=H, seed=70 + i, n_spots=20, masked=True)
+        frames.append(img)
+    ctx = ffs.Context(W, H, np.uint16, max_batch=B)
+    ctx.set_mask(mask)
+    ctx.set_params(want_strong_list=1)
+    errors = []
+
+    def worker(t):
+        try:
+            st = ctx.stream()
+            for rep in range(6):
+                mine = [frames[(t * 3 + rep + j) % len(frames)] for j in range(B)]
+                if (rep + t) % 2:
+                    res = st.process_compressed([bslz4.compress(f) for f in mine], first_frame_id=100 * t + rep)
+                else:
+                    res = st.process(np.stack(mine), first_frame_id=100 * t + rep)
+                assert [r.frame_id for r in res] == [100 * t + rep + j for j in range(B)]
+                for fr, img in zip(res, mine):
+                    assert_frame_matches_oracle(fr, img, mask)
+            st.close()
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
