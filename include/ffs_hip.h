@@ -144,7 +144,12 @@ int ffs_ctx_get_mask(ffs_ctx *ctx, uint8_t *host_mask);
 int ffs_ctx_set_params(ffs_ctx *ctx, const ffs_params *p);
 
 /* ---- streams: one in-flight batch each (replaces one worker thread's CudaStream +
- *      pinned/device buffers, spotfinder.cc:729-742) -------------------------------------------- */
+ *      pinned/device buffers, spotfinder.cc:729-742) --------------------------------------------
+ * An ffs_stream owns its buffers and its batch; the HIP streams underneath belong to the context (one for
+ * the dense kernels of all its ffs_streams, in submission order, two for the sparse launches, one for uploads:
+ * DESIGN.md section 3.4).  Distinct ffs_streams may be driven from distinct threads at the same time; keep
+ * two or more batches in flight (two or more ffs_streams) for throughput -- a batch's sparse stage runs beside
+ * the next batch's threshold kernel. */
 int ffs_stream_create(ffs_ctx *ctx, ffs_stream **out);
 void ffs_stream_destroy(ffs_stream *s);
 
