@@ -155,7 +155,7 @@ def bench_sweep(args, dev, local_rank):
         host[:, :, :W] = synth.frames(p, range(z0, z0 + B), threads=min(16, os.cpu_count() or 1))
         d_frames[z0 * fstride:(z0 + B) * fstride].copy_(torch.from_numpy(host.view(np.uint8).reshape(-1)))
     del host
-    streams = [ctx.stream() for _ in range(2)]
+    streams = [ctx.stream() for _ in range(4)]   # the whole sweep in flight: a batch's sparse stage runs beside the next batches' threshold kernels
     n_refl, finish_ms = 0, []
 
     def sweep():

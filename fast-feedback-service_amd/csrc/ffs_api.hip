@@ -105,6 +105,7 @@ struct ffs_ctx {
     hipStream_t sparse_st[2] = {nullptr, nullptr};  // FFS_SCHED=3: the sparse chains of the context's streams, alternating
     int n_streams_made = 0;
     std::mutex stream_mu;            // guards the lazy creation of the shared streams
+    std::vector<struct ffs_stack3d*> stack_pool;   // destroyed 3D stacks kept with their buffers for the next sweep (stream_mu)
     bool chain_ok = false;           // k_frame_chain may use its 140 KB of dynamic LDS on this device
     ThreadError err;  // the calling thread's most recent error on any context
 };
@@ -270,6 +271,14 @@ struct ffs_stack3d {
     uint64_t arrived = 0;
     PoolBuf<uint32_t> a_k, a_i;
     PoolBuf<StackSlice> d_table, h_table;
+    // ffs_stack3d_add_batch does not wait for its append: each call takes the next of kSlots slice tables and leaves an
+    // event behind; a slot is reused only after its event, and finish / a growing buffer / destroy wait for all of them
+    static constexpr int kSlots = 8;
+    PoolBuf<StackSlice> d_ring, h_ring;   // kSlots tables of ring_stride entries
+    size_t ring_stride = 0;
+    hipEvent_t slot_ev[kSlots] = {};
+    bool slot_used[kSlots] = {};
+    uint64_t n_adds = 0;
     // the stack in (z, k) order and the scratch of its labelling (sized in finish, kept for the next one)
     PoolBuf<uint32_t> d_k, d_i, d_z, d_parent, d_comp, d_begin, d_chunk_roots, d_small, d_sx, d_sy, d_sc;
     PoolBuf<CompAcc> d_acc;
@@ -401,9 +410,13 @@ extern "C" int ffs_ctx_create(int device, uint32_t width, uint32_t height, int p
     return FFS_OK;
 }
 
+static void stack3d_free(struct ffs_stack3d* st);
+
 extern "C" void ffs_ctx_destroy(ffs_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    for (auto* st : c->stack_pool) stack3d_free(st);
+    c->stack_pool.clear();
     if (c->d_maskbits) (void)hipFree(c->d_maskbits);
     if (c->d_ginfo) (void)hipFree(c->d_ginfo);
     if (c->d_mmap) (void)hipFree(c->d_mmap);
@@ -1958,6 +1971,17 @@ extern "C" int ffs_selftest_sqrt(ffs_ctx* c, uint64_t begin, uint64_t end, uint6
 // ---- 3D stack ------------------------------------------------------------------------------------------
 
 static int stack3d_create_impl(ffs_ctx* c, uint64_t max_total, ffs_stack3d** out) {
+    {   // a stack of this context that was destroyed: its stream and its (grown) buffers are ready -- a sweep's worth of
+        // hipMalloc / hipFree is 1.5 ms, more than its 100 frames take on the GPU
+        std::lock_guard<std::mutex> lock(c->stream_mu);
+        if (!c->stack_pool.empty()) {
+            ffs_stack3d* st = c->stack_pool.back();
+            c->stack_pool.pop_back();
+            st->max_total = max_total ? max_total : (1ull << 30);
+            *out = st;
+            return FFS_OK;
+        }
+    }
     ffs_stack3d* st = new (std::nothrow) ffs_stack3d();
     if (!st) return FFS_ERR_NOMEM;
     st->ctx = c;
@@ -1982,8 +2006,39 @@ extern "C" int ffs_stack3d_create(ffs_ctx* c, uint64_t max_total, ffs_stack3d** 
 
 extern "C" void ffs_stack3d_destroy(ffs_stack3d* st) {
     if (!st) return;
+    ffs_ctx* c = st->ctx;
+    (void)hipSetDevice(c->device);
+    {
+        std::lock_guard<std::mutex> lock(c->stream_mu);
+        if (c->stack_pool.size() < 2) {   // keep it, emptied, for the next sweep
+            for (int k = 0; k < ffs_stack3d::kSlots; ++k)
+                if (st->slot_used[k]) {
+                    (void)hipEventSynchronize(st->slot_ev[k]);
+                    st->slot_used[k] = false;
+                }
+            if (st->st) (void)hipStreamSynchronize(st->st);
+            st->slices.clear();
+            st->arrived = 0;
+            st->n_adds = 0;
+            st->out.clear();
+            st->sig_x.clear(); st->sig_y.clear(); st->sig_z.clear(); st->sig_i.clear(); st->sig_refl.clear();
+            st->last_finish_ms = 0;
+            c->stack_pool.push_back(st);
+            return;
+        }
+    }
+    stack3d_free(st);
+}
+
+static void stack3d_free(ffs_stack3d* st) {
     (void)hipSetDevice(st->ctx->device);
+    for (int k = 0; k < ffs_stack3d::kSlots; ++k)
+        if (st->slot_ev[k]) {
+            if (st->slot_used[k]) (void)hipEventSynchronize(st->slot_ev[k]);
+            (void)hipEventDestroy(st->slot_ev[k]);
+        }
     if (st->st) (void)hipStreamSynchronize(st->st);
+    st->d_ring.release(); st->h_ring.release();
     st->a_k.release(); st->a_i.release(); st->d_table.release(); st->h_table.release();
     st->d_k.release(); st->d_i.release(); st->d_z.release(); st->d_parent.release(); st->d_comp.release();
     st->d_begin.release(); st->d_chunk_roots.release(); st->d_small.release();
@@ -2001,6 +2056,15 @@ extern "C" void ffs_stack3d_destroy(ffs_stack3d* st) {
         }                                                                       \
     } while (0)
 
+// the appends still in flight (ffs_stack3d_add_batch leaves them running) are done when this returns
+static void stack3d_join_appends(ffs_stack3d* st) {
+    for (int k = 0; k < ffs_stack3d::kSlots; ++k)
+        if (st->slot_used[k]) {
+            (void)hipEventSynchronize(st->slot_ev[k]);
+            st->slot_used[k] = false;
+        }
+}
+
 // room for `more` entries behind the ones that have arrived (the lists already there are kept)
 static int stack3d_reserve(ffs_stack3d* st, uint64_t more) {
     ffs_ctx* c = st->ctx;
@@ -2008,6 +2072,7 @@ static int stack3d_reserve(ffs_stack3d* st, uint64_t more) {
         c->err = "ffs_stack3d: too many strong pixels in the stack";
         return FFS_ERR_OVERFLOW;
     }
+    if (st->arrived + more > st->a_k.cap || st->arrived + more > st->a_i.cap) stack3d_join_appends(st);  // (the buffers move)
     STK_TRY(c, st->a_k.ensure(st->arrived + more, true, st->st));
     STK_TRY(c, st->a_i.ensure(st->arrived + more, true, st->st));
     return FFS_OK;
@@ -2228,10 +2293,30 @@ static int stack3d_add_batch_impl(ffs_stack3d* st, ffs_stream* s) {
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = stack3d_reserve(st, more);
     if (rc != FFS_OK) return rc;
-    STK_TRY(c, st->h_table.ensure(nf));
-    STK_TRY(c, st->d_table.ensure(nf));
+    // The append runs in the stream's own sparse stream: behind the launch that wrote the lists, ahead of the one that
+    // will overwrite them -- nothing to wait for here.  Its slice table sits in one of kSlots slots.
+    const int slot = (int)(st->n_adds++ % ffs_stack3d::kSlots);
+    if (st->ring_stride < c->max_batch || !st->d_ring.p) {
+        stack3d_join_appends(st);
+        st->ring_stride = std::max<size_t>(c->max_batch, nf);
+        st->h_ring.pinned_host = true;
+        STK_TRY(c, st->h_ring.ensure(st->ring_stride * ffs_stack3d::kSlots));
+        STK_TRY(c, st->d_ring.ensure(st->ring_stride * ffs_stack3d::kSlots));
+    }
+    if (nf > st->ring_stride) {
+        c->err = "ffs_stack3d_add_batch: batch larger than the context's max_batch";
+        return FFS_ERR_INVALID;
+    }
+    if (!st->slot_ev[slot]) STK_TRY(c, hipEventCreateWithFlags(&st->slot_ev[slot], hipEventDisableTiming));
+    if (st->slot_used[slot]) {
+        STK_TRY(c, hipEventSynchronize(st->slot_ev[slot]));
+        st->slot_used[slot] = false;
+    }
+    StackSlice* h_tab = st->h_ring.p + (size_t)slot * st->ring_stride;
+    StackSlice* d_tab = st->d_ring.p + (size_t)slot * st->ring_stride;
     uint64_t at = st->arrived;
     uint32_t biggest = 0;
+    bool host_lists = false;
     for (uint32_t f = 0; f < nf; ++f) {
         const ffs_frame_result& r = s->results[f];
         const OverflowFrame* o = nullptr;
@@ -2239,28 +2324,31 @@ static int stack3d_add_batch_impl(ffs_stack3d* st, ffs_stream* s) {
             if (q.frame == f) o = &q;
         const uint32_t n = r.num_strong_pixels;
         // a frame that did not fit the stream's lists was re-run on its one-frame stream: its list is on the host
-        st->h_table.p[f] = StackSlice{0u, (uint32_t)at, o ? 0u : n, 0u};
+        h_tab[f] = StackSlice{0u, (uint32_t)at, o ? 0u : n, 0u};
         if (o && n) {
             if (o->k.size() != n) {  // (lists are only kept with want_strong_list)
                 c->err = "ffs_stack3d_add_batch: a frame overflowed the stream's lists; set want_strong_list (or a larger "
                          "max_strong_per_frame) for rotation sweeps";
                 return FFS_ERR_OVERFLOW;
             }
-            STK_TRY(c, hipMemcpyAsync(st->a_k.p + at, o->k.data(), (size_t)n * 4, hipMemcpyHostToDevice, st->st));
-            STK_TRY(c, hipMemcpyAsync(st->a_i.p + at, o->inten.data(), (size_t)n * 4, hipMemcpyHostToDevice, st->st));
+            STK_TRY(c, hipMemcpyAsync(st->a_k.p + at, o->k.data(), (size_t)n * 4, hipMemcpyHostToDevice, s->st2));
+            STK_TRY(c, hipMemcpyAsync(st->a_i.p + at, o->inten.data(), (size_t)n * 4, hipMemcpyHostToDevice, s->st2));
+            host_lists = true;
         }
         if (!o) biggest = std::max(biggest, n);
         st->slices[r.frame_id] = ffs_stack3d::Slice{(uint32_t)at, n};
         at += n;
     }
     if (biggest) {
-        STK_TRY(c, hipMemcpyAsync(st->d_table.p, st->h_table.p, (size_t)nf * sizeof(StackSlice), hipMemcpyHostToDevice, st->st));
+        STK_TRY(c, hipMemcpyAsync(d_tab, h_tab, (size_t)nf * sizeof(StackSlice), hipMemcpyHostToDevice, s->st2));
         (void)hipGetLastError();
-        hipLaunchKernelGGL(k_stack_append, dim3(std::min<uint32_t>(64, (biggest + 255) / 256), nf), dim3(256), 0, st->st,
-                           s->d_list_k, s->d_list_i, (uint64_t)s->cap, st->d_table.p, st->a_k.p, st->a_i.p);
+        hipLaunchKernelGGL(k_stack_append, dim3(std::min<uint32_t>(64, (biggest + 255) / 256), nf), dim3(256), 0, s->st2,
+                           s->d_list_k, s->d_list_i, (uint64_t)s->cap, d_tab, st->a_k.p, st->a_i.p);
         STK_TRY(c, hipGetLastError());
     }
-    STK_TRY(c, hipStreamSynchronize(st->st));  // the stream's lists may be overwritten by its next batch
+    STK_TRY(c, hipEventRecord(st->slot_ev[slot], s->st2));
+    st->slot_used[slot] = true;
+    if (host_lists) STK_TRY(c, hipStreamSynchronize(s->st2));  // (the overflow frames' lists live in the stream's result vectors)
     st->arrived = at;
     return FFS_OK;
 }
@@ -2287,6 +2375,8 @@ static int stack3d_finish_impl(ffs_stack3d* st, const ffs_reflection** reflectio
     ffs_ctx* c = st->ctx;
     std::lock_guard<std::mutex> lock(st->mu);
     HIP_TRY(c, hipSetDevice(c->device));
+    for (int k = 0; k < ffs_stack3d::kSlots; ++k)   // the appends of the last batches may still be running (in other streams)
+        if (st->slot_used[k]) HIP_TRY(c, hipStreamWaitEvent(st->st, st->slot_ev[k], 0));
     // z = rank of the frame id among the slices held (std::map order, spotfinder.cc:1105-1108)
     const int nz = (int)st->slices.size();
     uint64_t total = 0;
