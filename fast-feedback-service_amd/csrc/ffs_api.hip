@@ -194,6 +194,8 @@ struct ffs_stream {
     uint32_t* h_counts = nullptr;  // [max_batch] num_strong | [max_batch] n_comp | [max_batch*8] summary | [1] overflow
     ReflOut* h_recs = nullptr;
     uint32_t* h_counts_dev = nullptr;  // device-side address of h_counts (k_frame_chain writes the counters itself)
+    bool ev3_is_ev4 = false;       // one event behind the sparse launch (k_frame_chain leaves nothing to copy)
+    bool dev_input = false;        // this batch's frames were on the device already (ffs_submit_device): no upload, no ev[0]
     bool dense_valid = false;      // the byte masks of the last batch were produced
     bool chain_mode = false;       // this batch went through k_frame_chain: records at frame * max_comp, flags per frame
     ReflOut* h_recs_dev = nullptr;  // device-side address of h_recs when the records are written straight to the host
@@ -978,7 +980,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     s->cur_fstride = fstride;
 
     (void)hipGetLastError();  // drop any stale error state: the check below is for OUR launches
-    if (s->st_up != s->st) HIP_TRY(c, hipStreamWaitEvent(s->st, s->ev[1], 0));   // the frames are in place (upload / decode stream)
+    if (s->st_up != s->st && !s->dev_input) HIP_TRY(c, hipStreamWaitEvent(s->st, s->ev[1], 0));   // the frames are in place (upload / decode stream)
     if (p.algorithm == FFS_ALGO_DISPERSION_EXTENDED) {
         const int rc = ensure_extended_buffers(s);
         if (rc != FFS_OK) return rc;
@@ -1095,8 +1097,8 @@ dense_done:
         if (c->pixel_bytes == 2) hipLaunchKernelGGL(k_frame_chain<uint16_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, A);
         else hipLaunchKernelGGL(k_frame_chain<uint32_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, A);
         HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipEventRecord(s->ev[3], s->st2));
         HIP_TRY(c, hipEventRecord(s->ev[4], s->st2));
+        s->ev3_is_ev4 = true;
         s->spec_recs_copied = (uint64_t)s->max_batch * s->max_comp;
         s->bits_dirty = !one_kernel;
         s->counts_dirty = false;
@@ -1165,6 +1167,7 @@ dense_done:
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(s->ev[3], s->st2));
+    s->ev3_is_ev4 = false;
 
     // small counts first; ffs_wait() sizes the record copy from them
     const size_t B = s->max_batch;
@@ -1195,8 +1198,9 @@ extern "C" int ffs_submit_device(ffs_stream* s, const void* device_pixels, size_
     int rc = check_layout(s, pitch, fstride, n_frames);
     if (rc != FFS_OK) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipEventRecord(s->ev[0], s->st));
+    // (one marker, not two and a wait: every packet in the dense stream is ~5 us between two streaming kernels)
     HIP_TRY(c, hipEventRecord(s->ev[1], s->st));
+    s->dev_input = true;
     s->first_id = first_frame_id;
     return enqueue_batch(s, device_pixels, pitch, fstride, n_frames);
 }
@@ -1214,6 +1218,7 @@ extern "C" int ffs_submit(ffs_stream* s, const void* host_pixels, uint32_t n_fra
     }
     const Layout& L = c->L;
     HIP_TRY(c, hipSetDevice(c->device));
+    s->dev_input = false;
     HIP_TRY(c, hipEventRecord(s->ev[0], s->st_up));
     // one 2D copy: the default device layout keeps frames contiguous (frame_stride = H * pitch)
     const size_t row = (size_t)L.W * c->pixel_bytes;
@@ -1399,6 +1404,7 @@ static int ffs_submit_compressed_impl(ffs_stream* s, const void* const* chunks, 
         return FFS_ERR_INVALID;
     }
     HIP_TRY(c, hipSetDevice(c->device));
+    s->dev_input = false;
     HIP_TRY(c, hipEventRecord(s->ev[0], s->st_up));
     std::vector<size_t> base;
     int rc = stage_chunks(s, chunks, chunk_bytes, n_frames, base);
@@ -1572,8 +1578,8 @@ static int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32
                 ffs_stream* b = s->big;
                 const uint8_t* img = static_cast<const uint8_t*>(s->cur_img) + (size_t)f * s->cur_fstride;
                 b->first_id = s->first_id + f;
-                HIP_TRY(c, hipEventRecord(b->ev[0], b->st));
                 HIP_TRY(c, hipEventRecord(b->ev[1], b->st));
+                b->dev_input = true;
                 int rc = enqueue_batch(b, img, s->cur_pitch, s->cur_fstride, 1, &s->batch_params);
                 if (rc != FFS_OK) return rc;
                 HIP_TRY(c, hipEventSynchronize(b->ev[4]));
@@ -1653,11 +1659,12 @@ static int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32
         HIP_TRY(c, hipEventSynchronize(s->ev[5]));
         last = s->ev[5];
     }
-    (void)hipEventElapsedTime(&s->timings[0], s->ev[0], s->ev[1]);
+    s->timings[0] = 0.0f;
+    if (!s->dev_input) (void)hipEventElapsedTime(&s->timings[0], s->ev[0], s->ev[1]);
     (void)hipEventElapsedTime(&s->timings[1], s->ev[1], s->ev[2]);
-    (void)hipEventElapsedTime(&s->timings[2], s->ev[2], s->ev[3]);
-    (void)hipEventElapsedTime(&s->timings[3], s->ev[3], last);
-    (void)hipEventElapsedTime(&s->timings[4], s->ev[0], last);
+    (void)hipEventElapsedTime(&s->timings[2], s->ev[2], s->ev3_is_ev4 ? s->ev[4] : s->ev[3]);
+    (void)hipEventElapsedTime(&s->timings[3], s->ev3_is_ev4 ? s->ev[4] : s->ev[3], last);
+    (void)hipEventElapsedTime(&s->timings[4], s->dev_input ? s->ev[1] : s->ev[0], last);
 
     // assemble: boxes = components surviving the min-size filter (connected_components.cc:122-135),
     // reflections = components surviving filter_reflections (:207-236); both keep label order.
