@@ -55,6 +55,7 @@ struct Knobs {
     long long target_waves = 16384;
     int emit_variant = 1, ccl_variant = 2, link_runs = 1, ccl_grid = 32, ccl_cus = 0, direct_recs = 1;
     int sched = 3;             // FFS_SCHED: 1 = sparse chain on a high-priority stream of its own; 2 = also every dense kernel of the context on ONE stream
+    int use_occ = 1;           // FFS_OCC: k_frame_chain reads only the plane segments the occupancy bitmap names
     int fix_aside = 1;         // FFS_FIX_ASIDE: k_bright_fix in the sparse stream (SCHED >= 1)
     int decode_dense = 1;      // FFS_DECODE_DENSE: the decode kernel runs in the dense kernels' stream (0: in the upload stream)
     int dense_mask = 0;        // FFS_DENSE_MASK=1: always produce the dense byte mask
@@ -82,6 +83,7 @@ struct Knobs {
         dense_mask = env_int("FFS_DENSE_MASK", 0);
         decode_dense = env_int("FFS_DECODE_DENSE", 1);
         fix_aside = env_int("FFS_FIX_ASIDE", 1);
+        use_occ = env_int("FFS_OCC", 1);
         bright_cap = std::max(0, std::min(1 << 20, env_int("FFS_BRIGHT_CAP", 1 << 20)));
     }
 };
@@ -193,6 +195,7 @@ struct ffs_stream {
     size_t h_img_bytes = 0;
     uint32_t* h_counts = nullptr;  // [max_batch] num_strong | [max_batch] n_comp | [max_batch*8] summary | [1] overflow
     ReflOut* h_recs = nullptr;
+    uint32_t* d_occ = nullptr;     // [max_batch][occ_frame_words] occupancy of the strong plane (one bit per 16-byte segment)
     uint32_t* h_counts_dev = nullptr;  // device-side address of h_counts (k_frame_chain writes the counters itself)
     bool ev3_is_ev4 = false;       // one event behind the sparse launch (k_frame_chain leaves nothing to copy)
     bool dev_input = false;        // this batch's frames were on the device already (ffs_submit_device): no upload, no ev[0]
@@ -227,6 +230,8 @@ struct OverflowFrame {
     std::vector<ffs_reflection> refls;
     std::vector<uint32_t> k, inten;
 };
+
+static uint32_t occ_frame_words(const Layout& L) { return (uint32_t)(((uint64_t)L.H * (L.mpitch / 16) + 31) / 32 + 2); }  // (+2: the chain reads a word ahead)
 
 static size_t tile_counts_bytes(const ffs_stream* s) { return (((size_t)s->max_batch * s->ctx->n_tiles + 1) * 4 + 255) / 256 * 256; }
 
@@ -554,7 +559,7 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     if (s->st2 && s->st2 != s->st) { (void)hipStreamSynchronize(s->st2); if (!s->st2_shared) (void)hipStreamDestroy(s->st2); }
     // (d_n_comp, d_summary and d_overflow live inside the d_num_strong allocation)
     if (s->h_pack_tab) (void)hipHostFree(s->h_pack_tab);
-    void* dev[] = {s->d_pack_k, s->d_pack_i, s->d_pack_tab, s->d_acc2, s->d_chunk_roots, s->d_bright, s->d_comp, s->d_tab, s->d_dplane, s->d_eplane, s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_num_strong,
+    void* dev[] = {s->d_occ, s->d_pack_k, s->d_pack_i, s->d_pack_tab, s->d_acc2, s->d_chunk_roots, s->d_bright, s->d_comp, s->d_tab, s->d_dplane, s->d_eplane, s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_num_strong,
                    s->d_list_k, s->d_list_i, s->d_parent, s->d_comp_id, s->d_part_roots, s->d_acc, s->d_recs};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -663,6 +668,7 @@ static int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uin
     STREAM_TRY(dmalloc(&s->d_bits, B * L.plane_frame_stride));
     STREAM_TRY(dmalloc(&s->d_sbytes, B * L.bytes_frame_stride));
     STREAM_TRY(dmalloc(&s->d_tile_counts, tile_counts_bytes(s)));
+    STREAM_TRY(dmalloc(&s->d_occ, B * (size_t)occ_frame_words(L) * 4));
     STREAM_TRY(dmalloc(&s->d_bright, (size_t)kBrightCap * sizeof(uint2)));
 
     // per-frame counters in the layout of h_counts, so that one copy brings them all back:
@@ -701,6 +707,7 @@ static int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uin
         s->h_counts_dev = nullptr;
     }
     STREAM_TRY(hipMemsetAsync(s->d_overflow, 0, 4, s->st));
+    STREAM_TRY(hipMemsetAsync(s->d_occ, 0, B * (size_t)occ_frame_words(L) * 4, s->st));
     // bits beyond the image width (x >= W up to the row pitch) are never written by the threshold kernels and must read 0
     STREAM_TRY(hipMemsetAsync(s->d_bits, 0, B * L.plane_frame_stride, s->st));
     STREAM_TRY(hipStreamSynchronize(s->st));
@@ -774,6 +781,9 @@ static ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t 
     // The byte mask (the reference kernel's result_strong, 1 byte per pixel) is an OUTPUT only when it was asked for
     // (want_strong_mask: --writeout, parity tests): the hot path's own strong mask is the bit plane, and the 0.58 GB of
     // zeros per 32 Eiger frames cost the streaming kernel 15 % (FFS_DENSE_MASK=1 forces them, for A/B and the roofline leg)
+    a.occ = s->d_occ;
+    a.occ_frame_words = occ_frame_words(L);
+    a.occ_spr = L.mpitch / 16;
     a.dense_mask = (p.want_strong_mask || c->knobs.dense_mask || (a.dbg & 16)) && !(a.dbg & 8) ? 1 : 0;
     a.ginfo = c->d_ginfo;
     a.mmap = c->d_mmap;
@@ -1063,6 +1073,10 @@ dense_done:
     // extended algorithm's last pass always do)
     ca.dense_bytes = ((one_kernel || (p.algorithm == FFS_ALGO_DISPERSION_EXTENDED && ext_stream_first(s, ta))) ? ta.dense_mask : 1) ? 1 : 0;
     s->dense_valid = ca.dense_bytes != 0;
+    ca.occ = s->d_occ;
+    ca.occ_frame_words = occ_frame_words(L);
+    ca.occ_spr = L.mpitch / 16;
+    ca.use_occ = (one_kernel && c->knobs.use_occ) ? 1 : 0;   // (only the streaming kernels and their fix-up keep the bitmap)
     // FFS_CCL = 2 (default): the whole sparse stage in one launch, one workgroup per frame (kernels_chain.hpp)
     s->chain_mode = root_mode && ccl_variant >= 2 && c->chain_ok && s->direct_recs && s->h_counts_dev && c->n_tiles <= kChainMaxTiles && L.H <= kChainMaxRows && !skip;
     if (s->chain_mode) {

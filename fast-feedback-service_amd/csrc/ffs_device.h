@@ -74,6 +74,11 @@ struct ThresholdArgs {
     uint2* bright_list;        // [bright_cap] (frame << 16 | x, y)
     uint32_t bright_cap;
     uint32_t* overflow;        // status word: 8 = the bright-window list overflowed
+    // occupancy of the strong plane, one bit per 16-byte segment (128 pixels) of a plane row: set by whoever sets a plane
+    // bit in a one-kernel batch, read and cleared by k_frame_chain, which then loads only the segments that hold something
+    uint32_t* occ;             // [n][occ_frame_words]
+    uint32_t occ_frame_words;  // words per frame = ceil(H * occ_spr / 32)
+    uint32_t occ_spr;          // segments per plane row = mpitch / 16
     int dense_mask;            // the streaming kernels zero-fill the byte mask (somebody wants it); else they leave it alone
     int dbg;                   // FFS_K1_DEBUG: timing experiments only (results are wrong when set)
 };
@@ -128,6 +133,9 @@ struct CclArgs {
     uint32_t bpitch;
     uint64_t bytes_frame_stride;
     int dense_bytes;           // write the byte mask at all (only when somebody asked for it)
+    uint32_t* occ;             // see ThresholdArgs; null or use_occ == 0: the whole plane is read
+    uint32_t occ_frame_words, occ_spr;
+    int use_occ;
 };
 
 // Per-component accumulator (device) -- reduced with 64-bit integer atomics so the result

@@ -41,7 +41,8 @@ constexpr int kChainThreads = 1024;
 constexpr int kChainWaves = kChainThreads / 64;
 constexpr int kChainMaxRows = 4480;     // per-row offsets kept in LDS; taller frames take the four kernels
 constexpr int kChainMaxTiles = kChainMaxRows / kTileRows;
-constexpr int kChainListCap = 448;      // non-zero plane words a wave stages (a round of loads adds at most 256)
+constexpr int kChainListCap = 320;      // non-zero plane words a wave stages (a round of loads adds at most 256)
+constexpr int kChainSegCap = 512;       // occupied plane segments a wave lists per round of its occupancy bitmap (8 bits per lane)
 constexpr int kChainQuads = 4;          // rounds (4 words per lane each) per batch of plane loads; three batches are live
 constexpr int kChainLdsEntries = 20480; // strong pixels of a frame whose union-find forest fits LDS
 constexpr int kChainPer = kChainLdsEntries / kChainThreads;   // consecutive entries per thread in phases U / P / R
@@ -61,7 +62,8 @@ constexpr int kChainAccBytes = kChainSlots * ((int)sizeof(ChainAcc) + (int)sizeo
 constexpr int kChainOutGlobalBytes = kChainThreads * (int)sizeof(WireRec2);
 static_assert(kChainAccBytes <= kChainForestBytes && kChainOutGlobalBytes <= kChainForestBytes, "LDS plan");
 constexpr int kChainStageOff = (kChainMaxTiles + 1) * 4 + (kChainMaxRows + 1) * 4 + kChainForestBytes;
-constexpr int kChainDynBytes = kChainStageOff + kChainWaves * 2 * kChainListCap * 4;
+constexpr int kChainSegOff = kChainStageOff + kChainWaves * 2 * kChainListCap * 4;
+constexpr int kChainDynBytes = kChainSegOff + kChainWaves * kChainSegCap * 2;
 static_assert(kChainStageOff % 8 == 0 && kChainDynBytes <= 160 * 1024 - 256, "LDS plan");
 
 // Inclusive prefix sum over the 64 lanes in six DPP adds (row_shr 1/2/4/8 inside the rows of 16, then row_bcast:15 and
@@ -264,6 +266,79 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                 n_list = rem;
             };
 
+            const rsrc_t r_words = make_rsrc(words, (uint32_t)nw * 4u);   // (out of range reads 0: no branch around a load)
+            if (a.use_occ) {
+                // The streaming kernel left one bit per 16-byte segment of the plane that holds a strong pixel: read the
+                // bitmap (a few KB per wave instead of its 140 KB of plane), list the occupied segments in order, load
+                // only those.  The bits are cleared as they are read, like the plane words.
+                uint32_t* occ = a.occ + (uint64_t)frame * a.occ_frame_words;
+                uint16_t* s_seg = reinterpret_cast<uint16_t*>(s_dyn + kChainSegOff) + wave * kChainSegCap;
+                const uint32_t spr = a.occ_spr;
+                const uint32_t b0 = (uint32_t)yb * spr, nbits = (uint32_t)(ye - yb) * spr;
+                auto fetch8 = [&](uint32_t base, uint32_t& lo, uint32_t& hi) {   // the two bitmap words this lane's 8 bits lie in
+                    const uint32_t rel = base + 8u * (uint32_t)lane;
+                    lo = hi = 0;
+                    if (rel < nbits) {
+                        const uint32_t wi = (b0 + rel) >> 5;
+                        lo = occ[wi];
+                        hi = occ[wi + 1];   // (the bitmap has two words of slack)
+                    }
+                };
+                uint32_t lo, hi;
+                fetch8(0, lo, hi);
+                for (uint32_t base = 0; base < nbits; base += 512u) {
+                    const uint32_t rel = base + 8u * (uint32_t)lane;
+                    uint32_t v = 0;
+                    if (rel < nbits) {
+                        const uint32_t sh = (b0 + rel) & 31u, nb = min(8u, nbits - rel);
+                        const uint32_t mask = (1u << nb) - 1u;
+                        v = (uint32_t)((((unsigned long long)hi << 32) | lo) >> sh) & mask;
+                        if (v) {   // consumed: clear (neighbouring lanes, waves and 8-bit groups share the words)
+                            const uint32_t wi = (b0 + rel) >> 5;
+                            atomicAnd(occ + wi, ~(v << sh));
+                            if (sh > 24u) atomicAnd(occ + wi + 1, ~(v >> (32u - sh)));
+                        }
+                    }
+                    uint32_t nlo, nhi;
+                    fetch8(base + 512u, nlo, nhi);   // the next round's words are on their way while this one is worked on
+                    const uint32_t cnt = (uint32_t)__popc(v);
+                    const uint32_t inc = wave_inclusive_scan(cnt);
+                    const int T = __builtin_amdgcn_readlane((int)inc, 63);
+                    if (T != 0) {
+                        uint32_t pos = inc - cnt;
+                        while (v) {
+                            const int b = __ffs((int)v) - 1;
+                            v &= v - 1;
+                            s_seg[pos++] = (uint16_t)(rel + (uint32_t)b);
+                        }
+                        for (int sb = 0; sb < T; sb += 64) {
+                            const int e = sb + lane;
+                            const bool valid = e < T;
+                            const uint32_t sbit = valid ? (uint32_t)s_seg[e] : 0u;
+                            const uint32_t row_rel = sbit / spr, seg = sbit - row_rel * spr;
+                            const uint32_t woff = row_rel * (uint32_t)dpr + seg * 4u;   // word offset in this wave's rows
+                            const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r_words, valid ? woff * 4u : 0x80000000u, 0, 0);
+                            const uint32_t vv[4] = {q[0], q[1], q[2], q[3]};
+                            const uint32_t cw = (vv[0] != 0u) + (vv[1] != 0u) + (vv[2] != 0u) + (vv[3] != 0u);
+                            if (n_list + 256 > kChainListCap) drain(false);
+                            const uint32_t iw = wave_inclusive_scan(cw);
+                            int at = n_list + (int)(iw - cw);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                if (vv[c]) {
+                                    s_g[at] = woff + (uint32_t)c;
+                                    s_w[at] = vv[c];
+                                    ++at;
+                                }
+                            }
+                            n_list += __builtin_amdgcn_readlane((int)iw, 63);
+                        }
+                    }
+                    lo = nlo;
+                    hi = nhi;
+                }
+                drain(true);
+            } else {
             const int nrounds = (nw + 255) / 256;   // a round = 4 x 64 consecutive words: lane L holds words 256 r + 64 c + L
             // Rounds whose words lie in tiles without a strong pixel are not loaded at all (wave-uniform test).  Rounds are
             // visited in increasing order, so the tile of a round's first word is tracked, not divided for.
@@ -279,7 +354,6 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
             };
             // (buffer loads: out of range -- beyond the wave's words, or switched off -- reads 0, so the loads are not
             // wrapped in branches and the waits below can count them)
-            const rsrc_t r_words = make_rsrc(words, (uint32_t)nw * 4u);
             auto load_batch = [&](int b, uint32_t (&buf)[kChainQuads][4]) {
 #pragma unroll
                 for (int q = 0; q < kChainQuads; ++q) {
@@ -326,6 +400,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                 stage_batch(b + 2, b2);
             }
             drain(true);
+            }
         }
     }
     __syncthreads();

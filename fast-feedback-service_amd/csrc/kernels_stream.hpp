@@ -423,8 +423,11 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
             const uint32_t cb = s_q[14][lane];
             if (cb) {  // the plane is all zero when the kernel starts (the compaction clears what it consumed)
                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)cb, r_cb, (uint32_t)((uint64_t)fe * a.plane_frame_stride) + ge, row * a.mpitch, 0);
-                if constexpr (!EXT)  // (the extended algorithm's final pass counts its own strong pixels)
+                if constexpr (!EXT) {  // (the extended algorithm's final pass counts its own strong pixels)
                     atomicAdd(a.tile_counts + (uint64_t)(f0 + (int)fe) * a.n_tiles + (row / (uint32_t)kTileRows), (uint32_t)__popc(cb));
+                    const uint32_t ob = row * a.occ_spr + (ge >> 4);   // the 16-byte segment of the plane row this byte lies in
+                    atomicOr(a.occ + (uint64_t)(f0 + (int)fe) * a.occ_frame_words + (ob >> 5), 1u << (ob & 31u));
+                }
             }
         }
         qn = 0;
@@ -570,7 +573,11 @@ __global__ __launch_bounds__(256) void k_bright_fix(const ThresholdArgs a) {
         if (exact_strong<PixelT, EXT>(a, img, (int)x, (int)y)) {  // EXT: the dispersion half alone, into the first-pass plane
             uint8_t* plane = (EXT ? a.dplane : a.bits) + (uint64_t)frame * a.plane_frame_stride + (uint64_t)y * a.mpitch;
             atomicOr(reinterpret_cast<uint32_t*>(plane) + (x >> 5), 1u << (x & 31u));  // rows start on 4-byte boundaries
-            if (!EXT) atomicAdd(a.tile_counts + (uint64_t)frame * a.n_tiles + y / (uint32_t)kTileRows, 1u);
+            if (!EXT) {
+                atomicAdd(a.tile_counts + (uint64_t)frame * a.n_tiles + y / (uint32_t)kTileRows, 1u);
+                const uint32_t ob = y * a.occ_spr + (x >> 7);
+                atomicOr(a.occ + (uint64_t)frame * a.occ_frame_words + (ob >> 5), 1u << (ob & 31u));
+            }
         }
     }
 }
@@ -751,6 +758,8 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
                 uint32_t* plane = reinterpret_cast<uint32_t*>(a.bits + (uint64_t)(f0 + (int)fe) * a.plane_frame_stride + (uint64_t)row * a.mpitch);
                 atomicOr(plane + (x0 >> 5), cb << (x0 & 31u));
                 atomicAdd(a.tile_counts + (uint64_t)(f0 + (int)fe) * a.n_tiles + (row / (uint32_t)kTileRows), (uint32_t)__popc(cb));
+                const uint32_t ob = row * a.occ_spr + (x0 >> 7);
+                atomicOr(a.occ + (uint64_t)(f0 + (int)fe) * a.occ_frame_words + (ob >> 5), 1u << (ob & 31u));
             }
         }
         qn = 0;
