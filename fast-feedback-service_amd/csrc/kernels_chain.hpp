@@ -17,10 +17,11 @@
 // Phases (separated by __syncthreads(), which also orders the block's global writes):
 //   A  exclusive scan of the frame's per-tile counts (the streaming kernel's atomics) -> tile offsets in LDS; the
 //      counts are zeroed for the next batch
-//   E  compaction: each wave streams a contiguous range of tiles (buffer loads, twelve rounds of 256 words in flight,
-//      tiles without strong pixels skipped), stages the non-zero words of several tiles (ballot + mbcnt) and
-//      places their pixels 64 words at a time; nothing here waits for a load it just issued (the pixel VALUES
-//      are fetched in phase P)
+//   E  compaction: each wave takes a contiguous range of tiles; it reads the occupancy bitmap the streaming kernel
+//      left (one bit per 16-byte plane segment), lists the occupied segments in order and loads only those -- or,
+//      without a bitmap (extended algorithm), streams its whole range (buffer loads, twelve rounds of 256 words in
+//      flight, tiles without strong pixels skipped); the non-zero words are staged in LDS and their pixels placed
+//      64 words at a time; nothing here waits for a load it just issued (the pixel VALUES are fetched in phase P)
 //   S  per-row counts -> per-row list offsets (block scan, in LDS)
 //   U  union-find: vertical edges + the reference's row-wrap edge (the body of k_union<false>)
 //   then, for frames held in LDS:
