@@ -15,6 +15,7 @@
 #include <atomic>
 #include <vector>
 
+#include <hip/hip_ext.h>
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types only: the library is loaded with dlopen when several devices are in use
 
@@ -55,6 +56,7 @@ struct Knobs {
     long long target_waves = 16384;
     int emit_variant = 1, ccl_variant = 2, link_runs = 1, ccl_grid = 32, ccl_cus = 0, direct_recs = 1;
     int sched = 3;             // FFS_SCHED: 1 = sparse chain on a high-priority stream of its own; 2 = also every dense kernel of the context on ONE stream
+    int ext_launch = 1;        // FFS_EXT_LAUNCH: the streaming kernel carries its start / stop events (hipExtLaunchKernel)
     int use_occ = 1;           // FFS_OCC: k_frame_chain reads only the plane segments the occupancy bitmap names
     int fix_aside = 1;         // FFS_FIX_ASIDE: k_bright_fix in the sparse stream (SCHED >= 1)
     int decode_dense = 1;      // FFS_DECODE_DENSE: the decode kernel runs in the dense kernels' stream (0: in the upload stream)
@@ -84,6 +86,7 @@ struct Knobs {
         decode_dense = env_int("FFS_DECODE_DENSE", 1);
         fix_aside = env_int("FFS_FIX_ASIDE", 1);
         use_occ = env_int("FFS_OCC", 1);
+        ext_launch = env_int("FFS_EXT_LAUNCH", 1);
         bright_cap = std::max(0, std::min(1 << 20, env_int("FFS_BRIGHT_CAP", 1 << 20)));
     }
 };
@@ -197,6 +200,7 @@ struct ffs_stream {
     ReflOut* h_recs = nullptr;
     uint32_t* d_occ = nullptr;     // [max_batch][occ_frame_words] occupancy of the strong plane (one bit per 16-byte segment)
     uint32_t* h_counts_dev = nullptr;  // device-side address of h_counts (k_frame_chain writes the counters itself)
+    bool ev1_pending = false;      // ev[1] (start of the threshold stage) has not been recorded yet for this batch
     bool ev3_is_ev4 = false;       // one event behind the sparse launch (k_frame_chain leaves nothing to copy)
     bool dev_input = false;        // this batch's frames were on the device already (ffs_submit_device): no upload, no ev[0]
     bool dense_valid = false;      // the byte masks of the last batch were produced
@@ -907,6 +911,14 @@ static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_
         const unsigned n_groups = (n_frames + (unsigned)a.group_frames - 1) / (unsigned)a.group_frames;
         const int ahead = s->ctx->knobs.k1_ahead;
         if (s->ctx->pixel_bytes == 4) {
+            if (fix_st && s->ctx->knobs.ext_launch) {
+                hipExtLaunchKernelGGL(k_stream_u32<2>, dim3((unsigned)(b.n_strips * bands8s), n_groups), dim3(64), 0, s->st,
+                                      s->ev1_pending ? s->ev[1] : nullptr, fix_after, 0, b);
+                s->ev1_pending = false;
+                (void)hipStreamWaitEvent(fix_st, fix_after, 0);
+                hipLaunchKernelGGL(k_bright_fix<uint32_t>, dim3(32), dim3(256), 0, fix_st, b);
+                return;
+            }
             hipLaunchKernelGGL(k_stream_u32<2>, dim3((unsigned)(b.n_strips * bands8s), n_groups), dim3(64), 0, s->st, b);
             if (fix_st) {
                 (void)hipEventRecord(fix_after, s->st);
@@ -917,7 +929,15 @@ static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_
         }
         if (ahead >= 3)
             hipLaunchKernelGGL(k_stream_u16<3>, dim3((unsigned)(b.n_strips * bands8s), n_groups), dim3(64), 0, s->st, b);
-        else
+        else if (fix_st && s->ctx->knobs.ext_launch) {
+            // start and stop events ride on the dispatch itself (its completion signal): no marker packets around it
+            hipExtLaunchKernelGGL(k_stream_u16<2>, dim3((unsigned)(b.n_strips * bands8s), n_groups), dim3(64), 0, s->st,
+                                  s->ev1_pending ? s->ev[1] : nullptr, fix_after, 0, b);
+            s->ev1_pending = false;
+            (void)hipStreamWaitEvent(fix_st, fix_after, 0);
+            hipLaunchKernelGGL(k_bright_fix<uint16_t>, dim3(32), dim3(256), 0, fix_st, b);
+            return;
+        } else
             hipLaunchKernelGGL(k_stream_u16<2>, dim3((unsigned)(b.n_strips * bands8s), n_groups), dim3(64), 0, s->st, b);
         if (fix_st) {
             (void)hipEventRecord(fix_after, s->st);
@@ -1007,6 +1027,11 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
         HIP_TRY(c, hipMemsetAsync(s->d_tile_counts, 0, tile_counts_bytes(s), s->st));
     s->counts_dirty = true;
     s->bits_dirty = true;  // until every launch of this batch is enqueued (a failure in between leaves bits behind)
+    const bool will_ext_launch = one_kernel && s->st2 != s->st && c->knobs.fix_aside && c->knobs.ext_launch && c->knobs.k1_ahead < 3;
+    if (s->ev1_pending && !will_ext_launch) {
+        HIP_TRY(c, hipEventRecord(s->ev[1], s->st));
+        s->ev1_pending = false;
+    }
     if (p.algorithm == FFS_ALGO_DISPERSION_EXTENDED) {
         launch_extended(s, ta, n);
     } else {
@@ -1212,9 +1237,10 @@ extern "C" int ffs_submit_device(ffs_stream* s, const void* device_pixels, size_
     int rc = check_layout(s, pitch, fstride, n_frames);
     if (rc != FFS_OK) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
-    // (one marker, not two and a wait: every packet in the dense stream is ~5 us between two streaming kernels)
-    HIP_TRY(c, hipEventRecord(s->ev[1], s->st));
+    // (no marker here: every packet in the dense stream is ~5 us between two streaming kernels; enqueue_batch attaches
+    // the start event to its first kernel where it can, or records it)
     s->dev_input = true;
+    s->ev1_pending = true;
     s->first_id = first_frame_id;
     return enqueue_batch(s, device_pixels, pitch, fstride, n_frames);
 }
@@ -1592,8 +1618,8 @@ static int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32
                 ffs_stream* b = s->big;
                 const uint8_t* img = static_cast<const uint8_t*>(s->cur_img) + (size_t)f * s->cur_fstride;
                 b->first_id = s->first_id + f;
-                HIP_TRY(c, hipEventRecord(b->ev[1], b->st));
                 b->dev_input = true;
+                b->ev1_pending = true;
                 int rc = enqueue_batch(b, img, s->cur_pitch, s->cur_fstride, 1, &s->batch_params);
                 if (rc != FFS_OK) return rc;
                 HIP_TRY(c, hipEventSynchronize(b->ev[4]));
