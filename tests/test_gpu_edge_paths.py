@@ -291,3 +291,35 @@ def test_streams_of_one_context_from_several_threads(ffs):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.uint32])
+def test_random_shapes_and_densities(ffs, dtype):
+    """Small frames of random shape, mask and strong-pixel density (from none to a quarter of the frame), in
+    batches of random size: plane rows of one to five 16-byte segments, tiles cut by the frame's last rows, waves of
+    the per-frame workgroup with nothing to do, runs crossing word and segment boundaries, row-wrap pairs."""
+    rng = np.random.default_rng(2024 if dtype == np.uint16 else 2025)
+    for case in range(24):
+        W = int(rng.integers(1, 640))
+        H = int(rng.integers(1, 300))
+        B = int(rng.integers(1, 5))
+        mask = (rng.random((H, W)) > rng.choice([0.0, 0.02, 0.3])).astype(np.uint8)
+        ctx = ffs.Context(W, H, dtype, max_batch=B, max_strong_per_frame=W * H)
+        ctx.set_mask(mask)
+        mss, sep = int(rng.integers(0, 4)), float(rng.choice([0.0, 1.5, 20.0]))
+        ctx.set_params(want_strong_mask=int(case % 2), want_strong_list=1, min_spot_size=mss, max_peak_centroid_separation=sep)
+        st = ctx.stream()
+        frames = []
+        for f in range(B):
+            img = rng.poisson(rng.choice([0.2, 2.0, 30.0]), (H, W)).astype(dtype)
+            dens = rng.choice([0.0, 0.001, 0.02, 0.25])
+            hot = rng.random((H, W)) < dens
+            img[hot] += rng.integers(50, 4000, hot.sum()).astype(dtype)
+            if W > 1 and H > 1 and f == 0:
+                img[0, W - 1] = 3000
+                img[1, 0] = 2500
+            frames.append(img)
+        res = st.process(np.stack(frames))
+        for fr, img in zip(res, frames):
+            assert_frame_matches_oracle(fr, img, mask, min_spot_size=mss, max_sep=sep)
+        st.close()
