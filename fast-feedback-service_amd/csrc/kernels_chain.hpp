@@ -47,7 +47,6 @@ constexpr int kChainSegCap = 512;       // occupied plane segments a wave lists 
 constexpr int kChainQuads = 4;          // rounds (4 words per lane each) per batch of plane loads; three batches are live
 constexpr int kChainLdsEntries = 20480; // strong pixels of a frame whose union-find forest fits LDS
 constexpr int kChainPer = kChainLdsEntries / kChainThreads;   // consecutive entries per thread in phases U / P / R
-constexpr int kChainGroup = 10;         // entries a thread searches side by side in phase U (kChainPer = 2 groups)
 constexpr int kChainSlots = 512;        // components accumulated in LDS at a time
 
 // LDS accumulator of one component: sum I, sum (2x+1) I, sum (2y+1) I, peak = I << 32 | ~k
@@ -438,73 +437,54 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
         const uint32_t per = (n + kChainThreads - 1) / kChainThreads;
         const uint32_t i0 = min((uint32_t)tid * per, n), i1 = min(i0 + per, n);
 
+        // ---- X: the list's column numbers into LDS (16 bits each, in the staging area phase E is done with) --------
+        // With the per-row list offsets they ARE the list (k = y W + x), so phases U and P make no global access to it:
+        // a dependent access costs ~0.1 us here against ~1 us at the L2.
+        uint16_t* s_x = reinterpret_cast<uint16_t*>(s_dyn + kChainStageOff);
+        for (uint32_t i = tid; i < n; i += kChainThreads) {
+            const uint32_t kv = gk[i];
+            s_x[i] = (uint16_t)(kv - (kv / W) * W);
+        }
+        __syncthreads();
+        // the row of list entry i0: the last row whose offset is <= i0 (rows without strong pixels share their successor's)
+        uint32_t yrow = 0;
+        if (i0 < i1) {
+            uint32_t lo = 0, hi = H;   // first r in (0, H] with s_row[r] > i0, minus one
+            while (lo < hi) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (s_row[mid + 1] <= i0) lo = mid + 1; else hi = mid;
+            }
+            yrow = lo;
+        }
+        // does entry j (in row r) continue the run of entry j - 1, i.e. k[j - 1] + 1 == k[j]?  (Across a row end too:
+        // the reference's k + 1 edge has no row-end check, connected_components.cc:62-70.)
+        auto continues = [&](uint32_t j, uint32_t r) -> bool {
+            if (j == 0) return false;
+            const uint32_t xj = s_x[j], xp = s_x[j - 1];
+            if (j != s_row[r]) return xp + 1 == xj;                                   // same row
+            return xj == 0 && xp == W - 1 && r > 0 && s_row[r - 1] < s_row[r];        // first of its row: the row above ends the list before it
+        };
+
         // ---- U: vertical edges + row wrap (k_union<false> with the runs linked by the compaction) ----------------
-        // The list stays in global memory (a dependent access ~1 us), so a thread runs the binary searches of
-        // kChainGroup entries side by side: a step of all of them costs one round trip.
-        const rsrc_t r_gk = make_rsrc(gk, n * 4u);
-        constexpr uint32_t kOob = 0x80000000u;   // (an offset no resource reaches: the load returns 0)
         {
-            uint32_t kprev = i0 > 0 && i0 < i1 ? gk[i0 - 1] : 0xFFFFFFF0u;
-#pragma unroll
-            for (int h = 0; h < kChainPer / kChainGroup; ++h) {
-                const uint32_t ib = i0 + (uint32_t)(h * kChainGroup);
-                if (ib >= i1) break;
-                uint32_t ek[kChainGroup], lo[kChainGroup], hi[kChainGroup];
-                uint32_t starts = 0;
-#pragma unroll
-                for (int q = 0; q < kChainGroup; ++q) ek[q] = __builtin_amdgcn_raw_buffer_load_b32(r_gk, ib + q < i1 ? (ib + q) * 4u : kOob, 0, 0);
-#pragma unroll
-                for (int q = 0; q < kChainGroup; ++q) {
-                    const uint32_t i = ib + q;
-                    lo[q] = hi[q] = 0;
-                    if (i >= i1) continue;
-                    const uint32_t ki = ek[q];
-                    const uint32_t y = ki / W;
-                    const uint32_t kp = q > 0 ? ek[q - 1] : kprev;
-                    const bool st = i == 0 || kp + 1 != ki;
-                    starts |= st ? 1u << q : 0u;
-                    // the reference's k + 1 edge has no row-end check (connected_components.cc:62-70)
-                    if (!st && ki - y * W == 0) uf_union(spar, i - 1, i);
-                    if (y + 1 < H) {
-                        lo[q] = max(i + 1, s_row[y + 1]);
-                        hi[q] = max(lo[q], min(min(n, i + 1 + W), s_row[y + 2]));
-                    }
+            uint32_t y = yrow;
+            for (uint32_t i = i0; i < i1; ++i) {
+                while (s_row[y + 1] <= i) ++y;
+                const uint32_t x = s_x[i];
+                const bool cont = continues(i, y);
+                if (cont && x == 0) uf_union(spar, i - 1, i);   // the row-wrap edge (a run inside a row was linked by the compaction)
+                if (y + 1 >= H) continue;
+                uint32_t lo = max(i + 1, s_row[y + 1]);
+                const uint32_t end = max(lo, min(min(n, i + 1 + W), s_row[y + 2]));
+                uint32_t hi = end;
+                while (lo < hi) {   // lower bound of x among the next row's entries
+                    const uint32_t mid = lo + ((hi - lo) >> 1);
+                    if ((uint32_t)s_x[mid] < x) lo = mid + 1; else hi = mid;
                 }
-                for (;;) {   // lower bound of k + W in the next row's list range, all entries of the group in step
-                    uint32_t km[kChainGroup];
-                    bool any = false;
-#pragma unroll
-                    for (int q = 0; q < kChainGroup; ++q) {
-                        const bool open = lo[q] < hi[q];
-                        km[q] = __builtin_amdgcn_raw_buffer_load_b32(r_gk, open ? (lo[q] + ((hi[q] - lo[q]) >> 1)) * 4u : kOob, 0, 0);
-                        any |= open;
-                    }
-                    if (!any) break;
-#pragma unroll
-                    for (int q = 0; q < kChainGroup; ++q) {
-                        if (lo[q] < hi[q]) {
-                            const uint32_t mid = lo[q] + ((hi[q] - lo[q]) >> 1);
-                            if (km[q] < ek[q] + W) lo[q] = mid + 1; else hi[q] = mid;
-                        }
-                    }
-                }
-                uint32_t kb[kChainGroup], kbp[kChainGroup];   // the entry found and the one before it
-#pragma unroll
-                for (int q = 0; q < kChainGroup; ++q) {
-                    const bool look = ib + q < i1 && ek[q] / W + 1 < H && lo[q] < n;
-                    kb[q] = __builtin_amdgcn_raw_buffer_load_b32(r_gk, look ? lo[q] * 4u : kOob, 0, 0);
-                    kbp[q] = __builtin_amdgcn_raw_buffer_load_b32(r_gk, look && lo[q] > 0 ? (lo[q] - 1) * 4u : kOob, 0, 0);
-                    if (!(look && lo[q] > 0)) kbp[q] = 0xFFFFFFF0u;
-                }
-#pragma unroll
-                for (int q = 0; q < kChainGroup; ++q) {
-                    const uint32_t i = ib + q;
-                    if (i >= i1 || ek[q] / W + 1 >= H || lo[q] >= n) continue;
-                    const uint32_t key = ek[q] + W;
+                if (lo < end && (uint32_t)s_x[lo] == x) {
                     // one edge per pair of overlapping runs is enough (see k_union)
-                    if (kb[q] == key && (((starts >> q) & 1u) || kbp[q] + 1 != key)) uf_union(spar, i, lo[q]);
+                    if (!cont || !continues(lo, y + 1)) uf_union(spar, i, lo);
                 }
-                kprev = ek[kChainGroup - 1];
             }
         }
         __syncthreads();
@@ -529,13 +509,22 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
 #pragma unroll
             for (int q = 0; q < kChainPer / 2; ++q) eid[q] = 0xFFFFFFFFu;
         }
+        constexpr uint32_t kOob = 0x80000000u;   // (an offset no resource reaches: the load returns 0)
+        {
+            uint32_t y = yrow;
 #pragma unroll
-        for (int q = 0; q < kChainPer; ++q) exy[q] = __builtin_amdgcn_raw_buffer_load_b32(r_gk, i0 + q < i1 ? (i0 + q) * 4u : kOob, 0, 0);
+            for (int q = 0; q < kChainPer; ++q) {
+                exy[q] = 0;
+                if (i0 + q < i1) {
+                    while (s_row[y + 1] <= i0 + q) ++y;
+                    exy[q] = (y << 16) | (uint32_t)s_x[i0 + q];
+                }
+            }
+        }
         const rsrc_t r_img = make_rsrc(img, (uint32_t)a.H * a.pitch);
 #pragma unroll
         for (int q = 0; q < kChainPer; ++q) {
-            const uint32_t y = exy[q] / W, x = exy[q] - y * W;
-            exy[q] = (y << 16) | x;
+            const uint32_t y = exy[q] >> 16, x = exy[q] & 0xFFFFu;
             const uint32_t off = i0 + q < i1 ? y * a.pitch + x * (uint32_t)sizeof(PixelT) : kOob;
             uint32_t v;
             if constexpr (kPack) v = ((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r_img, off, 0, 0) & 0xFFFFu) | 0xFFFF0000u;
