@@ -9,10 +9,9 @@
 // machine is the slots it holds (one workgroup per frame), not its duration.
 //
 // With a whole frame in one workgroup the round trips can stay on the CU.  A dependent access costs ~1 us at the
-// L2 and ~0.1 us in LDS, so the frame's union-find forest and the per-row list offsets live in LDS (frames up to
-// kChainLdsEntries strong pixels; denser frames run the stages on the global arrays), the accumulators of 512
-// components at a time do too, and where the list itself (global) has to be searched a thread keeps ten searches
-// in flight.
+// L2 and ~0.1 us in LDS, so the frame's union-find forest, the per-row list offsets and the list's column numbers
+// (16 bits each: with the row offsets they are the list) live in LDS (frames up to kChainLdsEntries strong pixels;
+// denser frames run the stages on the global arrays), and the accumulators of 512 components at a time do too.
 //
 // Phases (separated by __syncthreads(), which also orders the block's global writes):
 //   A  exclusive scan of the frame's per-tile counts (the streaming kernel's atomics) -> tile offsets in LDS; the
@@ -23,7 +22,8 @@
 //      flight, tiles without strong pixels skipped); the non-zero words are staged in LDS and their pixels placed
 //      64 words at a time; nothing here waits for a load it just issued (the pixel VALUES are fetched in phase P)
 //   S  per-row counts -> per-row list offsets (block scan, in LDS)
-//   U  union-find: vertical edges + the reference's row-wrap edge (the body of k_union<false>)
+//   X  the list's column numbers into LDS
+//   U  union-find: vertical edges + the reference's row-wrap edge (k_union<false>'s edges), all in LDS
 //   then, for frames held in LDS:
 //   P  pixel values (twenty independent loads per thread); every entry finds its root; roots are numbered in list order (= label order, connected_components.cc:91,242)
 //   R  512 components at a time: entries add into LDS accumulators (integer atomics: order-independent), one thread
