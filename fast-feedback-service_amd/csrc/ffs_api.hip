@@ -56,6 +56,7 @@ struct Knobs {
     long long target_waves = 16384;
     int emit_variant = 1, ccl_variant = 2, link_runs = 1, ccl_grid = 32, ccl_cus = 0, direct_recs = 1;
     int sched = 3;             // FFS_SCHED: 1 = sparse chain on a high-priority stream of its own; 2 = also every dense kernel of the context on ONE stream
+    int chain_first = 2;       // FFS_CHAIN_FIRST = n > 0: the sparse launch also does the bright-window fix-up, and while at most n batches are in flight a streaming kernel waits until the previous batch's sparse launch has started
     int ext_launch = 1;        // FFS_EXT_LAUNCH: the streaming kernel carries its start / stop events (hipExtLaunchKernel)
     int use_occ = 1;           // FFS_OCC: k_frame_chain reads only the plane segments the occupancy bitmap names
     int fix_aside = 1;         // FFS_FIX_ASIDE: k_bright_fix in the sparse stream (SCHED >= 1)
@@ -87,6 +88,7 @@ struct Knobs {
         fix_aside = env_int("FFS_FIX_ASIDE", 1);
         use_occ = env_int("FFS_OCC", 1);
         ext_launch = env_int("FFS_EXT_LAUNCH", 1);
+        chain_first = env_int("FFS_CHAIN_FIRST", 2);
         bright_cap = std::max(0, std::min(1 << 20, env_int("FFS_BRIGHT_CAP", 1 << 20)));
     }
 };
@@ -111,6 +113,8 @@ struct ffs_ctx {
     int n_streams_made = 0;
     std::mutex stream_mu;            // guards the lazy creation of the shared streams
     std::vector<struct ffs_stack3d*> stack_pool;   // destroyed 3D stacks kept with their buffers for the next sweep (stream_mu)
+    std::atomic<int> inflight{0};    // batches between submit and wait, over all ffs_streams of the context
+    std::atomic<hipEvent_t> last_chain_start{nullptr};   // start event of the newest sparse launch: the next streaming kernel lets it get its CUs first
     bool chain_ok = false;           // k_frame_chain may use its 140 KB of dynamic LDS on this device
     ThreadError err;  // the calling thread's most recent error on any context
 };
@@ -200,6 +204,7 @@ struct ffs_stream {
     ReflOut* h_recs = nullptr;
     uint32_t* d_occ = nullptr;     // [max_batch][occ_frame_words] occupancy of the strong plane (one bit per 16-byte segment)
     uint32_t* h_counts_dev = nullptr;  // device-side address of h_counts (k_frame_chain writes the counters itself)
+    hipEvent_t ev_cs = nullptr;    // start of this stream's k_frame_chain launch (rides on the dispatch)
     bool ev1_pending = false;      // ev[1] (start of the threshold stage) has not been recorded yet for this batch
     bool ev3_is_ev4 = false;       // one event behind the sparse launch (k_frame_chain leaves nothing to copy)
     bool dev_input = false;        // this batch's frames were on the device already (ffs_submit_device): no upload, no ev[0]
@@ -235,9 +240,21 @@ struct OverflowFrame {
     std::vector<uint32_t> k, inten;
 };
 
+static inline void mark_busy(ffs_stream* s);
+static inline void mark_idle(ffs_stream* s);
+
 static uint32_t occ_frame_words(const Layout& L) { return (uint32_t)(((uint64_t)L.H * (L.mpitch / 16) + 31) / 32 + 2); }  // (+2: the chain reads a word ahead)
 
-static size_t tile_counts_bytes(const ffs_stream* s) { return (((size_t)s->max_batch * s->ctx->n_tiles + 1) * 4 + 255) / 256 * 256; }
+// per-tile counts | ... | [last - 1] workgroups of k_frame_chain through with the bright list | [last] entries of the bright list
+static inline void mark_busy(ffs_stream* s) {
+    if (!s->busy) ++s->ctx->inflight;
+    s->busy = true;
+}
+static inline void mark_idle(ffs_stream* s) {
+    if (s->busy) --s->ctx->inflight;
+    s->busy = false;
+}
+static size_t tile_counts_bytes(const ffs_stream* s) { return (((size_t)s->max_batch * s->ctx->n_tiles + 2) * 4 + 255) / 256 * 256; }
 
 // Growable device (or pinned host) buffer of the 3D stack: reallocated with slack when too small
 template <typename T>
@@ -557,6 +574,7 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     if (s->job.joinable()) s->job.join();
+    mark_idle(s);   // (a stream may be closed with its batch still in flight)
     if (s->big) ffs_stream_destroy(s->big);
     if (s->st_up && s->st_up != s->st) (void)hipStreamSynchronize(s->st_up);
     if (s->st) (void)hipStreamSynchronize(s->st);
@@ -572,6 +590,11 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
         if (p) (void)hipHostFree(p);
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
+    if (s->ev_cs) {
+        hipEvent_t mine = s->ev_cs;
+        s->ctx->last_chain_start.compare_exchange_strong(mine, nullptr);
+        (void)hipEventDestroy(s->ev_cs);
+    }
 
     if (s->st && !s->st_shared) (void)hipStreamDestroy(s->st);
     delete s;
@@ -668,6 +691,7 @@ static int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uin
         }
     }
     for (auto& e : s->ev) STREAM_TRY(hipEventCreate(&e));
+    STREAM_TRY(hipEventCreate(&s->ev_cs));
     STREAM_TRY(dmalloc(&s->d_img, B * L.frame_stride));
     STREAM_TRY(dmalloc(&s->d_bits, B * L.plane_frame_stride));
     STREAM_TRY(dmalloc(&s->d_sbytes, B * L.bytes_frame_stride));
@@ -899,7 +923,8 @@ static int ensure_extended_buffers(ffs_stream* s) {
 }
 
 // fix_st: the stream of the bright-window fix-up that follows a streaming kernel (nullptr: the dense stream itself)
-static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames, hipStream_t fix_st = nullptr, hipEvent_t fix_after = nullptr) {
+static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames, hipStream_t fix_st = nullptr, hipEvent_t fix_after = nullptr,
+                              bool skip_fix = false) {
     if (a.variant >= 2) {
         // the whole threshold in one kernel: final strong plane + per-tile counts (atomics into zeroed counters)
         ThresholdArgs b = a;
@@ -916,7 +941,7 @@ static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_
                                       s->ev1_pending ? s->ev[1] : nullptr, fix_after, 0, b);
                 s->ev1_pending = false;
                 (void)hipStreamWaitEvent(fix_st, fix_after, 0);
-                hipLaunchKernelGGL(k_bright_fix<uint32_t>, dim3(32), dim3(256), 0, fix_st, b);
+                if (!skip_fix) hipLaunchKernelGGL(k_bright_fix<uint32_t>, dim3(32), dim3(256), 0, fix_st, b);
                 return;
             }
             hipLaunchKernelGGL(k_stream_u32<2>, dim3((unsigned)(b.n_strips * bands8s), n_groups), dim3(64), 0, s->st, b);
@@ -935,7 +960,7 @@ static void launch_candidates(ffs_stream* s, const ThresholdArgs& a, uint32_t n_
                                   s->ev1_pending ? s->ev[1] : nullptr, fix_after, 0, b);
             s->ev1_pending = false;
             (void)hipStreamWaitEvent(fix_st, fix_after, 0);
-            hipLaunchKernelGGL(k_bright_fix<uint16_t>, dim3(32), dim3(256), 0, fix_st, b);
+            if (!skip_fix) hipLaunchKernelGGL(k_bright_fix<uint16_t>, dim3(32), dim3(256), 0, fix_st, b);
             return;
         } else
             hipLaunchKernelGGL(k_stream_u16<2>, dim3((unsigned)(b.n_strips * bands8s), n_groups), dim3(64), 0, s->st, b);
@@ -1028,6 +1053,22 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
     s->counts_dirty = true;
     s->bits_dirty = true;  // until every launch of this batch is enqueued (a failure in between leaves bits behind)
     const bool will_ext_launch = one_kernel && s->st2 != s->st && c->knobs.fix_aside && c->knobs.ext_launch && c->knobs.k1_ahead < 3;
+    // FFS_CCL = 2 (default): the whole sparse stage in one launch, one workgroup per frame (kernels_chain.hpp)
+    const bool will_chain = c->knobs.ccl_variant >= 2 && L.H <= 65535 && c->chain_ok && s->direct_recs && s->h_counts_dev
+                            && c->n_tiles <= kChainMaxTiles && L.H <= kChainMaxRows && !c->knobs.chain_skip;
+    // ... which then also does the bright-window fix-up, and whose workgroups (a whole CU each) should get their CUs
+    // BEFORE the next batch's streaming kernel floods the dispatcher: that kernel waits for this launch to have STARTED.
+    // (Without it a batch's sparse launch sits out the whole next streaming kernel: 0.35 ms more latency per batch.)
+    // Only while few batches are in flight: with a deep pipeline the latency is hidden anyway, the wait costs the dense
+    // stream ~15 us per batch and the fix-up inside the one-workgroup-per-frame launch ~25 us of its CUs (4 batches in
+    // flight: 0.369-0.377 against 0.353 ms per step; 2 in flight: 0.385 against 0.523).
+    const int depth = c->inflight.load() + (s->busy ? 0 : 1);
+    const bool chain_first = one_kernel && will_chain && will_ext_launch && c->knobs.chain_first > 0 && depth <= c->knobs.chain_first;
+    const bool fold_fix = chain_first;
+    if (chain_first) {
+        hipEvent_t prev = c->last_chain_start.load();
+        if (prev) HIP_TRY(c, hipStreamWaitEvent(s->st, prev, 0));
+    }
     if (s->ev1_pending && !will_ext_launch) {
         HIP_TRY(c, hipEventRecord(s->ev[1], s->st));
         s->ev1_pending = false;
@@ -1038,7 +1079,7 @@ static int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t 
         // with a sparse stream of its own, the bright-window fix-up goes there: the dense stream holds streaming
         // kernels only, back to back
         const bool fix_aside = one_kernel && s->st2 != s->st && c->knobs.fix_aside;
-        launch_candidates(s, ta, n, fix_aside ? s->st2 : nullptr, s->ev[2]);
+        launch_candidates(s, ta, n, fix_aside ? s->st2 : nullptr, s->ev[2], fold_fix);
         launch_exact(s, ta, n);
         if (fix_aside) {   // (ev[2] was recorded behind the streaming kernel, and st2 waits for it already)
             HIP_TRY(c, hipGetLastError());
@@ -1103,7 +1144,7 @@ dense_done:
     ca.occ_spr = L.mpitch / 16;
     ca.use_occ = (one_kernel && c->knobs.use_occ) ? 1 : 0;   // (only the streaming kernels and their fix-up keep the bitmap)
     // FFS_CCL = 2 (default): the whole sparse stage in one launch, one workgroup per frame (kernels_chain.hpp)
-    s->chain_mode = root_mode && ccl_variant >= 2 && c->chain_ok && s->direct_recs && s->h_counts_dev && c->n_tiles <= kChainMaxTiles && L.H <= kChainMaxRows && !skip;
+    s->chain_mode = root_mode && will_chain && !skip;
     if (s->chain_mode) {
         ChainArgs A{};
         A.c = ca;
@@ -1133,15 +1174,19 @@ dense_done:
         A.max_batch = (uint32_t)s->max_batch;
         A.rec_stride = s->max_comp;
         A.stop_after = Knobs::env_int("FFS_CHAIN_STOP", 0);
-        if (c->pixel_bytes == 2) hipLaunchKernelGGL(k_frame_chain<uint16_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, A);
-        else hipLaunchKernelGGL(k_frame_chain<uint32_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, A);
+        A.t = ta;
+        A.fix_bright = fold_fix ? 1 : 0;
+        A.fix_done = s->d_tile_counts + tile_counts_bytes(s) / 4 - 2;
+        if (c->pixel_bytes == 2) hipExtLaunchKernelGGL(k_frame_chain<uint16_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, s->ev_cs, nullptr, 0, A);
+        else hipExtLaunchKernelGGL(k_frame_chain<uint32_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, s->ev_cs, nullptr, 0, A);
+        if (one_kernel && s->st2 != s->st) c->last_chain_start.store(s->ev_cs);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(s->ev[4], s->st2));
         s->ev3_is_ev4 = true;
         s->spec_recs_copied = (uint64_t)s->max_batch * s->max_comp;
         s->bits_dirty = !one_kernel;
         s->counts_dirty = false;
-        s->busy = true;
+        mark_busy(s);
         s->n_frames = n;
         return FFS_OK;
     }
@@ -1221,7 +1266,7 @@ dense_done:
     HIP_TRY(c, hipEventRecord(s->ev[4], s->st2));
     s->bits_dirty = !one_kernel;  // the compaction of a one-kernel batch leaves the plane all zero again
     s->counts_dirty = (skip & 3) != 0;  // k_union cleared the counts of the frames of this batch (all the streaming kernel touched)
-    s->busy = true;
+    mark_busy(s);
     s->n_frames = n;
     return FFS_OK;
 }
@@ -1453,7 +1498,7 @@ static int ffs_submit_compressed_impl(ffs_stream* s, const void* const* chunks, 
     // helper thread, so that the caller gets its thread back while the index is built; ffs_wait joins it.
     s->first_id = first_frame_id;
     s->n_frames = n_frames;
-    s->busy = true;
+    mark_busy(s);
     s->job_rc = FFS_OK;
     s->job_err.clear();
     const ffs_params snap = c->params;
@@ -1557,7 +1602,7 @@ static int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32
         s->job.join();
         if (s->job_rc != FFS_OK) {
             (void)hipStreamSynchronize(s->st_up);
-            s->busy = false;
+            mark_idle(s);
             c->err = s->job_err;
             return s->job_rc;
         }
@@ -1575,7 +1620,7 @@ static int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32
         overflow = 0;
         for (uint32_t f = 0; f < n; ++f) overflow |= s->h_counts[10 * B + 1 + f];
     }
-    s->busy = false;
+    mark_idle(s);
     s->ovf.clear();
     if (overflow) {
         s->bits_dirty = true;
@@ -1627,7 +1672,7 @@ static int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32
                 if (b_ovf & 3u) {  // only the component count can still be short (it was a guess while the list was cut)
                     (void)hipMemsetAsync(b->d_overflow, 0, 4, b->st2);
                     (void)hipStreamSynchronize(b->st2);
-                    b->busy = false;
+                    mark_idle(b);
                     b->bits_dirty = true;
                     need_cap = std::max<uint64_t>(need_cap, b->h_counts[0]);
                     need_comp = std::max<uint64_t>(need_comp * 2, b->h_counts[b->max_batch]);

@@ -35,6 +35,7 @@
 // Results are those of the four-kernel chain bit for bit (same edges, same integer accumulators, same order).
 #pragma once
 #include "kernels_ccl.hpp"
+#include "kernels_threshold.hpp"   // exact_strong: the bright-window fix-up runs here when the batch has one launch only
 
 namespace ffsamd {
 
@@ -84,6 +85,9 @@ struct ChainArgs {
     uint32_t* h_counts;     // pinned host block (device address): [B] strong pixels, [B] components, [B][8] summary, [1] unused, [B] flags
     uint32_t max_batch;     // B
     uint32_t rec_stride;    // records between the frames' record areas (= max_comp)
+    ThresholdArgs t;        // for the bright-window fix-up (fix_bright != 0): what k_bright_fix does, by this launch
+    int fix_bright;
+    uint32_t* fix_done;     // workgroups through with the bright list (the last one zeroes the list's count)
     int stop_after;         // (timing experiments) 1..4: return after phase A / E / U / P
 };
 
@@ -140,6 +144,39 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
     const uint32_t W = (uint32_t)a.W, H = (uint32_t)a.H;
     const int dpr = a.mpitch >> 2;
 
+    // ---- B: bright windows (k_bright_fix's work): the listed pixels of THIS frame get their exact 64-bit sums and, if
+    // strong, their plane bit, occupancy bit and tile count -- before phase A reads the counts
+    uint32_t bright_flag = 0;
+    if (A.fix_bright) {
+        const ThresholdArgs& t = A.t;
+        const uint32_t listed = *t.bright_n;
+        const uint32_t nb = min(listed, t.bright_cap);
+        const uint8_t* fimg = (const uint8_t*)t.image + (uint64_t)frame * t.frame_stride;
+        for (uint32_t e = tid; e < nb; e += kChainThreads) {
+            const uint2 r = t.bright_list[e];
+            if ((r.x >> 16) != (uint32_t)frame) continue;
+            const uint32_t x = r.x & 0xFFFFu, y = r.y;
+            if (exact_strong<PixelT, false>(t, fimg, (int)x, (int)y)) {
+                uint8_t* plane = t.bits + (uint64_t)frame * t.plane_frame_stride + (uint64_t)y * t.mpitch;
+                atomicOr(reinterpret_cast<uint32_t*>(plane) + (x >> 5), 1u << (x & 31u));
+                atomicAdd(t.tile_counts + (uint64_t)frame * t.n_tiles + y / (uint32_t)kTileRows, 1u);
+                const uint32_t ob = y * t.occ_spr + (x >> 7);
+                atomicOr(t.occ + (uint64_t)frame * t.occ_frame_words + (ob >> 5), 1u << (ob & 31u));
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            // the last workgroup through with the list empties it for the next batch (the host re-runs a batch whose list overflowed)
+            const uint32_t before_me = atomicAdd(A.fix_done, 1u);
+            if (before_me + 1 == gridDim.x) {
+                if (listed > t.bright_cap) bright_flag = 8u;
+                *t.bright_n = 0;
+                *A.fix_done = 0;
+            }
+        }
+    }
+
     // ---- A: tile offsets ------------------------------------------------------------------------------
     uint32_t total;
     {
@@ -152,7 +189,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
         }
         if (tid == 0) {
             s_toff[n_tiles] = total;
-            if (frame == 0 && sa.zero_word) *sa.zero_word = 0;
+            if (frame == 0 && sa.zero_word && !A.fix_bright) *sa.zero_word = 0;
         }
         if (tid < 8) s_sm[tid] = 0;
         for (int y = tid; y <= a.H; y += kChainThreads) s_row[y] = 0;
@@ -696,7 +733,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
     // ---- counters: device copies for the other consumers of the lists, host copies for ffs_wait() --------------
     __syncthreads();
     if (tid == 0) {
-        uint32_t flags = *a.overflow;   // what the dense stages raised (bright-list overflow, corrupt chunk)
+        uint32_t flags = *a.overflow | bright_flag;   // what the dense stages raised (corrupt chunk; bright-list overflow)
         if (total > a.cap) flags |= 1u;
         if (before > sa.max_comp) flags |= 2u;
         a.num_strong[frame] = total;
