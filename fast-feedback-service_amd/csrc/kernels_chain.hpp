@@ -14,6 +14,8 @@
 // denser frames run the stages on the global arrays), and the accumulators of 512 components at a time do too.
 //
 // Phases (separated by __syncthreads(), which also orders the block's global writes):
+//   B  (only while few batches are in flight, see ffs_api.hip) the bright-window fix-up, k_bright_fix's work, for the
+//      listed pixels of this frame; the last workgroup through with the list empties it
 //   A  exclusive scan of the frame's per-tile counts (the streaming kernel's atomics) -> tile offsets in LDS; the
 //      counts are zeroed for the next batch
 //   E  compaction: each wave takes a contiguous range of tiles; it reads the occupancy bitmap the streaming kernel
