@@ -56,6 +56,7 @@ struct Knobs {
     long long target_waves = 16384;
     int emit_variant = 1, ccl_variant = 2, link_runs = 1, ccl_grid = 32, ccl_cus = 0, direct_recs = 1;
     int sched = 3;             // FFS_SCHED: 1 = sparse chain on a high-priority stream of its own; 2 = also every dense kernel of the context on ONE stream
+    int chain_stop = 0, dummy_us = 0, dummy_wg = 32, dummy_threads = 1024, dummy_lds = 0;   // FFS_CHAIN_STOP, FFS_DUMMY_*: timing experiments
     int chain_first = 2;       // FFS_CHAIN_FIRST = n > 0: the sparse launch also does the bright-window fix-up, and while at most n batches are in flight a streaming kernel waits until the previous batch's sparse launch has started
     int ext_launch = 1;        // FFS_EXT_LAUNCH: the streaming kernel carries its start / stop events (hipExtLaunchKernel)
     int use_occ = 1;           // FFS_OCC: k_frame_chain reads only the plane segments the occupancy bitmap names
@@ -89,6 +90,11 @@ struct Knobs {
         use_occ = env_int("FFS_OCC", 1);
         ext_launch = env_int("FFS_EXT_LAUNCH", 1);
         chain_first = env_int("FFS_CHAIN_FIRST", 2);
+        chain_stop = env_int("FFS_CHAIN_STOP", 0);
+        dummy_us = env_int("FFS_DUMMY_US", 0);
+        dummy_wg = std::max(1, env_int("FFS_DUMMY_WG", 32));
+        dummy_threads = std::max(64, std::min(1024, env_int("FFS_DUMMY_THREADS", 1024)));
+        dummy_lds = std::max(0, std::min(65536, env_int("FFS_DUMMY_LDS", 0)));
         bright_cap = std::max(0, std::min(1 << 20, env_int("FFS_BRIGHT_CAP", 1 << 20)));
     }
 };
@@ -1173,7 +1179,7 @@ dense_done:
         A.h_counts = s->h_counts_dev;
         A.max_batch = (uint32_t)s->max_batch;
         A.rec_stride = s->max_comp;
-        A.stop_after = Knobs::env_int("FFS_CHAIN_STOP", 0);
+        A.stop_after = c->knobs.chain_stop;
         A.t = ta;
         A.fix_bright = fold_fix ? 1 : 0;
         A.fix_done = s->d_tile_counts + tile_counts_bytes(s) / 4 - 2;
@@ -1191,10 +1197,10 @@ dense_done:
         return FFS_OK;
     }
     if (skip & 1) {
-        const int us = Knobs::env_int("FFS_DUMMY_US", 0);
+        const int us = c->knobs.dummy_us;
         if (us > 0)
-            hipLaunchKernelGGL(k_dummy_spin, dim3(Knobs::env_int("FFS_DUMMY_WG", 32)), dim3(Knobs::env_int("FFS_DUMMY_THREADS", 1024)),
-                               (size_t)Knobs::env_int("FFS_DUMMY_LDS", 0), s->st2, (uint32_t)us * 100u, s->d_tile_counts);
+            hipLaunchKernelGGL(k_dummy_spin, dim3(c->knobs.dummy_wg), dim3(c->knobs.dummy_threads),
+                               (size_t)c->knobs.dummy_lds, s->st2, (uint32_t)us * 100u, s->d_tile_counts);
     } else if (emit_variant >= 1 || root_mode) {
         if (c->pixel_bytes == 2)
             hipLaunchKernelGGL(k_emit_list_w<uint16_t>, dim3(c->n_tiles, n), dim3(64), 0, s->st2, ca);
