@@ -11,7 +11,7 @@
 // With a whole frame in one workgroup the round trips can stay on the CU.  A dependent access costs ~1 us at the
 // L2 and ~0.1 us in LDS, so the frame's union-find forest, the per-row list offsets and the list's column numbers
 // (16 bits each: with the row offsets they are the list) live in LDS (frames up to kChainLdsEntries strong pixels;
-// denser frames run the stages on the global arrays), and the accumulators of 512 components at a time do too.
+// denser frames run the stages on the global arrays), and the accumulators of 832 components at a time do too.
 //
 // Phases (separated by __syncthreads(), which also orders the block's global writes):
 //   B  (only while few batches are in flight, see ffs_api.hip) the bright-window fix-up, k_bright_fix's work, for the
@@ -28,7 +28,7 @@
 //   U  union-find: vertical edges + the reference's row-wrap edge (k_union<false>'s edges), all in LDS
 //   then, for frames held in LDS:
 //   P  pixel values (twenty independent loads per thread); every entry finds its root; roots are numbered in list order (= label order, connected_components.cc:91,242)
-//   R  512 components at a time: entries add into LDS accumulators (integer atomics: order-independent), one thread
+//   R  832 components at a time: entries add into LDS accumulators (integer atomics: order-independent), one thread
 //      per component writes its 40-byte record, the records leave as consecutive dwords
 //   and for denser frames: R' accumulators at the root's list index in global memory, F' records chunk by chunk
 //   (the bodies of k_reduce_roots / k_finalize_roots).
@@ -50,7 +50,7 @@ constexpr int kChainSegCap = 512;       // occupied plane segments a wave lists 
 constexpr int kChainQuads = 4;          // rounds (4 words per lane each) per batch of plane loads; three batches are live
 constexpr int kChainLdsEntries = 20480; // strong pixels of a frame whose union-find forest fits LDS
 constexpr int kChainPer = kChainLdsEntries / kChainThreads;   // consecutive entries per thread in phases U / P / R
-constexpr int kChainSlots = 512;        // components accumulated in LDS at a time
+constexpr int kChainSlots = 832;        // components accumulated in LDS at a time
 
 // LDS accumulator of one component: sum I, sum (2x+1) I, sum (2y+1) I, peak = I << 32 | ~k
 struct ChainAcc {
