@@ -1,0 +1,415 @@
+// ffs_context.hip -- contexts, masks, parameters and tuning, streams (see ffs_internal.hpp for the map of the library).
+// The C ABI is declared in include/ffs_hip.h; every entry point there names the reference interface it replaces.
+#include "ffs_internal.hpp"
+#include "kernels_mask.hpp"
+
+static_assert(sizeof(ReflOut) == sizeof(ffs_reflection), "record layout");
+static_assert(offsetof(ReflOut, sum_intensity) == offsetof(ffs_reflection, sum_intensity), "record layout");
+
+thread_local std::string g_create_error;
+
+extern "C" void ffs_default_params(ffs_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->min_count = 2;  // baseline/spotfinder/standalone.cc:17
+    p->nsig_b = 6.0;   // :19
+    p->nsig_s = 3.0;   // :20
+    p->threshold = 0.0;
+    p->max_valid = -1;
+    p->min_spot_size = 3;     // spotfinder/spotfinder.cc:321
+    p->min_spot_size_3d = 3;  // :327
+    p->max_peak_centroid_separation = 2.0f;  // :335
+    p->want_reflections = 1;
+    p->want_strong_list = 0;
+    p->want_strong_mask = 0;
+    p->algorithm = FFS_ALGO_DISPERSION;
+    p->extended_flavour = 0;
+}
+
+extern "C" int ffs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int ffs_device_name(int device, char* buf, size_t buflen) {
+    hipDeviceProp_t prop;
+    if (!buf || buflen == 0) return FFS_ERR_INVALID;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return FFS_ERR_NODEVICE;
+    std::snprintf(buf, buflen, "%s (%s)", prop.name, prop.gcnArchName);
+    return FFS_OK;
+}
+
+extern "C" int ffs_device_total_mem(int device, uint64_t* bytes) {
+    hipDeviceProp_t prop;
+    if (!bytes) return FFS_ERR_INVALID;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return FFS_ERR_NODEVICE;
+    *bytes = prop.totalGlobalMem;
+    return FFS_OK;
+}
+
+extern "C" const char* ffs_last_error(const ffs_ctx* ctx) {
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();  // both are per-thread texts
+}
+
+extern "C" int ffs_ctx_create(int device, uint32_t width, uint32_t height, int pixel_bytes,
+                              uint32_t max_batch, uint32_t max_strong, ffs_ctx** out) {
+    if (!out) return FFS_ERR_INVALID;
+    *out = nullptr;
+    if (width == 0 || height == 0 || (pixel_bytes != 2 && pixel_bytes != 4) || max_batch == 0
+        || width > 10240 || (uint64_t)width * height >= (1ull << 32)) {
+        g_create_error = "ffs_ctx_create: need 0 < width <= 10240, width*height < 2^32, pixel_bytes 2 or 4, max_batch > 0";
+        return FFS_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        g_create_error = "no HIP device visible (libffs_hip.so has no CPU fallback)";
+        return FFS_ERR_NODEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        g_create_error = "ffs_ctx_create: device index out of range";
+        return FFS_ERR_NODEVICE;
+    }
+    ffs_ctx* c = new (std::nothrow) ffs_ctx();
+    if (!c) return FFS_ERR_NOMEM;
+    c->device = device;
+#ifdef FFS_EXPERIMENTS
+    {   // timing experiments: from the environment, in this build only
+        auto env_int = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+        Tuning::Exp& x = c->tune.exp;
+        x.k1_debug = env_int("FFS_EXP_K1_DEBUG", 0);
+        x.chain_skip = env_int("FFS_EXP_CHAIN_SKIP", 0);
+        x.chain_stop = env_int("FFS_EXP_CHAIN_STOP", 0);
+        x.dummy_us = env_int("FFS_EXP_DUMMY_US", 0);
+        x.dummy_wg = std::max(1, env_int("FFS_EXP_DUMMY_WG", 32));
+        x.dummy_threads = std::max(64, std::min(1024, env_int("FFS_EXP_DUMMY_THREADS", 1024)));
+        x.dummy_lds = std::max(0, std::min(65536, env_int("FFS_EXP_DUMMY_LDS", 0)));
+    }
+#endif
+    c->pixel_bytes = pixel_bytes;
+    c->max_batch = max_batch;
+    Layout& L = c->L;
+    L.W = (int)width;
+    L.H = (int)height;
+    L.pitch_px = round_up((int)width, 128);  // byte-mask rows start on 128-byte lines
+    L.pitch = (uint32_t)L.pitch_px * (uint32_t)pixel_bytes;
+    L.mpitch = (uint32_t)L.pitch_px / 8;
+    L.bpitch = (uint32_t)L.pitch_px;
+    L.frame_stride = (uint64_t)L.pitch * height;
+    L.plane_frame_stride = (uint64_t)L.mpitch * height;
+    L.bytes_frame_stride = (uint64_t)L.bpitch * height;
+    if (L.frame_stride >= (1ull << 32)) {
+        g_create_error = "frame larger than 4 GiB";
+        delete c;
+        return FFS_ERR_INVALID;
+    }
+    const uint64_t npx = (uint64_t)width * height;
+    c->cap = max_strong ? max_strong : (uint32_t)std::min<uint64_t>(npx, 1u << 18);
+    c->cap = (uint32_t)std::min<uint64_t>(c->cap, npx);
+    c->max_comp = std::min<uint32_t>(c->cap, 1u << 16);
+    c->n_tiles = ((int)height + kTileRows - 1) / kTileRows;
+    ffs_default_params(&c->params);
+    if (hipSetDevice(device) != hipSuccess) {
+        g_create_error = "hipSetDevice failed";
+        delete c;
+        return FFS_ERR_DEVICE;
+    }
+    hipError_t e = hipMalloc(&c->d_maskbits, L.plane_frame_stride + 256);
+    // one dword per lane group of 16 bytes of pixels: 8 pixels (16-bit) or 4 pixels (32-bit)
+    if (e == hipSuccess) e = hipMalloc(&c->d_ginfo, (size_t)(L.H + kInfoExtraRows) * ((size_t)L.pitch_px * pixel_bytes / 4) + 256);
+    if (e == hipSuccess) e = hipMalloc(&c->d_mmap, (size_t)L.H * L.pitch_px + 256);
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipMalloc(mask): ") + hipGetErrorString(e);
+        ffs_ctx_destroy(c);
+        return FFS_ERR_NOMEM;
+    }
+    *out = c;
+    int rc = ffs_ctx_set_mask(c, nullptr);
+    if (rc != FFS_OK) {
+        g_create_error = c->err;
+        ffs_ctx_destroy(c);
+        *out = nullptr;
+        return rc;
+    }
+    return FFS_OK;
+}
+
+extern "C" void ffs_ctx_destroy(ffs_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (auto* st : c->stack_pool) stack3d_free(st);
+    c->stack_pool.clear();
+    if (c->d_maskbits) (void)hipFree(c->d_maskbits);
+    if (c->d_ginfo) (void)hipFree(c->d_ginfo);
+    if (c->d_mmap) (void)hipFree(c->d_mmap);
+    if (c->dense_st) (void)hipStreamDestroy(c->dense_st);
+    if (c->up_st) (void)hipStreamDestroy(c->up_st);
+    for (auto st : c->sparse_st) if (st) (void)hipStreamDestroy(st);
+    for (auto e : c->chain_ev) if (e) (void)hipEventDestroy(e);
+    delete c;
+}
+
+// The tables of the one-kernel threshold path depend on the mask alone: rebuilt whenever it changes.
+static int rebuild_mask_tables(ffs_ctx* c) {
+    const Layout& L = c->L;
+    const uint32_t gpitch = (uint32_t)L.pitch_px * (uint32_t)c->pixel_bytes / 4;
+    HIP_TRY(c, hipMemset(c->d_ginfo, 0, (size_t)(L.H + kInfoExtraRows) * gpitch));
+    const int groups = L.pitch_px / (c->pixel_bytes == 2 ? 8 : 4);
+    (void)hipGetLastError();  // drop any stale error state: the check below is for this launch
+    if (c->pixel_bytes == 2)
+        hipLaunchKernelGGL(k_build_maps, dim3((groups + 255) / 256, L.H), dim3(256), 0, 0, c->d_maskbits, L.mpitch, L.W, L.H,
+                           L.pitch_px, c->d_mmap, c->d_ginfo, gpitch);
+    else
+        hipLaunchKernelGGL(k_build_maps4, dim3((groups + 255) / 256, L.H), dim3(256), 0, 0, c->d_maskbits, L.mpitch, L.W, L.H,
+                           L.pitch_px, c->d_mmap, c->d_ginfo, gpitch);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipDeviceSynchronize());
+    return FFS_OK;
+}
+
+static int ffs_ctx_set_mask_impl(ffs_ctx* c, const uint8_t* host_mask) {
+    if (!c) return FFS_ERR_INVALID;
+    const Layout& L = c->L;
+    std::vector<uint8_t> bits(L.plane_frame_stride, 0);
+    for (int y = 0; y < L.H; ++y) {
+        uint8_t* row = bits.data() + (size_t)y * L.mpitch;
+        if (host_mask) {
+            const uint8_t* m = host_mask + (size_t)y * L.W;
+            for (int x = 0; x < L.W; ++x)
+                if (m[x]) row[x >> 3] |= (uint8_t)(1u << (x & 7));
+        } else {
+            for (int x = 0; x < L.W; ++x) row[x >> 3] |= (uint8_t)(1u << (x & 7));
+        }
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpy(c->d_maskbits, bits.data(), bits.size(), hipMemcpyHostToDevice));
+    return rebuild_mask_tables(c);
+}
+
+static int ffs_ctx_get_mask_impl(ffs_ctx* c, uint8_t* host_mask) {
+    if (!c || !host_mask) return FFS_ERR_INVALID;
+    const Layout& L = c->L;
+    std::vector<uint8_t> bits(L.plane_frame_stride);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpy(bits.data(), c->d_maskbits, bits.size(), hipMemcpyDeviceToHost));
+    for (int y = 0; y < L.H; ++y)
+        for (int x = 0; x < L.W; ++x)
+            host_mask[(size_t)y * L.W + x] = (bits[(size_t)y * L.mpitch + (x >> 3)] >> (x & 7)) & 1;
+    return FFS_OK;
+}
+
+extern "C" int ffs_ctx_apply_resolution_mask(ffs_ctx* c, float wavelength, float distance_m,
+                                             float bcx, float bcy, float psx, float psy, float dmin,
+                                             float dmax) {
+    if (!c) return FFS_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const Layout& L = c->L;
+    dim3 block(64, 1), grid((L.mpitch + 63) / 64, L.H);
+    hipLaunchKernelGGL(k_resolution_mask, grid, block, 0, 0, c->d_maskbits, L.mpitch, L.W, L.H,
+                       wavelength, distance_m, bcx, bcy, psx, psy, dmin, dmax);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipDeviceSynchronize());
+    return rebuild_mask_tables(c);
+}
+
+extern "C" int ffs_ctx_set_params(ffs_ctx* c, const ffs_params* p) {
+    if (!c || !p) return FFS_ERR_INVALID;
+    if (p->min_count < 2 || p->min_count > 49 || p->nsig_b < 0 || p->nsig_s < 0 || p->threshold < 0) {
+        c->err = "ffs_ctx_set_params: need 2 <= min_count <= 49, nsig_b >= 0, nsig_s >= 0, threshold >= 0";
+        return FFS_ERR_INVALID;  // the asserts of standalone.cc:52-63
+    }
+    if ((p->algorithm != FFS_ALGO_DISPERSION && p->algorithm != FFS_ALGO_DISPERSION_EXTENDED)
+        || (p->extended_flavour != 0 && p->extended_flavour != 1)) {
+        c->err = "ffs_ctx_set_params: unknown algorithm / extended_flavour";
+        return FFS_ERR_INVALID;
+    }
+    c->params = *p;
+    return FFS_OK;
+}
+
+extern "C" int ffs_ctx_device_layout(const ffs_ctx* c, size_t* pitch, size_t* fstride) {
+    if (!c) return FFS_ERR_INVALID;
+    if (pitch) *pitch = c->L.pitch;
+    if (fstride) *fstride = c->L.frame_stride;
+    return FFS_OK;
+}
+
+// ---- tuning (ffs_internal.hpp: Tuning) -------------------------------------------------------------------------
+extern "C" int ffs_ctx_set_tuning(ffs_ctx* c, const char* key, long long value) {
+    if (!c || !key) return FFS_ERR_INVALID;
+    Tuning& t = c->tune;
+    const std::string k = key;
+    auto in = [&](long long lo, long long hi) { return value >= lo && value <= hi; };
+    bool ok = true;
+    if (k == "threshold_path") { if ((ok = in(0, 1))) t.threshold_path = (int)value; }
+    else if (k == "ext_first_pass") { if ((ok = value == 0 || value == 2)) t.ext_first_pass = (int)value; }
+    else if (k == "sparse_stage") { if ((ok = in(1, 2))) t.sparse_stage = (int)value; }
+    else if (k == "sched") { if ((ok = (value == 0 || value == 3) && c->n_streams_made == 0)) t.sched = (int)value; }
+    else if (k == "chain_first") { if ((ok = in(0, 64))) t.chain_first = (int)value; }
+    else if (k == "bright_cap") { if ((ok = in(0, kBrightCap))) t.bright_cap = (int)value; }
+    else if (k == "frames_per_group") { if ((ok = in(1, 1 << 30))) t.frames_per_group = (int)value; }
+    else if (k == "target_waves") { if ((ok = in(1, 1 << 24))) t.target_waves = value; }
+    else if (k == "dense_mask") { if ((ok = in(0, 1))) t.dense_mask = (int)value; }
+    else if (k == "occupancy_bitmap") { if ((ok = in(0, 1))) t.occupancy_bitmap = (int)value; }
+    else if (k == "direct_records") { if ((ok = in(0, 1) && c->n_streams_made == 0)) t.direct_records = (int)value; }
+    else if (k == "decode_in_dense_stream") { if ((ok = in(0, 1))) t.decode_in_dense_stream = (int)value; }
+    else {
+        c->err = "ffs_ctx_set_tuning: unknown key '" + k + "'";
+        return FFS_ERR_INVALID;
+    }
+    if (!ok) {
+        c->err = "ffs_ctx_set_tuning: value out of range for '" + k + "' (sched / direct_records: before the first stream is created)";
+        return FFS_ERR_INVALID;
+    }
+    return FFS_OK;
+}
+
+// ---- streams ---------------------------------------------------------------------------------------
+
+extern "C" void ffs_stream_destroy(ffs_stream* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    if (s->job.joinable()) s->job.join();
+    mark_idle(s);   // (a stream may be closed with its batch still in flight)
+    if (s->big) ffs_stream_destroy(s->big);
+    if (s->st_up && s->st_up != s->st) (void)hipStreamSynchronize(s->st_up);
+    if (s->st) (void)hipStreamSynchronize(s->st);
+    if (s->st2 && s->st2 != s->st) { (void)hipStreamSynchronize(s->st2); if (!s->st2_shared) (void)hipStreamDestroy(s->st2); }
+    // (d_n_comp, d_summary and d_overflow live inside the d_num_strong allocation)
+    if (s->h_pack_tab) (void)hipHostFree(s->h_pack_tab);
+    void* dev[] = {s->d_occ, s->d_pack_k, s->d_pack_i, s->d_pack_tab, s->d_acc2, s->d_chunk_roots, s->d_bright, s->d_comp, s->d_tab, s->d_dplane,
+                   s->d_eplane, s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_num_strong, s->d_list_k, s->d_list_i,
+                   s->d_parent, s->d_recs};
+    for (void* p : dev)
+        if (p) (void)hipFree(p);
+    void* host[] = {s->h_tab, s->h_img, s->h_counts, s->h_recs, s->h_list_k, s->h_list_i, s->h_mask};
+    for (void* p : host)
+        if (p) (void)hipHostFree(p);
+    for (auto& e : s->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (s->ev_pack) (void)hipEventDestroy(s->ev_pack);
+    if (s->ev_sent) (void)hipEventDestroy(s->ev_sent);
+    // (the start events of its sparse launches belong to the context: a thread about to wait on one is safe)
+    if (s->st && !s->st_shared) (void)hipStreamDestroy(s->st);
+    delete s;
+}
+
+extern "C" int ffs_stream_create(ffs_ctx* c, ffs_stream** out) {
+    if (!c || !out) return FFS_ERR_INVALID;
+    return stream_create_sized(c, c->max_batch, c->cap, c->max_comp, out);
+}
+
+int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uint32_t max_comp, ffs_stream** out) {
+    *out = nullptr;
+    HIP_TRY(c, hipSetDevice(c->device));
+    ffs_stream* s = new (std::nothrow) ffs_stream();
+    if (!s) return FFS_ERR_NOMEM;
+    s->ctx = c;
+    s->max_batch = max_batch;
+    s->cap = cap;
+    s->max_comp = max_comp;
+    const Layout& L = c->L;
+    const size_t B = s->max_batch;
+#define STREAM_TRY(expr)                                                        \
+    do {                                                                        \
+        hipError_t e_ = (expr);                                                 \
+        if (e_ != hipSuccess) {                                                 \
+            c->err = std::string(#expr) + ": " + hipGetErrorString(e_);         \
+            ffs_stream_destroy(s);                                              \
+            return e_ == hipErrorOutOfMemory ? FFS_ERR_NOMEM : FFS_ERR_DEVICE;  \
+        }                                                                       \
+    } while (0)
+    // HIP streams.  The sparse stage (compaction, union-find, reductions) is latency-bound and keeps a
+    // few CUs busy; the streaming kernel wants the whole machine.  sched 3 (default): every streaming kernel of the context
+    // goes through ONE stream (first in, first out: nothing of another batch behind which it could queue), the sparse work
+    // of a batch is one launch on one of two shared high-priority streams, uploads and decoding have a stream of their own
+    // -- four hardware queues in all.  sched 0: one HIP stream per ffs_stream for everything.
+    // (Measured and dropped: CU masks for the two stages, a stream per batch for the sparse work, two dense streams.)
+    {
+        std::lock_guard<std::mutex> lock(c->stream_mu);
+        if (c->tune.sched >= 3) {
+            int lo = 0, hi = 0;
+            STREAM_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (least, greatest)
+            if (!c->dense_st) STREAM_TRY(hipStreamCreateWithPriority(&c->dense_st, hipStreamNonBlocking, (lo + hi) / 2));
+            s->st = c->dense_st;
+            s->st_shared = true;
+            if (!c->up_st) STREAM_TRY(hipStreamCreateWithFlags(&c->up_st, hipStreamNonBlocking));
+            s->st_up = c->up_st;
+            const int j = c->n_streams_made & 1;
+            if (!c->sparse_st[j]) STREAM_TRY(hipStreamCreateWithPriority(&c->sparse_st[j], hipStreamNonBlocking, hi));
+            s->st2 = c->sparse_st[j];
+            s->st2_shared = true;
+        } else {
+            STREAM_TRY(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+            s->st2 = s->st;
+        }
+        ++c->n_streams_made;
+        if (!c->chain_ev[0])
+            for (auto& e : c->chain_ev) STREAM_TRY(hipEventCreate(&e));
+        if (!c->chain_ok) c->chain_ok = chain_prepare_device();   // (else: the four grid-wide kernels)
+    }
+    if (!s->st_up) s->st_up = s->st;
+    for (auto& e : s->ev) STREAM_TRY(hipEventCreate(&e));
+    STREAM_TRY(dmalloc(&s->d_img, B * L.frame_stride));
+    STREAM_TRY(dmalloc(&s->d_bits, B * L.plane_frame_stride));
+    STREAM_TRY(dmalloc(&s->d_sbytes, B * L.bytes_frame_stride));
+    STREAM_TRY(dmalloc(&s->d_tile_counts, tile_counts_bytes(s)));
+    STREAM_TRY(dmalloc(&s->d_occ, B * (size_t)occ_frame_words(L) * 4));
+    STREAM_TRY(dmalloc(&s->d_bright, (size_t)kBrightCap * sizeof(uint2)));
+
+    // per-frame counters in the layout of h_counts, so that one copy brings them all back:
+    // [B] strong pixels | [B] components | [B][8] summary | [1] overflow / error flag
+    STREAM_TRY(dmalloc(&s->d_num_strong, (B * 10 + 1) * 4));
+    s->d_n_comp = s->d_num_strong + B;
+    s->d_summary = s->d_num_strong + 2 * B;
+    s->d_overflow = s->d_num_strong + 10 * B;
+    STREAM_TRY(dmalloc(&s->d_row_off, B * (size_t)(L.H + 1) * 4));
+    STREAM_TRY(dmalloc(&s->d_list_k, B * (size_t)s->cap * 4));
+    STREAM_TRY(dmalloc(&s->d_list_i, B * (size_t)s->cap * 4));
+    STREAM_TRY(dmalloc(&s->d_parent, B * (size_t)s->cap * 4));
+    STREAM_TRY(dmalloc(&s->d_acc2, B * (size_t)s->cap * sizeof(CompAcc2)));
+    STREAM_TRY(dmalloc(&s->d_chunk_roots, B * (size_t)(s->cap / 512 + 1) * 4));
+    STREAM_TRY(dmalloc(&s->d_recs, B * (size_t)s->max_comp * sizeof(ReflOut)));
+    // raw frames, or bitshuffle-LZ4 chunks (which can exceed the raw size by < 1 % when incompressible)
+    s->h_img_bytes = B * ((size_t)L.W * L.H * c->pixel_bytes + (size_t)L.W * L.H * c->pixel_bytes / 128 + 4096);
+    STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_img), s->h_img_bytes, hipHostMallocDefault));
+    STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), (B * 11 + 1) * 4, hipHostMallocDefault));  // (+ [B] per-frame flags, k_frame_chain)
+    std::memset(s->h_counts, 0, (B * 11 + 1) * 4);
+    STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_recs), B * (size_t)s->max_comp * sizeof(ReflOut),
+                             hipHostMallocDefault));
+    // The sparse kernels write the (few MB of) records and the counters straight into these pinned, device-visible
+    // buffers: no copy follows them.  Tuning "direct_records" = 0 keeps the device buffers + copies (A/B).
+    s->direct_recs = c->tune.direct_records != 0;
+    if (s->direct_recs
+        && hipHostGetDevicePointer(reinterpret_cast<void**>(&s->h_recs_dev), s->h_recs, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        s->direct_recs = false;
+    }
+    if (s->direct_recs && hipHostGetDevicePointer(reinterpret_cast<void**>(&s->h_counts_dev), s->h_counts, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        s->h_counts_dev = nullptr;
+    }
+    STREAM_TRY(hipMemsetAsync(s->d_overflow, 0, 4, s->st));
+    STREAM_TRY(hipMemsetAsync(s->d_occ, 0, B * (size_t)occ_frame_words(L) * 4, s->st));
+    // bits beyond the image width (x >= W up to the row pitch) are never written by the threshold kernels and must read 0
+    STREAM_TRY(hipMemsetAsync(s->d_bits, 0, B * L.plane_frame_stride, s->st));
+    STREAM_TRY(hipStreamSynchronize(s->st));
+#undef STREAM_TRY
+    *out = s;
+    return FFS_OK;
+}
+
+extern "C" int ffs_stream_host_buffer(ffs_stream* s, void** ptr, size_t* bytes) {
+    if (!s) return FFS_ERR_INVALID;
+    if (ptr) *ptr = s->h_img;
+    if (bytes) *bytes = s->h_img_bytes;
+    return FFS_OK;
+}
+
+// ---- guarded entry points (the mask conversions grow std::vectors) ---------------------------------------------
+extern "C" int ffs_ctx_set_mask(ffs_ctx* c, const uint8_t* host_mask) {
+    return guarded(c, [&] { return ffs_ctx_set_mask_impl(c, host_mask); });
+}
+extern "C" int ffs_ctx_get_mask(ffs_ctx* c, uint8_t* host_mask) {
+    return guarded(c, [&] { return ffs_ctx_get_mask_impl(c, host_mask); });
+}

@@ -3,6 +3,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Timing experiments (phases switched off, kernels stopped half way: results are wrong when used) exist only in builds
+// with -DFFS_EXPERIMENTS (make experiments -> libffs_hip_exp.so, for tools/); the product library has none of them.
+#ifdef FFS_EXPERIMENTS
+#define FFS_DBG(args, bit) (((args).dbg & (bit)) != 0)
+#define FFS_STOP_AFTER(A, phase) if ((A).stop_after == (phase)) return
+#else
+#define FFS_DBG(args, bit) false
+#define FFS_STOP_AFTER(A, phase) do {} while (0)
+#endif
+
 namespace ffsamd {
 
 // ---- frame layout in HBM ---------------------------------------------------------------------
@@ -24,13 +34,11 @@ struct Layout {
     uint64_t bytes_frame_stride; // bytes between frames of the byte mask = H * bpitch
 };
 
-// ---- candidate kernel geometry -----------------------------------------------------------------
-// One wave64 marches down a column strip of 64 lanes x 8 px = 512 px.  Lanes 0 and 63 are halo
-// (their windows are incomplete), lanes 1..62 own 496 px of output.  Strip s covers
-// x in [496 s - 8, 496 s + 504).
-constexpr int kLanePx = 8;
-constexpr int kStripOwnedPx = 62 * kLanePx;  // 496
-constexpr int kStripStartOffset = -kLanePx;  // strip 0 starts at x = -8 (lane 0 inactive)
+// ---- streaming threshold kernels: geometry (kernels_stream.hpp) ---------------------------------------
+// One wave64 marches down a column strip; a lane holds 16 bytes of a pixel row (8 pixels of 16 bits, 4 of 32).
+// Lanes 0 and 63 are halo (their windows are incomplete), lanes 1..62 own output.
+constexpr int kSOwned = 62;
+constexpr int kInfoExtraRows = 3;    // ginfo row y carries the mask bits of row y and the window counts of row y - 3
 
 // Exact-stage tiles: one 256-thread workgroup per 8 rows.
 constexpr int kTileRows = 8;
@@ -55,13 +63,14 @@ struct ThresholdArgs {
     double nsig_b, nsig_s, threshold;
     double nsig_b2, nsig_s2;   // squares (float64), for the square-root-free form of the predicate
     long long max_valid;       // < 0: no test
-    int variant;               // candidate kernel variant: 0 = per-pixel test, 1 = group screen + LDS queue
+    int bright_to_plane;       // streaming kernels: 0 = bright windows go onto bright_list (k_bright_fix decides them);
+                               // 1 = they are marked in the plane as candidates and the exact kernel filters the plane
     // extended dispersion (kernels_extended.hpp)
     uint8_t* dplane;           // first-pass "not background" bit planes [n][H][mpitch]
     uint8_t* eplane;           // eroded signal-region bit planes [n][H][mpitch]
     int ext_strips, ext_band_rows, ext_bands;
     int ext_flavour;           // 0 = baseline.cpp rules, 1 = device-kernel rules
-    int ext_variant;           // first pass, 16-bit pixels: 1 = candidate kernel + exact stage, 0 = k_ext_first
+    int ext_variant;           // first pass, 16-bit pixels: 2 = streaming kernel (k_stream_u16<true>), 0 = k_ext_first
     // one-kernel threshold for 16-bit pixels (kernels_stream.hpp)
     const uint8_t* ginfo;      // [H + 3][gpitch] one dword per 8-pixel group: mask bits | min count << 8 | max count << 16
     const uint8_t* mmap;       // [H][pitch_px] 7x7 window count of every pixel
@@ -80,7 +89,7 @@ struct ThresholdArgs {
     uint32_t occ_frame_words;  // words per frame = ceil(H * occ_spr / 32)
     uint32_t occ_spr;          // segments per plane row = mpitch / 16
     int dense_mask;            // the streaming kernels zero-fill the byte mask (somebody wants it); else they leave it alone
-    int dbg;                   // FFS_K1_DEBUG: timing experiments only (results are wrong when set)
+    int dbg;                   // timing experiments (-DFFS_EXPERIMENTS builds only; results are wrong when set)
 };
 
 // ---- strong-pixel lists and connected components -------------------------------------------------
@@ -158,7 +167,7 @@ struct SegArgs {
     const uint32_t* list_k;   // per segment: ascending (z, k)
     const uint32_t* list_i;
     uint32_t* parent;
-    uint32_t* comp_id;
+    uint32_t* comp_id;        // 3D only: component number of each root entry
     const uint32_t* seg_n;    // [n_seg] entries per segment
     uint64_t seg_stride;      // entries between segment starts
     uint32_t* n_comp;         // [n_seg]
@@ -167,8 +176,6 @@ struct SegArgs {
     uint32_t* overflow;
     uint32_t W, H;
     const uint32_t* row_off;  // 2D only: [n_seg][H+1] per-row list offsets (may be null)
-    uint32_t* part_roots;     // 2D only: [n_seg][kLabelParts] roots per part of the list (k_count_roots)
-    int runs_linked;          // 2D only: k_link_runs ran, k_union does the vertical edges only
     // 3D only
     const uint32_t* slice_begin;  // [n_slices + 1] entry offsets of each slice inside the segment
     int n_slices;
@@ -189,6 +196,14 @@ struct SegArgs {
     uint32_t* zero_word;      // one more word to clear, or null
 };
 
+
+// One slice of the 3D stack's copy tables (kernels_stack3d.hpp)
+struct StackSlice {
+    uint32_t src;   // offset in the arrival buffers (k_stack_gather) / in the stream's list of that frame (k_stack_append)
+    uint32_t dst;   // offset in the destination buffers
+    uint32_t n;     // entries
+    uint32_t z;     // k_stack_gather: position of the slice in the stack
+};
 
 // Matches ffs_reflection in include/ffs_hip.h
 struct ReflOut {

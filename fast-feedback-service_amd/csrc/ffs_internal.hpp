@@ -1,0 +1,262 @@
+// ffs_internal.hpp -- what the translation units of libffs_hip.so share: the structs behind the opaque handles of
+// include/ffs_hip.h, error plumbing, and the few functions one unit calls in another.  Host side only; the kernels
+// live in kernels_*.hpp, each included by exactly one unit:
+//   ffs_context.hip  contexts, masks (kernels_mask.hpp), tuning, streams
+//   ffs_submit.hip   launch geometry, the launches of a batch (threshold -> sparse stage), submit entry points,
+//                    compressed input (kernels_stream / threshold / extended / ccl / chain / decode)
+//   ffs_wait.hip     ffs_wait: overflow re-runs, result assembly, result accessors
+//   ffs_stack3d.hip  rotation sweeps: the device-resident 3D stack and the exchange between GPUs (kernels_stack3d)
+//   ffs_bench.hip    measurement entry points (kernel timings, memory ceiling, native pipeline loop, sqrt self-test)
+// No exception leaves the library (guarded()).
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "ffs_hip.h"
+#include "ffs_device.h"
+
+using namespace ffsamd;
+
+// ---- errors ---------------------------------------------------------------------------------------------------
+extern thread_local std::string g_create_error;   // ffs_last_error(NULL): failures before a context exists
+
+// Error text is kept per calling thread (several worker threads drive their own streams of one
+// context; a shared std::string would be a data race exactly when things go wrong).  `ctx->err = ...`
+// and `ctx->err.c_str()` keep reading naturally at the call sites.
+struct ThreadError {
+    static std::string& text() {
+        static thread_local std::string t;
+        return t;
+    }
+    const ThreadError& operator=(const std::string& m) const { text() = m; return *this; }
+    const ThreadError& operator=(const char* m) const { text() = m; return *this; }
+    const char* c_str() const { return text().c_str(); }
+    operator std::string() const { return text(); }
+};
+
+// ---- tuning ---------------------------------------------------------------------------------------------------
+// Every setting here selects between paths that give the SAME results (A/B partners, fall-backs, capacities that
+// tests shrink); they are set per context through ffs_ctx_set_tuning(), never through the environment.  The timing
+// experiments that break results exist only in -DFFS_EXPERIMENTS builds (`exp`, read from FFS_EXP_* there).
+struct Tuning {
+    int threshold_path = 0;     // 0: bright windows -> list -> k_bright_fix; 1: bright windows -> plane -> k_exact (also the
+                                //    fall-back when the list overflows)
+    int ext_first_pass = 2;     // extended algorithm, 16-bit pixels: 2 = streaming kernel, 0 = k_ext_first
+    int sparse_stage = 2;       // 2 = one launch per batch, a workgroup per frame (k_frame_chain); 1 = four grid-wide kernels
+    int sched = 3;              // 3 = the context's streams share one dense, two sparse and one upload HIP stream; 0 = one HIP stream per ffs_stream
+    int chain_first = 2;        // while at most n batches are in flight the sparse launch does the bright fix-up and the next
+                                //    streaming kernel waits for its start; 0 = never
+    int bright_cap = 1 << 20;   // entries of the bright-window list actually used
+    int frames_per_group = 1 << 30;   // frames side by side in one super row of the streaming kernels (cap)
+    long long target_waves = 16384;   // waves a streaming launch aims for
+    int dense_mask = 0;         // 1: always produce the dense byte mask
+    int occupancy_bitmap = 1;   // k_frame_chain reads only the plane segments the occupancy bitmap names
+    int direct_records = 1;     // records and counters are written straight into pinned host memory
+    int decode_in_dense_stream = 1;   // the decode kernel runs in the dense kernels' stream (0: in the upload stream)
+    int ccl_grid = 32;          // workgroups per frame of the grid-wide sparse kernels
+#ifdef FFS_EXPERIMENTS
+    struct Exp {
+        int k1_debug = 0, chain_skip = 0, chain_stop = 0, dummy_us = 0, dummy_wg = 32, dummy_threads = 1024, dummy_lds = 0;
+    } exp;
+#endif
+};
+
+struct ffs_stack3d;
+
+struct ffs_ctx {
+    int device = 0;
+    Tuning tune;
+    Layout L{};
+    int pixel_bytes = 2;
+    uint32_t max_batch = 1;
+    uint32_t cap = 0;       // strong pixels per frame
+    uint32_t max_comp = 0;  // components per frame
+    int n_tiles = 0;
+    ffs_params params{};
+    uint8_t* d_maskbits = nullptr;
+    uint8_t* d_ginfo = nullptr;  // per-group mask bits + window-count bounds (kernels_stream.hpp)
+    uint8_t* d_mmap = nullptr;   // per-pixel window counts
+    hipStream_t dense_st = nullptr;  // sched 3: the one stream of the dense kernels
+    hipStream_t up_st = nullptr;     // ... and the one stream of uploads and decoding
+    hipStream_t sparse_st[2] = {nullptr, nullptr};  // ... the sparse launches of the context's streams, alternating
+    int n_streams_made = 0;
+    std::mutex stream_mu;            // guards the lazy creation of the shared streams, the stack pool and the event ring
+    std::vector<ffs_stack3d*> stack_pool;   // destroyed 3D stacks kept with their buffers for the next sweep (stream_mu)
+    std::atomic<int> inflight{0};    // batches between submit and wait, over all ffs_streams of the context
+    // Start events of the sparse launches (they ride on the dispatch): the next streaming kernel lets the newest one get
+    // its CUs first.  The events belong to the CONTEXT (created with the first stream, destroyed with the context), so a
+    // thread may wait on one while another thread destroys the ffs_stream that recorded it.
+    static constexpr int kChainEvents = 16;
+    hipEvent_t chain_ev[kChainEvents] = {};
+    std::atomic<uint32_t> chain_ev_next{0};     // slots handed out so far
+    std::atomic<int> chain_ev_newest{-1};       // slot of the newest recorded start, -1: none yet
+    bool chain_ok = false;           // k_frame_chain may use its dynamic LDS on this device
+    ThreadError err;  // the calling thread's most recent error on any context
+};
+
+struct OverflowFrame;
+
+constexpr uint32_t kBrightCap = 1u << 20;  // entries of the bright-window list per batch (8 MB)
+
+struct ffs_stream {
+    ffs_ctx* ctx = nullptr;
+    uint32_t max_batch = 1;   // frames per submit
+    uint32_t cap = 0;         // strong pixels per frame the lists hold
+    uint32_t max_comp = 0;    // components per frame the record buffers hold
+    ffs_stream* big = nullptr;               // one-frame stream with room for frames that exceed cap / max_comp
+    std::vector<OverflowFrame> ovf;          // such frames of the last batch, re-run on `big`
+    int force_path = -1;                     // >= 0: threshold path of the next enqueue (bright-list overflow -> 1)
+    uint32_t *d_pack_k = nullptr, *d_pack_i = nullptr;  // a batch's lists packed end to end for another device's 3D stack
+    StackSlice *d_pack_tab = nullptr, *h_pack_tab = nullptr;
+    hipEvent_t ev_pack = nullptr;            // the packed lists are ready on the source device
+    hipEvent_t ev_sent = nullptr;            // ... and have been copied out of the pack buffers (an event of device ev_sent_dev, the stack's)
+    int ev_sent_dev = -1;
+    bool sent_pending = false;
+    hipStream_t st = nullptr;    // threshold kernels (+ H2D)
+    hipStream_t st_up = nullptr; // uploads + decode; == st unless the dense kernels of the context share one stream
+    bool st2_shared = false;
+    bool st_shared = false;      // st is the context's dense stream (not ours to destroy)
+    hipStream_t st2 = nullptr;   // compaction + connected components + D2H; == st unless the context has sparse streams
+    hipEvent_t ev[7] = {};   // [6]: the compressed chunks and their block table are on the device
+    // device
+    uint8_t* d_img = nullptr;
+    uint8_t* d_bits = nullptr;
+    uint8_t* d_sbytes = nullptr;
+    uint8_t *d_dplane = nullptr, *d_eplane = nullptr;  // extended algorithm only (allocated on first use)
+    uint8_t* d_comp = nullptr;                         // compressed chunks (allocated on first use)
+    uint2 *d_tab = nullptr, *h_tab = nullptr;          // per-block (offset, length) tables
+    uint32_t dec_blocks = 0, dec_last = 0, dec_tail = 0, dec_block_elems = 0;
+    // Without direct records: copied back speculatively with the counts (one wait instead of two): room for the most
+    // records per frame seen so far on this stream, +25 %; ffs_wait fetches the rest if a batch exceeds it.
+    uint32_t spec_recs_per_frame = 256;
+    uint64_t spec_recs_copied = 0;
+    std::thread job;          // ffs_submit_compressed's helper (block index + launches); joined by ffs_wait
+    int job_rc = 0;
+    std::string job_err;
+    uint32_t *d_tile_counts = nullptr, *d_num_strong = nullptr, *d_row_off = nullptr;
+    uint2* d_bright = nullptr;  // pixels the streaming kernels hand to k_bright_fix; their count sits behind the tile counts
+    uint32_t *d_list_k = nullptr, *d_list_i = nullptr, *d_parent = nullptr;
+    uint32_t *d_n_comp = nullptr, *d_overflow = nullptr, *d_summary = nullptr;
+    CompAcc2* d_acc2 = nullptr;          // accumulators at the root's list index
+    uint32_t* d_chunk_roots = nullptr;
+    ReflOut* d_recs = nullptr;
+    // pinned host
+    uint8_t* h_img = nullptr;
+    size_t h_img_bytes = 0;
+    uint32_t* h_counts = nullptr;  // [max_batch] num_strong | [max_batch] n_comp | [max_batch*8] summary | [1] overflow | [max_batch] per-frame flags
+    ReflOut* h_recs = nullptr;
+    uint32_t* d_occ = nullptr;     // [max_batch][occ_frame_words] occupancy of the strong plane (one bit per 16-byte segment)
+    uint32_t* h_counts_dev = nullptr;  // device-side address of h_counts (k_frame_chain writes the counters itself)
+    bool ev1_pending = false;      // ev[1] (start of the threshold stage) has not been recorded yet for this batch
+    bool ev3_is_ev4 = false;       // one event behind the sparse launch (k_frame_chain leaves nothing to copy)
+    bool dev_input = false;        // this batch's frames were on the device already (ffs_submit_device): no upload, no ev[0]
+    bool dense_valid = false;      // the byte masks of the last batch were produced
+    bool chain_mode = false;       // this batch went through k_frame_chain: records at frame * max_comp, flags per frame
+    ReflOut* h_recs_dev = nullptr;  // device-side address of h_recs when the records are written straight to the host
+    bool direct_recs = false;
+    bool bits_cleared = false;  // the last batch's compaction zeroed the strong plane again (the streaming kernels' invariant)
+    bool bits_dirty = false;    // the strong plane may hold bits: the streaming kernels need it zeroed first
+    bool counts_dirty = true;   // the per-tile counts (+ bright-list count) may be non-zero: the streaming kernels add into them
+    bool occ_dirty = false;     // the occupancy bitmap may hold bits nobody will consume
+    uint32_t *h_list_k = nullptr, *h_list_i = nullptr;
+    uint8_t* h_mask = nullptr;
+    // state of the batch in flight
+    bool busy = false;
+    uint32_t n_frames = 0;
+    int64_t first_id = 0;
+    const void* cur_img = nullptr;
+    size_t cur_pitch = 0, cur_fstride = 0;
+    ffs_params batch_params{};
+    float timings[5] = {0, 0, 0, 0, 0};
+    // results
+    std::vector<ffs_frame_result> results;
+    std::vector<ffs_box> boxes;
+    std::vector<ffs_reflection> refls;
+};
+
+// Results of a frame that did not fit the stream's lists, from its re-run on the one-frame stream
+struct OverflowFrame {
+    uint32_t frame = 0;
+    ffs_frame_result res{};
+    std::vector<ffs_box> boxes;
+    std::vector<ffs_reflection> refls;
+    std::vector<uint32_t> k, inten;
+};
+
+// ---- no exception crosses the C ABI -----------------------------------------------------------------------
+// The entry points that grow std::vectors (results, staging tables, masks) run inside a catch-all: an
+// allocation failure or a length error becomes FFS_ERR_NOMEM with its text in ffs_last_error, instead of
+// std::terminate -> abort() in the caller's process.
+template <typename F>
+static int guarded(ffs_ctx* c, F&& body) {
+    try {
+        return body();
+    } catch (const std::exception& e) {
+        if (c) c->err = std::string("exception inside libffs_hip: ") + e.what();
+        else g_create_error = std::string("exception inside libffs_hip: ") + e.what();
+        return FFS_ERR_NOMEM;
+    } catch (...) {
+        if (c) c->err = "unknown exception inside libffs_hip";
+        return FFS_ERR_NOMEM;
+    }
+}
+
+#define HIP_TRY(ctx, expr)                                                              \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);             \
+            return e_ == hipErrorOutOfMemory ? FFS_ERR_NOMEM : FFS_ERR_DEVICE;          \
+        }                                                                               \
+    } while (0)
+
+// ---- small helpers ------------------------------------------------------------------------------------------
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline uint32_t occ_frame_words(const Layout& L) { return (uint32_t)(((uint64_t)L.H * (L.mpitch / 16) + 31) / 32 + 2); }  // (+2: the chain reads a word ahead)
+// per-tile counts | ... | [last - 1] workgroups of k_frame_chain through with the bright list | [last] entries of the bright list;
+// a multiple of 256 bytes so that one fill clears it
+static inline size_t tile_counts_bytes(const ffs_stream* s) { return (((size_t)s->max_batch * s->ctx->n_tiles + 2) * 4 + 255) / 256 * 256; }
+static inline void mark_busy(ffs_stream* s) {
+    if (!s->busy) ++s->ctx->inflight;
+    s->busy = true;
+}
+static inline void mark_idle(ffs_stream* s) {
+    if (s->busy) --s->ctx->inflight;
+    s->busy = false;
+}
+template <typename T>
+static hipError_t dmalloc(T** p, size_t n_bytes) {
+    return hipMalloc(reinterpret_cast<void**>(p), n_bytes + 256);
+}
+
+// ---- functions one unit calls in another ----------------------------------------------------------------------
+// ffs_context.hip
+int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uint32_t max_comp, ffs_stream** out);
+// ffs_submit.hip
+bool chain_prepare_device();   // asks for k_frame_chain's dynamic LDS on the current device; false: use the four kernels
+ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t pitch, size_t fstride, uint32_t n_frames);
+int check_layout(ffs_stream* s, size_t pitch, size_t fstride, uint32_t n_frames);
+int ensure_extended_buffers(ffs_stream* s);
+int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride, uint32_t n, const ffs_params* snapshot = nullptr);
+// one launch of the threshold stage's dense kernel on s->st with HIP events on the dispatch itself (either may be null),
+// and of the kernel that follows it (k_bright_fix / k_exact; extended: erosion + final pass) -- what ffs_bench_threshold times
+void bench_launch_dense(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames, hipEvent_t start, hipEvent_t stop);
+void bench_launch_rest(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames);
+// ffs_wait.hip
+int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_results);
+// ffs_stack3d.hip
+void stack3d_free(ffs_stack3d* st);

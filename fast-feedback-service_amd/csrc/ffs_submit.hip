@@ -1,0 +1,736 @@
+// ffs_submit.hip -- everything that puts a batch on the device: launch geometry, the launches of the threshold stage
+// and of the sparse stage (compaction -> connected components -> records), the submit entry points and compressed
+// input.  All kernels of the hot path are included here and nowhere else (see ffs_internal.hpp).
+//
+// Reference: the per-frame section of spotfinder/spotfinder.cc:751-1008 (H2D, kernel launch wrapper
+// spotfinder/spotfinder.cu:148-189, D2H of the mask, host connected components).
+#include "ffs_internal.hpp"
+#include "kernels_threshold.hpp"
+#include "kernels_extended.hpp"
+#include "kernels_stream.hpp"
+#include "kernels_ccl.hpp"
+#include "kernels_chain.hpp"
+#include "kernels_decode.hpp"
+
+bool chain_prepare_device() {   // more than 64 KB of dynamic LDS has to be asked for, per device
+    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
+    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
+    (void)hipGetLastError();
+    return e1 == hipSuccess && e2 == hipSuccess;
+}
+
+ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t pitch, size_t fstride, uint32_t n_frames) {
+    const ffs_ctx* c = s->ctx;
+    const Layout& L = c->L;
+    const ffs_params& p = s->batch_params;
+    ThresholdArgs a{};
+    a.image = img;
+    a.frame_stride = fstride;
+    a.pitch = (uint32_t)pitch;
+    a.maskbits = c->d_maskbits;
+    a.bits = s->d_bits;
+    a.strong_bytes = s->d_sbytes;
+    a.tile_counts = s->d_tile_counts;
+    a.W = L.W;
+    a.H = L.H;
+    a.pitch_px = L.pitch_px;
+    a.mpitch = L.mpitch;
+    a.bpitch = L.bpitch;
+    a.plane_frame_stride = L.plane_frame_stride;
+    a.bytes_frame_stride = L.bytes_frame_stride;
+    a.n_tiles = c->n_tiles;
+    a.kS = (float)(p.nsig_s * p.nsig_s * (1.0 - 1.0 / 65536.0));
+    a.kB = (float)(p.nsig_b * (1.0 - 1.0 / 1048576.0));
+    a.min_count = p.min_count;
+    a.nsig_b = p.nsig_b;
+    a.nsig_s = p.nsig_s;
+    a.nsig_b2 = p.nsig_b * p.nsig_b;
+    a.nsig_s2 = p.nsig_s * p.nsig_s;
+    a.threshold = p.threshold;
+    a.max_valid = p.max_valid;
+    // bright windows (sum p >= 65536; 32-bit pixels >= 2^24): onto the list k_bright_fix works off, or -- tuning
+    // "threshold_path" = 1, and whenever that list overflowed (ffs_wait re-runs the batch) -- into the plane as candidates
+    a.bright_to_plane = s->force_path >= 0 ? s->force_path : c->tune.threshold_path;
+    a.overflow = s->d_overflow;
+    a.bright_n = s->d_tile_counts + tile_counts_bytes(s) / 4 - 1;
+    a.bright_list = s->d_bright;
+    a.bright_cap = std::min<uint32_t>(kBrightCap, (uint32_t)c->tune.bright_cap);
+    a.occ = s->d_occ;
+    a.occ_frame_words = occ_frame_words(L);
+    a.occ_spr = L.mpitch / 16;
+    // The byte mask (the reference kernel's result_strong, 1 byte per pixel) is an OUTPUT only when it was asked for
+    // (want_strong_mask: --writeout, parity tests): the hot path's own strong mask is the bit plane, and the 0.58 GB of
+    // zeros per 32 Eiger frames cost the streaming kernel 15 %.  (The exact kernel of path 1 sets its 1s: zero-filled then too.)
+    a.dense_mask = (p.want_strong_mask || c->tune.dense_mask || a.bright_to_plane) ? 1 : 0;
+#ifdef FFS_EXPERIMENTS
+    a.dbg = c->tune.exp.k1_debug;
+    if (a.dbg & 16) a.dense_mask = 1;
+    if (a.dbg & 8) a.dense_mask = 0;
+#endif
+    a.ginfo = c->d_ginfo;
+    a.mmap = c->d_mmap;
+    a.gpitch = (uint32_t)L.pitch_px * (uint32_t)c->pixel_bytes / 4;
+    a.gpf = c->pixel_bytes == 2 ? (L.W + 7) / 8 : (L.W + 3) / 4;
+    a.n_frames = (int)n_frames;
+    {   // Streaming kernels: frames side by side in one super row, as many as keep every buffer of the group below 2 GiB.
+        // Bands: enough waves to fill the 256 CUs several times over, bands no shorter than 72 rows (the 6-row warm-up of
+        // every band stays below 8 %) -- and a whole number of bands per XCD: the kernels deal the bands round-robin to the
+        // 8 XCDs (band = xcd + 8 k, so that neighbouring strips share an L2); with 29 bands three XCDs had a band less to
+        // do than the others and the launch waited for the busy five (511 us per 32 Eiger frames against 430-440 with 48 or 56).
+        const uint64_t per_frame = std::max<uint64_t>(fstride, L.bytes_frame_stride);
+        a.group_frames = (int)std::max<uint64_t>(1, std::min<uint64_t>(n_frames, ((1ull << 31) - 1) / per_frame));
+        a.group_frames = std::min(a.group_frames, c->tune.frames_per_group);
+        const int n_groups = ((int)n_frames + a.group_frames - 1) / a.group_frames;
+        const long long lanes = (long long)a.group_frames * (a.gpf + 1);
+        const long long lines = (long long)a.group_frames * (L.bpitch / 128);  // byte-mask lines to zero per row
+        const int lines_per_wave = c->pixel_bytes == 2 ? 4 : 2;  // a wave zero-fills 512 / 256 bytes of the byte mask per row
+        a.n_strips = (int)std::max<long long>((lanes + kSOwned - 1) / kSOwned, (lines + lines_per_wave - 1) / lines_per_wave);
+        const long long per_band = std::max<long long>(1, (long long)a.n_strips * n_groups);
+        long long nb = std::max<long long>(1, std::min<long long>(c->tune.target_waves / per_band, L.H / 72));
+        if (nb >= 8) nb = nb / 8 * 8;
+        a.band_rows = (int)std::min<long long>(1024, (L.H + nb - 1) / nb);
+        a.n_bands = (L.H + a.band_rows - 1) / a.band_rows;
+    }
+    a.dplane = s->d_dplane;
+    a.eplane = s->d_eplane;
+    a.ext_flavour = p.extended_flavour;
+    a.ext_variant = (c->pixel_bytes == 2 && s->force_path < 0) ? c->tune.ext_first_pass : 0;
+    a.ext_strips = (L.pitch_px + kExtOwnedPx - 1) / kExtOwnedPx;
+    {   // one pixel per lane: bands of 64..256 rows keep the 6-row warm-up below 10 %
+        const long long ext_target = 8192;
+        long long er = ((long long)L.H * a.ext_strips * n_frames + 4 * ext_target - 1) / (4 * ext_target);
+        er = std::max<long long>(64, std::min<long long>(er, 256));
+        a.ext_band_rows = (int)er;
+        a.ext_bands = (L.H + a.ext_band_rows - 1) / a.ext_band_rows;
+    }
+    return a;
+}
+
+// ---- the threshold stage's launches -----------------------------------------------------------------------------
+static dim3 stream_grid(const ThresholdArgs& a, uint32_t n_frames) {
+    const int bands8 = (a.n_bands + 7) / 8 * 8;  // the XCD-aware block map wants a multiple of 8 bands
+    const unsigned n_groups = (n_frames + (unsigned)a.group_frames - 1) / (unsigned)a.group_frames;
+    return dim3((unsigned)(a.n_strips * bands8), n_groups);
+}
+
+// The whole standard threshold in one kernel: final strong plane + per-tile counts (atomics into zeroed counters).
+// Start and stop events ride on the dispatch itself (its completion signal): no marker packets around it.
+static void launch_stream(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames, hipEvent_t start, hipEvent_t stop) {
+    const dim3 grid = stream_grid(a, n_frames);
+    if (s->ctx->pixel_bytes == 4) hipExtLaunchKernelGGL(k_stream_u32<2>, grid, dim3(64), 0, s->st, start, stop, 0, a);
+    else hipExtLaunchKernelGGL((k_stream_u16<2>), grid, dim3(64), 0, s->st, start, stop, 0, a);
+}
+static void launch_bright_fix(ffs_stream* s, const ThresholdArgs& a, hipStream_t st) {
+    if (s->ctx->pixel_bytes == 4) hipLaunchKernelGGL(k_bright_fix<uint32_t>, dim3(32), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_bright_fix<uint16_t>, dim3(32), dim3(256), 0, st, a);
+}
+// path 1: every pixel marked in the plane (decided strong pixels and bright-window candidates alike) takes the gathered
+// predicate; rewrites the plane, the per-tile counts and sets the byte mask's 1s
+static void launch_exact(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames, hipStream_t st) {
+    const dim3 grid((unsigned)a.n_tiles, n_frames);
+    if (s->ctx->pixel_bytes == 4) hipLaunchKernelGGL(k_exact<uint32_t>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_exact<uint16_t>, grid, dim3(256), 0, st, a);
+}
+
+// Extended dispersion: first pass -> erosion -> final threshold (kernels_extended.hpp).  Leaves the strong plane in
+// a.bits, the byte mask and the per-tile counts as the exact stage does.  First pass, 16-bit pixels: the streaming kernel
+// in its extended mode decides it exactly in its drain (ext_variant 2, default); k_ext_first is the plain one-pixel-
+// per-lane kernel that computes the same plane directly (32-bit pixels, tuning "ext_first_pass" = 0, and the fall-back
+// when the bright-window list of a batch overflowed).
+static bool ext_stream_first(const ThresholdArgs& a) { return a.ext_variant >= 2; }
+
+static void launch_ext_first(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames, hipEvent_t start, hipEvent_t stop) {
+    if (ext_stream_first(a)) {
+        // the kernel writes the non-zero bytes of the first-pass plane; the bright-list count sits behind the tile counts
+        (void)hipMemsetAsync(a.dplane, 0, (size_t)n_frames * a.plane_frame_stride, s->st);
+        (void)hipMemsetAsync(a.tile_counts, 0, tile_counts_bytes(s), s->st);
+        hipExtLaunchKernelGGL((k_stream_u16<2, true>), stream_grid(a, n_frames), dim3(64), 0, s->st, start, stop, 0, a);
+        hipLaunchKernelGGL((k_bright_fix<uint16_t, true>), dim3(32), dim3(256), 0, s->st, a);
+        return;
+    }
+    dim3 g1((unsigned)(a.ext_strips * a.ext_bands), n_frames);
+    if (s->ctx->pixel_bytes == 2) hipExtLaunchKernelGGL(k_ext_first<uint16_t>, g1, dim3(64), 0, s->st, start, stop, 0, a);
+    else hipExtLaunchKernelGGL(k_ext_first<uint32_t>, g1, dim3(64), 0, s->st, start, stop, 0, a);
+}
+static void launch_ext_rest(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
+    const bool u16 = s->ctx->pixel_bytes == 2;
+    // The byte mask: the streaming kernel zero-filled it if somebody wants it (k_ext_final sets 1s in it either way; without a
+    // taker they land in a buffer nobody reads); after k_ext_first it is always produced, so zero it here.
+    if (!ext_stream_first(a)) (void)hipMemsetAsync(a.strong_bytes, 0, (size_t)n_frames * a.bytes_frame_stride, s->st);
+    const unsigned erode_lanes = (a.mpitch / 4) * (unsigned)((a.H + kErodeRows - 1) / kErodeRows);
+    hipLaunchKernelGGL(k_ext_erode, dim3((erode_lanes + 255) / 256, n_frames), dim3(256), 0, s->st, a);
+    dim3 g3((unsigned)a.n_tiles, n_frames);
+    if (u16) hipLaunchKernelGGL(k_ext_final<uint16_t>, g3, dim3(256), 0, s->st, a);
+    else hipLaunchKernelGGL(k_ext_final<uint32_t>, g3, dim3(256), 0, s->st, a);
+}
+
+int ensure_extended_buffers(ffs_stream* s) {
+    if (s->d_dplane) return FFS_OK;
+    ffs_ctx* c = s->ctx;
+    const size_t bytes = (size_t)s->max_batch * c->L.plane_frame_stride;
+    if (dmalloc(&s->d_dplane, bytes) != hipSuccess || dmalloc(&s->d_eplane, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        c->err = "hipMalloc(extended dispersion planes) failed";
+        return FFS_ERR_NOMEM;
+    }
+    return FFS_OK;
+}
+
+void bench_launch_dense(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames, hipEvent_t start, hipEvent_t stop) {
+    if (s->batch_params.algorithm == FFS_ALGO_DISPERSION_EXTENDED) launch_ext_first(s, a, n_frames, start, stop);
+    else launch_stream(s, a, n_frames, start, stop);
+}
+void bench_launch_rest(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
+    if (s->batch_params.algorithm == FFS_ALGO_DISPERSION_EXTENDED) launch_ext_rest(s, a, n_frames);
+    else if (a.bright_to_plane) launch_exact(s, a, n_frames, s->st);
+    else launch_bright_fix(s, a, s->st);
+}
+
+int check_layout(ffs_stream* s, size_t pitch, size_t fstride, uint32_t n_frames) {
+    ffs_ctx* c = s->ctx;
+    if (n_frames == 0 || n_frames > s->max_batch) {
+        c->err = "n_frames must be in 1..max_batch";
+        return FFS_ERR_INVALID;
+    }
+    if (pitch % 16 || pitch < (size_t)c->L.pitch_px * c->pixel_bytes || pitch >= (1ull << 32)
+        || fstride < pitch * c->L.H || (pitch * c->L.H) >= (1ull << 32)) {
+        c->err = "device layout: pitch must be a multiple of 16 bytes and >= round_up(width,128)*pixel_bytes; "
+                 "frame_stride >= pitch*height";
+        return FFS_ERR_INVALID;
+    }
+    return FFS_OK;
+}
+
+#ifdef FFS_EXPERIMENTS
+// (experiment) occupies slots for a given time without touching memory
+__global__ void k_dummy_spin(uint32_t ticks, uint32_t* sink) {
+    extern __shared__ uint32_t s_dummy[];
+    const uint64_t t0 = wall_clock64();
+    uint32_t it = 0;
+    while (wall_clock64() - t0 < ticks && it < (1u << 20)) { __builtin_amdgcn_s_sleep(20); ++it; }
+    if (it == 0xFFFFFFFFu) { s_dummy[threadIdx.x] = it; *sink = s_dummy[0]; }
+}
+#endif
+
+// ---- one batch ------------------------------------------------------------------------------------------------------
+int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride, uint32_t n, const ffs_params* snapshot) {
+    ffs_ctx* c = s->ctx;
+    const Layout& L = c->L;
+    s->batch_params = snapshot ? *snapshot : c->params;
+    const ffs_params& p = s->batch_params;
+    s->cur_img = d_img;
+    s->cur_pitch = pitch;
+    s->cur_fstride = fstride;
+    const bool ext = p.algorithm == FFS_ALGO_DISPERSION_EXTENDED;
+
+    (void)hipGetLastError();  // drop any stale error state: the check below is for OUR launches
+    if (s->st_up != s->st && !s->dev_input) HIP_TRY(c, hipStreamWaitEvent(s->st, s->ev[1], 0));   // the frames are in place (upload / decode stream)
+    if (ext) {
+        const int rc = ensure_extended_buffers(s);
+        if (rc != FFS_OK) return rc;
+    }
+    const ThresholdArgs ta = make_threshold_args(s, d_img, pitch, fstride, n);
+    // "streamed": the plane the sparse stage reads was produced by a streaming kernel into a zeroed plane (and is zeroed
+    // again by the compaction); path 0 also keeps the occupancy bitmap in step with it
+    const bool streamed = !ext;
+    const bool list_path = streamed && !ta.bright_to_plane;
+    if (streamed && s->bits_dirty)  // (another algorithm or a failed batch left bits behind)
+        HIP_TRY(c, hipMemsetAsync(s->d_bits, 0, (size_t)s->max_batch * L.plane_frame_stride, s->st));
+    if (streamed && s->counts_dirty)
+        HIP_TRY(c, hipMemsetAsync(s->d_tile_counts, 0, tile_counts_bytes(s), s->st));
+    if (s->occ_dirty) {
+        HIP_TRY(c, hipMemsetAsync(s->d_occ, 0, (size_t)s->max_batch * occ_frame_words(L) * 4, s->st));
+        s->occ_dirty = false;
+    }
+    s->counts_dirty = true;
+    s->bits_dirty = true;  // until every launch of this batch is enqueued (a failure in between leaves bits behind)
+    // The whole sparse stage in one launch, one workgroup per frame (kernels_chain.hpp) ...
+    bool will_chain = c->tune.sparse_stage >= 2 && L.H <= 65535 && c->chain_ok && s->direct_recs && s->h_counts_dev
+                      && c->n_tiles <= kChainMaxTiles && L.H <= kChainMaxRows;
+#ifdef FFS_EXPERIMENTS
+    if (c->tune.exp.chain_skip) will_chain = false;
+#endif
+    // ... which then also does the bright-window fix-up, and whose workgroups (a whole CU each) should get their CUs
+    // BEFORE the next batch's streaming kernel floods the dispatcher: that kernel waits for this launch to have STARTED.
+    // (Without it a batch's sparse launch sits out the whole next streaming kernel: 0.35 ms more latency per batch.)
+    // Only while few batches are in flight: with a deep pipeline the latency is hidden anyway, the wait costs the dense
+    // stream ~15 us per batch and the fix-up inside the one-workgroup-per-frame launch ~25 us of its CUs (4 batches in
+    // flight: 0.369-0.377 against 0.353 ms per step; 2 in flight: 0.385 against 0.523).
+    const bool aside = streamed && s->st2 != s->st;   // the context has sparse streams: the dense stream holds streaming kernels only
+    const int depth = c->inflight.load() + (s->busy ? 0 : 1);
+    const bool chain_first = list_path && aside && will_chain && c->tune.chain_first > 0 && depth <= c->tune.chain_first;
+    if (chain_first) {
+        std::lock_guard<std::mutex> lock(c->stream_mu);   // (the newest start event cannot be re-recorded between the two lines)
+        const int slot = c->chain_ev_newest.load();
+        if (slot >= 0) HIP_TRY(c, hipStreamWaitEvent(s->st, c->chain_ev[slot], 0));
+    }
+    hipEvent_t ev_start = nullptr;
+    if (s->ev1_pending) { ev_start = s->ev[1]; s->ev1_pending = false; }
+    if (ext) {
+        launch_ext_first(s, ta, n, ev_start, nullptr);
+        launch_ext_rest(s, ta, n);
+        HIP_TRY(c, hipEventRecord(s->ev[2], s->st));
+        if (s->st2 != s->st) HIP_TRY(c, hipStreamWaitEvent(s->st2, s->ev[2], 0));
+    } else if (list_path && aside) {
+        // the bright-window fix-up goes to the sparse stream (or into the sparse launch itself: chain_first)
+        launch_stream(s, ta, n, ev_start, s->ev[2]);
+        HIP_TRY(c, hipStreamWaitEvent(s->st2, s->ev[2], 0));
+        if (!chain_first) launch_bright_fix(s, ta, s->st2);
+    } else {
+        launch_stream(s, ta, n, ev_start, nullptr);
+        if (list_path) launch_bright_fix(s, ta, s->st);
+        else launch_exact(s, ta, n, s->st);
+        HIP_TRY(c, hipEventRecord(s->ev[2], s->st));
+        if (s->st2 != s->st) HIP_TRY(c, hipStreamWaitEvent(s->st2, s->ev[2], 0));
+    }
+    HIP_TRY(c, hipGetLastError());
+
+    CclArgs ca{};
+    ca.image = d_img;
+    ca.frame_stride = fstride;
+    ca.pitch = (uint32_t)pitch;
+    ca.bits = s->d_bits;
+    ca.clear_bits = streamed ? 1 : 0;
+    s->bits_cleared = ca.clear_bits != 0;
+    ca.tile_counts = s->d_tile_counts;
+    ca.num_strong = s->d_num_strong;
+    ca.row_off = s->d_row_off;
+    ca.list_k = s->d_list_k;
+    ca.list_i = s->d_list_i;
+    ca.parent = s->d_parent;
+    ca.n_comp = s->d_n_comp;
+    ca.overflow = s->d_overflow;
+    ca.W = L.W;
+    ca.H = L.H;
+    ca.pitch_px = L.pitch_px;
+    ca.mpitch = L.mpitch;
+    ca.plane_frame_stride = L.plane_frame_stride;
+    ca.n_tiles = c->n_tiles;
+    ca.cap = s->cap;
+    ca.max_comp = s->max_comp;
+    ca.pixel_bytes = c->pixel_bytes;
+    ca.strong_bytes = s->d_sbytes;
+    ca.bpitch = L.bpitch;
+    ca.bytes_frame_stride = L.bytes_frame_stride;
+    ca.acc2 = s->d_acc2;
+    ca.summary = s->d_summary;
+    // (the byte mask: zero-filled by the streaming kernels only when asked for; the exact stages always produce it)
+    ca.dense_bytes = ((list_path || (ext && ext_stream_first(ta))) ? ta.dense_mask : 1) ? 1 : 0;
+    s->dense_valid = ca.dense_bytes != 0;
+    ca.occ = s->d_occ;
+    ca.occ_frame_words = occ_frame_words(L);
+    ca.occ_spr = L.mpitch / 16;
+    // only the streaming kernels and their fix-up keep the bitmap (path 1: a superset of the final plane, which is fine)
+    ca.use_occ = (streamed && c->tune.occupancy_bitmap) ? 1 : 0;
+    s->occ_dirty = streamed && !(ca.use_occ && will_chain);   // nobody consumes (and clears) the bits the streaming kernel sets
+
+    SegArgs sa{};
+    sa.list_k = s->d_list_k;
+    sa.list_i = s->d_list_i;
+    sa.parent = s->d_parent;
+    sa.seg_n = s->d_num_strong;
+    sa.seg_stride = s->cap;
+    sa.n_comp = s->d_n_comp;
+    sa.max_comp = s->max_comp;
+    sa.overflow = s->d_overflow;
+    sa.W = (uint32_t)L.W;
+    sa.H = (uint32_t)L.H;
+    sa.row_off = s->d_row_off;
+    sa.n_slices = 1;
+    sa.min_spot_size = p.min_spot_size;
+    sa.max_sep = p.max_peak_centroid_separation;
+    sa.summary = s->d_summary;
+    sa.acc2 = s->d_acc2;
+    sa.zero_counts = s->d_tile_counts;
+    sa.zero_per_seg = (uint32_t)c->n_tiles;
+    sa.zero_word = s->d_tile_counts + tile_counts_bytes(s) / 4 - 1;
+
+    s->chain_mode = will_chain;
+    if (s->chain_mode) {
+        ChainArgs A{};
+        A.c = ca;
+        A.s = sa;
+        A.s.recs = s->h_recs_dev;
+        A.h_counts = s->h_counts_dev;
+        A.max_batch = (uint32_t)s->max_batch;
+        A.rec_stride = s->max_comp;
+#ifdef FFS_EXPERIMENTS
+        A.stop_after = c->tune.exp.chain_stop;
+#endif
+        A.t = ta;
+        A.fix_bright = chain_first ? 1 : 0;
+        A.fix_done = s->d_tile_counts + tile_counts_bytes(s) / 4 - 2;
+        {
+            // the launch's start event belongs to the context (ffs_internal.hpp); published under the lock the waiting side takes
+            std::lock_guard<std::mutex> lock(c->stream_mu);
+            const int slot = (int)(c->chain_ev_next.fetch_add(1) % ffs_ctx::kChainEvents);
+            if (c->pixel_bytes == 2) hipExtLaunchKernelGGL(k_frame_chain<uint16_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
+            else hipExtLaunchKernelGGL(k_frame_chain<uint32_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
+            if (aside) c->chain_ev_newest.store(slot);
+        }
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(s->ev[4], s->st2));
+        s->ev3_is_ev4 = true;
+        s->spec_recs_copied = (uint64_t)s->max_batch * s->max_comp;
+        s->bits_dirty = !streamed;
+        s->counts_dirty = false;
+        mark_busy(s);
+        s->n_frames = n;
+        return FFS_OK;
+    }
+    // the same stages as four grid-wide kernels (frames taller than k_frame_chain's LDS plan, records not written to the
+    // host directly, tuning "sparse_stage" = 1)
+    bool skip_sparse = false;
+#ifdef FFS_EXPERIMENTS
+    if (c->tune.exp.chain_skip) {
+        skip_sparse = true;
+        if (c->tune.exp.dummy_us > 0)
+            hipLaunchKernelGGL(k_dummy_spin, dim3(c->tune.exp.dummy_wg), dim3(c->tune.exp.dummy_threads),
+                               (size_t)c->tune.exp.dummy_lds, s->st2, (uint32_t)c->tune.exp.dummy_us * 100u, s->d_tile_counts);
+    }
+#endif
+    if (!skip_sparse) {
+        sa.recs = s->direct_recs ? (void*)s->h_recs_dev : (void*)s->d_recs;
+        sa.chunk_roots = s->d_chunk_roots;
+        sa.chunks_max = s->cap / kRootChunk + 1;
+        const dim3 gseg((unsigned)c->tune.ccl_grid, n), b256(256);
+        if (c->pixel_bytes == 2) hipLaunchKernelGGL(k_emit_list_w<uint16_t>, dim3(c->n_tiles, n), dim3(64), 0, s->st2, ca);
+        else hipLaunchKernelGGL(k_emit_list_w<uint32_t>, dim3(c->n_tiles, n), dim3(64), 0, s->st2, ca);
+        hipLaunchKernelGGL(k_union<false>, gseg, b256, 0, s->st2, sa);
+        hipLaunchKernelGGL(k_reduce_roots, gseg, b256, 0, s->st2, sa);
+        hipLaunchKernelGGL(k_finalize_roots, gseg, b256, 0, s->st2, sa);
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(s->ev[3], s->st2));
+    s->ev3_is_ev4 = false;
+
+    // small counts first; ffs_wait() sizes the record copy from them
+    const size_t B = s->max_batch;
+    HIP_TRY(c, hipMemcpyAsync(s->h_counts, s->d_num_strong, (B * 10 + 1) * 4, hipMemcpyDeviceToHost, s->st2));
+    if (s->direct_recs) {
+        s->spec_recs_copied = (uint64_t)B * s->max_comp;  // everything is on the host already
+    } else {
+        s->spec_recs_copied = std::min<uint64_t>((uint64_t)s->spec_recs_per_frame * n, (uint64_t)B * s->max_comp);
+        HIP_TRY(c, hipMemcpyAsync(s->h_recs, s->d_recs, s->spec_recs_copied * sizeof(WireRec2), hipMemcpyDeviceToHost, s->st2));
+    }
+    HIP_TRY(c, hipEventRecord(s->ev[4], s->st2));
+    s->bits_dirty = !streamed || skip_sparse;  // the compaction of a streamed batch leaves the plane all zero again
+    s->counts_dirty = skip_sparse;  // k_union cleared the counts of the frames of this batch (all the streaming kernel touched)
+    mark_busy(s);
+    s->n_frames = n;
+    return FFS_OK;
+}
+
+extern "C" int ffs_submit_device(ffs_stream* s, const void* device_pixels, size_t pitch, size_t fstride,
+                                 uint32_t n_frames, int64_t first_frame_id) {
+    if (!s || !device_pixels) return FFS_ERR_INVALID;
+    ffs_ctx* c = s->ctx;
+    if (s->busy) {
+        c->err = "stream already has a batch in flight: call ffs_wait() first";
+        return FFS_ERR_INVALID;
+    }
+    int rc = check_layout(s, pitch, fstride, n_frames);
+    if (rc != FFS_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // (no marker here: every packet in the dense stream is ~5 us between two streaming kernels; enqueue_batch attaches
+    // the start event to its first kernel where it can, or records it)
+    s->dev_input = true;
+    s->ev1_pending = true;
+    s->first_id = first_frame_id;
+    return enqueue_batch(s, device_pixels, pitch, fstride, n_frames);
+}
+
+extern "C" int ffs_submit(ffs_stream* s, const void* host_pixels, uint32_t n_frames, int64_t first_frame_id) {
+    if (!s || !host_pixels) return FFS_ERR_INVALID;
+    ffs_ctx* c = s->ctx;
+    if (s->busy) {
+        c->err = "stream already has a batch in flight: call ffs_wait() first";
+        return FFS_ERR_INVALID;
+    }
+    if (n_frames == 0 || n_frames > s->max_batch) {
+        c->err = "n_frames must be in 1..max_batch";
+        return FFS_ERR_INVALID;
+    }
+    const Layout& L = c->L;
+    HIP_TRY(c, hipSetDevice(c->device));
+    s->dev_input = false;
+    HIP_TRY(c, hipEventRecord(s->ev[0], s->st_up));
+    // one 2D copy: the default device layout keeps frames contiguous (frame_stride = H * pitch)
+    const size_t row = (size_t)L.W * c->pixel_bytes;
+    HIP_TRY(c, hipMemcpy2DAsync(s->d_img, L.pitch, host_pixels, row, row, (size_t)L.H * n_frames,
+                                hipMemcpyHostToDevice, s->st_up));
+    HIP_TRY(c, hipEventRecord(s->ev[1], s->st_up));
+    s->first_id = first_frame_id;
+    return enqueue_batch(s, s->d_img, L.pitch, L.frame_stride, n_frames);
+}
+
+
+// ---- compressed input -------------------------------------------------------------------------------
+
+static int ensure_decode_buffers(ffs_stream* s) {
+    ffs_ctx* c = s->ctx;
+    if (s->d_comp) return FFS_OK;
+    const size_t es = c->pixel_bytes, nelem = (size_t)c->L.W * c->L.H;
+    // bitshuffle's blocking (bshuf_default_block_size, and the loop of bshuf_blocked_wrap_fun)
+    const size_t block = (size_t)kDecBlockBytes / es;
+    const size_t n_full = nelem / block, rem = nelem - n_full * block;
+    s->dec_block_elems = (uint32_t)block;
+    s->dec_blocks = (uint32_t)(n_full + (rem >= 8 ? 1 : 0));
+    s->dec_last = (uint32_t)(rem >= 8 ? rem / 8 * 8 : block);
+    s->dec_tail = (uint32_t)(rem % 8);
+    const size_t tab_bytes = (size_t)s->max_batch * (s->dec_blocks + 1) * sizeof(uint2);
+    if (dmalloc(&s->d_comp, s->h_img_bytes + 64) != hipSuccess || dmalloc(&s->d_tab, tab_bytes) != hipSuccess
+        || hipHostMalloc(reinterpret_cast<void**>(&s->h_tab), tab_bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        c->err = "allocation of the compressed-chunk buffers failed";
+        return FFS_ERR_NOMEM;
+    }
+    return FFS_OK;
+}
+
+static inline uint32_t be32(const uint8_t* p) {
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+}
+
+// Step 1 (caller's thread): validates the headers, places the chunks in the pinned staging buffer
+// (unless they already are there) and starts their copy to the device.  Fills base[] = offset of every
+// chunk in the staging / device buffer.
+static int stage_chunks(ffs_stream* s, const void* const* chunks, const size_t* chunk_bytes, uint32_t n,
+                        std::vector<size_t>& base) {
+    ffs_ctx* c = s->ctx;
+    const Layout& L = c->L;
+    int rc = ensure_decode_buffers(s);
+    if (rc != FFS_OK) return rc;
+    const size_t es = c->pixel_bytes, raw_bytes = (size_t)L.W * L.H * es;
+    uint32_t in_place = 0;
+    for (uint32_t f = 0; f < n; ++f) {
+        if (!chunks[f] || chunk_bytes[f] < 12) {
+            c->err = "ffs_submit_compressed: a chunk is shorter than its 12-byte header";
+            return FFS_ERR_INVALID;
+        }
+        const uint8_t* p = static_cast<const uint8_t*>(chunks[f]);
+        uint64_t total = 0;
+        for (int i = 0; i < 8; ++i) total = (total << 8) | p[i];
+        if (total != raw_bytes) {
+            c->err = "ffs_submit_compressed: chunk header says " + std::to_string(total) + " bytes, the context's frames have "
+                     + std::to_string(raw_bytes);
+            return FFS_ERR_INVALID;
+        }
+        if (p >= s->h_img && p + chunk_bytes[f] <= s->h_img + s->h_img_bytes) ++in_place;
+    }
+    if (in_place != 0 && in_place != n) {
+        c->err = "ffs_submit_compressed: either all chunks lie in the stream's host buffer or none";
+        return FFS_ERR_INVALID;
+    }
+    base.assign(n, 0);
+    size_t lo = 0, hi = 0;
+    if (in_place) {
+        lo = SIZE_MAX;
+        for (uint32_t f = 0; f < n; ++f) {
+            base[f] = (size_t)(static_cast<const uint8_t*>(chunks[f]) - s->h_img);
+            lo = std::min(lo, base[f]);
+            hi = std::max(hi, base[f] + chunk_bytes[f]);
+        }
+        lo &= ~(size_t)15;
+    } else {
+        size_t cur = 0;
+        for (uint32_t f = 0; f < n; ++f) {
+            if (cur + chunk_bytes[f] > s->h_img_bytes) {
+                c->err = "ffs_submit_compressed: the batch's chunks exceed the staging buffer";
+                return FFS_ERR_INVALID;
+            }
+            std::memcpy(s->h_img + cur, chunks[f], chunk_bytes[f]);
+            base[f] = cur;
+            cur = (cur + chunk_bytes[f] + 15) & ~(size_t)15;
+        }
+        hi = cur;
+    }
+    if (hi > 0xFFFFFFF0ull) {
+        c->err = "ffs_submit_compressed: more than 4 GiB of chunks in one batch";
+        return FFS_ERR_INVALID;
+    }
+    HIP_TRY(c, hipMemcpyAsync(s->d_comp + lo, s->h_img + lo, hi - lo, hipMemcpyHostToDevice, s->st_up));
+    return FFS_OK;
+}
+
+// Step 2 (may run on the stream's helper thread while the chunks cross PCIe): indexes the blocks --
+// each frame is a chain of [4-byte length][payload], a pointer chase of ~2 ms for 32 Eiger frames;
+// the frames' chains are walked side by side so that their cache misses overlap -- and enqueues the
+// table copy.  Errors go to `err`, not to the context (another thread may own that string).
+static int index_blocks(ffs_stream* s, const std::vector<size_t>& base, const std::vector<size_t>& chunk_bytes,
+                        std::string& err) {
+    ffs_ctx* c = s->ctx;
+    const uint32_t n = (uint32_t)base.size();
+    const size_t es = c->pixel_bytes;
+    const uint32_t nb = s->dec_blocks, stride = nb + 1;
+    std::vector<size_t> pos(n, 12);
+    std::atomic<bool> ok{true};
+    static const bool trace = std::getenv("FFS_TRACE_SUBMIT") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto walk = [&](uint32_t f0, uint32_t f1) {  // frames [f0, f1), chains interleaved
+        for (uint32_t b = 0; b < nb; ++b)
+            for (uint32_t f = f0; f < f1; ++f) {
+                if (pos[f] + 4 > chunk_bytes[f]) { ok = false; return; }
+                const uint32_t clen = be32(s->h_img + base[f] + pos[f]);
+                s->h_tab[(size_t)f * stride + b] = make_uint2((uint32_t)(base[f] + pos[f] + 4), clen);
+                pos[f] += 4 + (size_t)clen;
+            }
+        for (uint32_t f = f0; f < f1; ++f) {
+            const size_t tail = (size_t)s->dec_tail * es;
+            if (pos[f] + tail > chunk_bytes[f]) ok = false;
+            s->h_tab[(size_t)f * stride + nb] = make_uint2((uint32_t)(base[f] + pos[f]), (uint32_t)tail);
+        }
+    };
+    const uint32_t n_thr = (uint64_t)n * nb >= 32768 ? std::min<uint32_t>(4, n) : 1;
+    if (n_thr <= 1) {
+        walk(0, n);
+    } else {
+        std::vector<std::thread> th;
+        for (uint32_t t = 1; t < n_thr; ++t) th.emplace_back(walk, n * t / n_thr, n * (t + 1) / n_thr);
+        walk(0, n / n_thr);
+        for (auto& t : th) t.join();
+    }
+    if (trace)
+        std::fprintf(stderr, "[ffs] indexed %u blocks in %.3f ms (%u threads)\n", n * nb,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), n_thr);
+    if (!ok) {
+        err = "ffs_submit_compressed: block lengths run past the end of a chunk";
+        return FFS_ERR_INVALID;
+    }
+    const hipError_t e = hipMemcpyAsync(s->d_tab, s->h_tab, (size_t)n * stride * sizeof(uint2), hipMemcpyHostToDevice, s->st_up);
+    if (e != hipSuccess) {
+        err = std::string("hipMemcpyAsync(block table): ") + hipGetErrorString(e);
+        return FFS_ERR_DEVICE;
+    }
+    return FFS_OK;
+}
+
+static void launch_decode(ffs_stream* s, uint32_t n, hipStream_t st) {
+    ffs_ctx* c = s->ctx;
+    DecodeArgs da{};
+    da.comp = s->d_comp;
+    da.table = s->d_tab;
+    da.image = s->d_img;
+    da.frame_stride = c->L.frame_stride;
+    da.pitch = c->L.pitch;
+    da.W = c->L.W;
+    da.H = c->L.H;
+    da.elem_bytes = c->pixel_bytes;
+    da.blocks_per_frame = s->dec_blocks;
+    da.block_elems = s->dec_block_elems;
+    da.last_block_elems = s->dec_last;
+    da.tail_elems = s->dec_tail;
+    da.error = s->d_overflow;
+    const dim3 grid(s->dec_blocks + 1, n);
+    if (c->pixel_bytes == 2) hipLaunchKernelGGL(k_bshuf_lz4_decode<2>, grid, dim3(64), 0, st, da);
+    else hipLaunchKernelGGL(k_bshuf_lz4_decode<4>, grid, dim3(64), 0, st, da);
+}
+
+static int ffs_submit_compressed_impl(ffs_stream* s, const void* const* chunks, const size_t* chunk_bytes,
+                                     uint32_t n_frames, int64_t first_frame_id) {
+    if (!s || !chunks || !chunk_bytes) return FFS_ERR_INVALID;
+    ffs_ctx* c = s->ctx;
+    if (s->busy) {
+        c->err = "stream already has a batch in flight: call ffs_wait() first";
+        return FFS_ERR_INVALID;
+    }
+    if (n_frames == 0 || n_frames > s->max_batch) {
+        c->err = "n_frames must be in 1..max_batch";
+        return FFS_ERR_INVALID;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    s->dev_input = false;
+    HIP_TRY(c, hipEventRecord(s->ev[0], s->st_up));
+    std::vector<size_t> base;
+    int rc = stage_chunks(s, chunks, chunk_bytes, n_frames, base);
+    if (rc != FFS_OK) return rc;
+    // The rest -- block index, table copy, decode kernel and the hot path's launches -- is enqueued by a
+    // helper thread, so that the caller gets its thread back while the index is built; ffs_wait joins it.
+    s->first_id = first_frame_id;
+    s->n_frames = n_frames;
+    mark_busy(s);
+    s->job_rc = FFS_OK;
+    s->job_err.clear();
+    const ffs_params snap = c->params;
+    std::vector<size_t> sizes(chunk_bytes, chunk_bytes + n_frames);
+    s->job = std::thread([s, c, snap, n_frames, base = std::move(base), sizes = std::move(sizes)]() {
+        if (hipSetDevice(c->device) != hipSuccess) {
+            s->job_rc = FFS_ERR_DEVICE;
+            s->job_err = "hipSetDevice failed on the stream's helper thread";
+            return;
+        }
+        int r = index_blocks(s, base, sizes, s->job_err);
+        if (r == FFS_OK) {
+            (void)hipGetLastError();
+            // the decode kernel runs with the dense kernels (in their order), behind the copies of its input
+            hipError_t e = hipSuccess;
+            hipStream_t dst = c->tune.decode_in_dense_stream ? s->st : s->st_up;
+            if (dst != s->st_up) {
+                e = hipEventRecord(s->ev[6], s->st_up);
+                if (e == hipSuccess) e = hipStreamWaitEvent(dst, s->ev[6], 0);
+            }
+            launch_decode(s, n_frames, dst);
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipEventRecord(s->ev[1], dst);
+            if (e != hipSuccess) {
+                s->job_err = std::string("decode launch: ") + hipGetErrorString(e);
+                r = FFS_ERR_DEVICE;
+            }
+        }
+        if (r == FFS_OK) {
+            r = enqueue_batch(s, s->d_img, c->L.pitch, c->L.frame_stride, n_frames, &snap);
+            if (r != FFS_OK) s->job_err = c->err;
+        }
+        s->job_rc = r;
+    });
+    return FFS_OK;
+}
+
+extern "C" int ffs_decode_only(ffs_stream* s, const void* const* chunks, const size_t* chunk_bytes, uint32_t n_frames,
+                               uint32_t iters, float* ms_decode, void* host_out) {
+    if (!s || !chunks || !chunk_bytes || iters == 0) return FFS_ERR_INVALID;
+    ffs_ctx* c = s->ctx;
+    if (s->busy || n_frames == 0 || n_frames > s->max_batch) {
+        c->err = "ffs_decode_only: stream busy or n_frames out of range";
+        return FFS_ERR_INVALID;
+    }
+    const Layout& L = c->L;
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<size_t> base;
+    int rc = stage_chunks(s, chunks, chunk_bytes, n_frames, base);
+    if (rc == FFS_OK) {
+        std::string err;
+        rc = index_blocks(s, base, std::vector<size_t>(chunk_bytes, chunk_bytes + n_frames), err);
+        if (rc != FFS_OK) c->err = err;
+    }
+    if (rc != FFS_OK) {
+        (void)hipStreamSynchronize(s->st_up);
+        return rc;
+    }
+    (void)hipGetLastError();
+    HIP_TRY(c, hipEventRecord(s->ev[0], s->st_up));
+    for (uint32_t i = 0; i < iters; ++i) launch_decode(s, n_frames, s->st_up);
+    HIP_TRY(c, hipEventRecord(s->ev[1], s->st_up));
+    HIP_TRY(c, hipGetLastError());
+    uint32_t flag = 0;
+    HIP_TRY(c, hipMemcpyAsync(&flag, s->d_overflow, 4, hipMemcpyDeviceToHost, s->st_up));
+    HIP_TRY(c, hipStreamSynchronize(s->st_up));
+    float ms = 0;
+    HIP_TRY(c, hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
+    if (ms_decode) *ms_decode = ms / iters;
+    if (host_out) {
+        const size_t row = (size_t)L.W * c->pixel_bytes;
+        HIP_TRY(c, hipMemcpy2D(host_out, row, s->d_img, L.pitch, row, (size_t)L.H * n_frames, hipMemcpyDeviceToHost));
+    }
+    if (flag & 4u) {
+        HIP_TRY(c, hipMemset(s->d_overflow, 0, 4));
+        c->err = "corrupt bitshuffle-LZ4 chunk: an LZ4 block did not decode to its block size";
+        return FFS_ERR_INVALID;
+    }
+    return FFS_OK;
+}
+
+extern "C" int ffs_submit_compressed(ffs_stream* s, const void* const* chunks, const size_t* chunk_bytes,
+                                     uint32_t n_frames, int64_t first_frame_id) {
+    return guarded(s ? s->ctx : nullptr, [&] { return ffs_submit_compressed_impl(s, chunks, chunk_bytes, n_frames, first_frame_id); });
+}

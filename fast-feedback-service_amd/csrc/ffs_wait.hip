@@ -1,0 +1,350 @@
+// ffs_wait.hip -- ffs_wait: the batch's counters and records are on the host when its last event has fired; frames that
+// did not fit the stream's lists are run again, results are assembled, and the accessors hand them out.
+// Reference: what follows the kernel in spotfinder/spotfinder.cc:887-1008 (D2H, ConnectedComponents, JSON fields).
+#include "ffs_internal.hpp"
+
+static int ensure_list_host(ffs_stream* s) {
+    ffs_ctx* c = s->ctx;
+    if (!s->h_list_k) {
+        const size_t bytes = (size_t)s->max_batch * s->cap * 4;
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&s->h_list_k), bytes, hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&s->h_list_i), bytes, hipHostMallocDefault));
+    }
+    return FFS_OK;
+}
+
+int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_results) {
+    if (!s) return FFS_ERR_INVALID;
+    ffs_ctx* c = s->ctx;
+    if (!s->busy) {
+        c->err = "ffs_wait: nothing submitted";
+        return FFS_ERR_INVALID;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (s->job.joinable()) {
+        s->job.join();
+        if (s->job_rc != FFS_OK) {
+            (void)hipStreamSynchronize(s->st_up);
+            mark_idle(s);
+            c->err = s->job_err;
+            return s->job_rc;
+        }
+    }
+    HIP_TRY(c, hipEventSynchronize(s->ev[4]));
+    const uint32_t n = s->n_frames;
+    const size_t B = s->max_batch;
+    const Layout& L = c->L;
+    const ffs_params& p = s->batch_params;
+    const uint32_t* h_ns = s->h_counts;
+    const uint32_t* h_nc = s->h_counts + B;
+    const uint32_t* h_sm = s->h_counts + 2 * B;
+    uint32_t overflow = s->h_counts[10 * B];
+    if (s->chain_mode) {  // k_frame_chain: one flag word per frame
+        overflow = 0;
+        for (uint32_t f = 0; f < n; ++f) overflow |= s->h_counts[10 * B + 1 + f];
+    }
+    mark_idle(s);
+    s->ovf.clear();
+    if (overflow) {
+        s->bits_dirty = true;
+        (void)hipMemsetAsync(s->d_overflow, 0, 4, s->st2);
+        (void)hipStreamSynchronize(s->st2);
+        if (overflow & 4u) {
+            c->err = "corrupt bitshuffle-LZ4 chunk: an LZ4 block did not decode to its block size";
+            return FFS_ERR_INVALID;
+        }
+        if (overflow & 8u) {
+            // more bright-window pixels than the list k_stream_u16 hands to k_bright_fix holds (a batch of
+            // saturated frames): run the batch again with those pixels marked in the plane as candidates for the exact kernel
+            // (threshold path 1; the extended algorithm: its plain first pass), which has no such list
+            s->force_path = 1;
+            int rc = enqueue_batch(s, s->cur_img, s->cur_pitch, s->cur_fstride, s->n_frames, &s->batch_params);
+            s->force_path = -1;
+            if (rc != FFS_OK) return rc;
+            return ffs_wait_impl(s, results, n_results);
+        }
+        // A frame with more strong pixels than the stream's lists hold (flag 1) or more components than its
+        // record buffers (flag 2) -- an ice ring, the direct beam.  The reference has no such limit (std::map of
+        // signals, connected_components.cc:24-32), so neither may the drop-in: the other frames of the batch are
+        // complete (lists and records are per frame), and each frame that did not fit is run again on its own on
+        // a one-frame stream with room for it (kept for the next time).
+        for (uint32_t f = 0; f < n; ++f) {
+            if (h_ns[f] <= s->cap && h_nc[f] <= s->max_comp) continue;
+            uint64_t need_cap = std::max<uint64_t>(h_ns[f], s->cap);
+            uint64_t need_comp = h_ns[f] > s->cap ? need_cap : std::max<uint64_t>(h_nc[f], s->max_comp);  // list truncated: count unknown
+            for (int attempt = 0;; ++attempt) {
+                if (s->big && (s->big->cap < need_cap || s->big->max_comp < need_comp)) {
+                    ffs_stream_destroy(s->big);
+                    s->big = nullptr;
+                }
+                if (!s->big) {
+                    const uint64_t npx = (uint64_t)L.W * L.H;
+                    const uint32_t bc = (uint32_t)std::min<uint64_t>(npx, need_cap + need_cap / 4 + 1024);
+                    const uint32_t bm = (uint32_t)std::min<uint64_t>(bc, need_comp + need_comp / 4 + 1024);
+                    int rc = stream_create_sized(c, 1, bc, bm, &s->big);
+                    if (rc != FFS_OK) return rc;  // a real out-of-memory
+                }
+                ffs_stream* b = s->big;
+                const uint8_t* img = static_cast<const uint8_t*>(s->cur_img) + (size_t)f * s->cur_fstride;
+                b->first_id = s->first_id + f;
+                b->dev_input = true;
+                b->ev1_pending = true;
+                int rc = enqueue_batch(b, img, s->cur_pitch, s->cur_fstride, 1, &s->batch_params);
+                if (rc != FFS_OK) return rc;
+                HIP_TRY(c, hipEventSynchronize(b->ev[4]));
+                const uint32_t b_ovf = b->chain_mode ? b->h_counts[10 * (size_t)b->max_batch + 1] : b->h_counts[10 * (size_t)b->max_batch];
+                if (b_ovf & 3u) {  // only the component count can still be short (it was a guess while the list was cut)
+                    (void)hipMemsetAsync(b->d_overflow, 0, 4, b->st2);
+                    (void)hipStreamSynchronize(b->st2);
+                    mark_idle(b);
+                    b->bits_dirty = true;
+                    need_cap = std::max<uint64_t>(need_cap, b->h_counts[0]);
+                    need_comp = std::max<uint64_t>(need_comp * 2, b->h_counts[b->max_batch]);
+                    if (attempt >= 4) {
+                        c->err = "a frame still overflows its one-frame stream";
+                        return FFS_ERR_OVERFLOW;
+                    }
+                    continue;
+                }
+                const ffs_frame_result* br = nullptr;
+                uint32_t bn = 0;
+                rc = ffs_wait_impl(b, &br, &bn);
+                if (rc != FFS_OK) return rc;
+                s->ovf.emplace_back();
+                OverflowFrame& o = s->ovf.back();
+                o.frame = f;
+                o.res = br[0];
+                o.boxes.assign(br[0].boxes, br[0].boxes + br[0].n_boxes);
+                if (br[0].reflections) o.refls.assign(br[0].reflections, br[0].reflections + br[0].n_reflections);
+                if (br[0].strong_k) {
+                    o.k.assign(br[0].strong_k, br[0].strong_k + br[0].num_strong_pixels);
+                    o.inten.assign(br[0].strong_intensity, br[0].strong_intensity + br[0].num_strong_pixels);
+                }
+                break;
+            }
+        }
+    }
+    auto overflow_frame = [&](uint32_t f) -> const OverflowFrame* {
+        for (const OverflowFrame& o : s->ovf)
+            if (o.frame == f) return &o;
+        return nullptr;
+    };
+    uint64_t total_recs = 0;
+    uint32_t max_ns = 0;
+    for (uint32_t f = 0; f < n; ++f) {
+        total_recs += std::min<uint32_t>(h_nc[f], s->max_comp);  // (the kernels never write more than max_comp per frame)
+        max_ns = std::max(max_ns, std::min<uint32_t>(h_ns[f], s->cap));
+    }
+    bool second_phase = false;
+    if (total_recs > s->spec_recs_copied) {  // more records than the speculative copy brought: fetch the rest
+        const size_t rb = sizeof(WireRec2);
+        HIP_TRY(c, hipMemcpyAsync(reinterpret_cast<uint8_t*>(s->h_recs) + s->spec_recs_copied * rb,
+                                  reinterpret_cast<const uint8_t*>(s->d_recs) + s->spec_recs_copied * rb,
+                                  (total_recs - s->spec_recs_copied) * rb, hipMemcpyDeviceToHost, s->st2));
+        second_phase = true;
+    }
+    s->spec_recs_per_frame = std::max<uint32_t>(s->spec_recs_per_frame,
+                                                (uint32_t)std::min<uint64_t>(s->max_comp, (total_recs / n + 1) * 5 / 4));
+    if (p.want_strong_list && max_ns) {
+        second_phase = true;
+        int rc = ensure_list_host(s);
+        if (rc != FFS_OK) return rc;
+        HIP_TRY(c, hipMemcpy2DAsync(s->h_list_k, (size_t)s->cap * 4, s->d_list_k, (size_t)s->cap * 4,
+                                    (size_t)max_ns * 4, n, hipMemcpyDeviceToHost, s->st2));
+        HIP_TRY(c, hipMemcpy2DAsync(s->h_list_i, (size_t)s->cap * 4, s->d_list_i, (size_t)s->cap * 4,
+                                    (size_t)max_ns * 4, n, hipMemcpyDeviceToHost, s->st2));
+    }
+    if (p.want_strong_mask) {
+        second_phase = true;
+        if (!s->h_mask)
+            HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&s->h_mask), B * (size_t)L.W * L.H, hipHostMallocDefault));
+        // the reference's full-mask D2H (spotfinder.cc:887-894), all frames of the batch in one 2D copy
+        HIP_TRY(c, hipMemcpy2DAsync(s->h_mask, L.W, s->d_sbytes, L.bpitch, L.W, (size_t)L.H * n,
+                                    hipMemcpyDeviceToHost, s->st2));
+    }
+    hipEvent_t last = s->ev[4];
+    if (second_phase) {
+        HIP_TRY(c, hipEventRecord(s->ev[5], s->st2));
+        HIP_TRY(c, hipEventSynchronize(s->ev[5]));
+        last = s->ev[5];
+    }
+    s->timings[0] = 0.0f;
+    if (!s->dev_input) (void)hipEventElapsedTime(&s->timings[0], s->ev[0], s->ev[1]);
+    (void)hipEventElapsedTime(&s->timings[1], s->ev[1], s->ev[2]);
+    (void)hipEventElapsedTime(&s->timings[2], s->ev[2], s->ev3_is_ev4 ? s->ev[4] : s->ev[3]);
+    (void)hipEventElapsedTime(&s->timings[3], s->ev3_is_ev4 ? s->ev[4] : s->ev[3], last);
+    (void)hipEventElapsedTime(&s->timings[4], s->dev_input ? s->ev[1] : s->ev[0], last);
+
+    // assemble: boxes = components surviving the min-size filter (connected_components.cc:122-135),
+    // reflections = components surviving filter_reflections (:207-236); both keep label order.
+    s->results.assign(n, ffs_frame_result{});
+    s->boxes.clear();
+    s->refls.clear();
+    s->boxes.reserve(total_recs);
+    if (p.want_reflections) s->refls.reserve(total_recs);
+    std::vector<size_t> box_at(n), refl_at(n);
+    const WireRec2* wrec = reinterpret_cast<const WireRec2*>(s->h_recs);
+    for (uint32_t f = 0; f < n; ++f) {
+        box_at[f] = s->boxes.size();
+        refl_at[f] = s->refls.size();
+        const uint32_t nc = std::min<uint32_t>(h_nc[f], s->max_comp);
+        if (s->chain_mode) wrec = reinterpret_cast<const WireRec2*>(s->h_recs) + (size_t)f * s->max_comp;  // k_frame_chain: every frame has its own record area
+        if (const OverflowFrame* o = overflow_frame(f)) {  // re-run on the one-frame stream: skip the cut records
+            wrec += nc;
+            s->boxes.insert(s->boxes.end(), o->boxes.begin(), o->boxes.end());
+            if (p.want_reflections) s->refls.insert(s->refls.end(), o->refls.begin(), o->refls.end());
+            continue;
+        }
+        for (uint32_t q = 0; q < nc; ++q, ++wrec) {
+            const uint32_t npx = wrec->npx_flags & 0x3FFFFFFFu, flags = wrec->npx_flags >> 30;
+            if (p.min_spot_size == 0 || npx >= p.min_spot_size)
+                s->boxes.push_back(ffs_box{wrec->x_min, wrec->y_min, wrec->x_max, wrec->y_max, (int32_t)npx});
+            if (p.want_reflections && flags == 0) {
+                ffs_reflection r{};
+                r.x_min = wrec->x_min; r.x_max = wrec->x_max; r.y_min = wrec->y_min; r.y_max = wrec->y_max;
+                r.z_min = 0; r.z_max = 0;
+                r.num_pixels = (int32_t)npx;
+                r.com_x = wrec->com_x; r.com_y = wrec->com_y; r.com_z = 0.5f;  // z = 0 for a single frame
+                r.peak_x = wrec->peak_x; r.peak_y = wrec->peak_y; r.peak_z = 0;
+                r.peak_intensity = wrec->peak_intensity;
+                r.peak_centroid_distance = wrec->peak_centroid_distance;
+                r.flags = 0;
+                r.sum_intensity = wrec->sum_intensity;
+                s->refls.push_back(r);
+            }
+        }
+    }
+    for (uint32_t f = 0; f < n; ++f) {
+        ffs_frame_result& r = s->results[f];
+        const uint32_t* sm = h_sm + (size_t)f * 8;
+        r.frame_id = s->first_id + f;
+        r.num_strong_pixels = h_ns[f];
+        r.num_strong_pixels_filtered = sm[1];
+        r.n_components = h_nc[f];
+        r.n_boxes = sm[0];
+        r.boxes = s->boxes.data() + box_at[f];
+        r.n_reflections = p.want_reflections ? sm[2] : 0;
+        r.reflections = p.want_reflections ? s->refls.data() + refl_at[f] : nullptr;
+        r.n_filtered_size = sm[3];
+        r.n_filtered_sep = sm[4];
+        if (p.want_strong_list) {
+            r.strong_k = s->h_list_k ? s->h_list_k + (size_t)f * s->cap : nullptr;
+            r.strong_intensity = s->h_list_i ? s->h_list_i + (size_t)f * s->cap : nullptr;
+        }
+        if (p.want_strong_mask) r.strong_mask = s->h_mask + (size_t)f * L.W * L.H;
+        if (const OverflowFrame* o = overflow_frame(f)) {
+            const ffs_frame_result& b = o->res;
+            r.num_strong_pixels = b.num_strong_pixels;
+            r.num_strong_pixels_filtered = b.num_strong_pixels_filtered;
+            r.n_components = b.n_components;
+            r.n_boxes = b.n_boxes;
+            r.n_reflections = p.want_reflections ? b.n_reflections : 0;
+            r.n_filtered_size = b.n_filtered_size;
+            r.n_filtered_sep = b.n_filtered_sep;
+            if (p.want_strong_list) {
+                r.strong_k = o->k.data();
+                r.strong_intensity = o->inten.data();
+            }
+        }
+    }
+    if (results) *results = s->results.data();
+    if (n_results) *n_results = n;
+    return FFS_OK;
+}
+
+extern "C" int ffs_stream_batch_arrays(ffs_stream* s, const ffs_box** boxes, uint32_t* n_boxes,
+                                       const ffs_reflection** refls, uint32_t* n_refls) {
+    if (!s) return FFS_ERR_INVALID;
+    if (boxes) *boxes = s->boxes.data();
+    if (n_boxes) *n_boxes = (uint32_t)s->boxes.size();
+    if (refls) *refls = s->refls.data();
+    if (n_refls) *n_refls = (uint32_t)s->refls.size();
+    return FFS_OK;
+}
+
+extern "C" int ffs_stream_timings(ffs_stream* s, float ms[5]) {
+    if (!s || !ms) return FFS_ERR_INVALID;
+    std::memcpy(ms, s->timings, sizeof(s->timings));
+    return FFS_OK;
+}
+
+extern "C" int ffs_stream_spot_centres(ffs_stream* s, float* rows4, uint32_t cap, uint32_t* n_written) {
+    if (!s || !rows4) return FFS_ERR_INVALID;
+    if (s->busy) {
+        s->ctx->err = "ffs_stream_spot_centres: a batch is in flight";
+        return FFS_ERR_INVALID;
+    }
+    uint32_t n = 0;
+    uint64_t wanted = 0;
+    for (const ffs_frame_result& r : s->results) {
+        // the id's low 32 bits as a bit pattern: as a float VALUE ids would collide from 2^24 on
+        const uint32_t id_bits = (uint32_t)((uint64_t)r.frame_id & 0xFFFFFFFFull);
+        float id;
+        std::memcpy(&id, &id_bits, 4);
+        wanted += r.n_reflections;
+        for (uint32_t q = 0; q < r.n_reflections && n < cap; ++q, ++n) {
+            float* row = rows4 + (size_t)n * 4;
+            row[0] = id;
+            row[1] = r.reflections[q].com_x;
+            row[2] = r.reflections[q].com_y;
+            row[3] = r.reflections[q].com_z;
+        }
+    }
+    // last row: (rows written, rows wanted) as uint32 bit patterns -- wanted > written tells the receiver
+    // that `cap` was too small (nothing is dropped silently)
+    float* last = rows4 + (size_t)cap * 4;
+    const uint32_t tail[4] = {n, (uint32_t)std::min<uint64_t>(wanted, 0xFFFFFFFFull), 0u, 0u};
+    std::memcpy(last, tail, sizeof(tail));
+    if (n_written) *n_written = n;
+    return wanted > n ? FFS_ERR_OVERFLOW : FFS_OK;
+}
+
+extern "C" int ffs_stream_debug_planes(ffs_stream* s, const uint8_t** strong_bytes, size_t* mask_pitch,
+                                       size_t* mask_fstride) {
+    if (!s) return FFS_ERR_INVALID;
+    if (strong_bytes) *strong_bytes = s->d_sbytes;
+    if (mask_pitch) *mask_pitch = s->ctx->L.bpitch;
+    if (mask_fstride) *mask_fstride = s->ctx->L.bytes_frame_stride;
+    return FFS_OK;
+}
+
+extern "C" int ffs_stream_debug_bitplane(ffs_stream* s, uint32_t frame, int which, uint8_t* host_out) {
+    if (!s || !host_out || which < 0 || which > 2) return FFS_ERR_INVALID;
+    ffs_ctx* c = s->ctx;
+    const Layout& L = c->L;
+    if (s->busy || frame >= s->max_batch) {
+        c->err = "ffs_stream_debug_bitplane: stream busy or frame out of range";
+        return FFS_ERR_INVALID;
+    }
+    const uint8_t* src = which == 0 ? s->d_bits : which == 1 ? s->d_dplane : s->d_eplane;
+    if (!src) {
+        c->err = "ffs_stream_debug_bitplane: that plane exists only after an extended-dispersion batch";
+        return FFS_ERR_INVALID;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (which == 0 && s->bits_cleared && !s->dense_valid) {
+        // the compaction consumed (and cleared) the plane and nobody asked for the byte mask: the strong-pixel list has them
+        const uint32_t ns = std::min<uint32_t>(s->h_counts[frame], s->cap);
+        std::vector<uint32_t> ks(ns);
+        if (ns) HIP_TRY(c, hipMemcpy(ks.data(), s->d_list_k + (size_t)frame * s->cap, (size_t)ns * 4, hipMemcpyDeviceToHost));
+        std::memset(host_out, 0, (size_t)L.W * L.H);
+        for (uint32_t k : ks) host_out[k] = 1;
+        return FFS_OK;
+    }
+    if (which == 0 && s->bits_cleared) {
+        // the compaction consumed (and cleared) the plane; the byte mask holds the same pixels
+        HIP_TRY(c, hipMemcpy2D(host_out, L.W, s->d_sbytes + (size_t)frame * L.bytes_frame_stride, L.bpitch, L.W, L.H,
+                               hipMemcpyDeviceToHost));
+        return FFS_OK;
+    }
+    std::vector<uint8_t> packed(L.plane_frame_stride);
+    HIP_TRY(c, hipMemcpy(packed.data(), src + (size_t)frame * L.plane_frame_stride, packed.size(), hipMemcpyDeviceToHost));
+    for (int y = 0; y < L.H; ++y)
+        for (int x = 0; x < L.W; ++x)
+            host_out[(size_t)y * L.W + x] = (packed[(size_t)y * L.mpitch + (x >> 3)] >> (x & 7)) & 1u;
+    return FFS_OK;
+}
+
+extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_results) {
+    return guarded(s ? s->ctx : nullptr, [&] { return ffs_wait_impl(s, results, n_results); });
+}

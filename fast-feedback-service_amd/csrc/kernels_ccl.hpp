@@ -1,124 +1,17 @@
-// kernels_ccl.hpp (included by ffs_api.hip) -- strong-pixel compaction and 2D/3D connected components on gfx950.
+// kernels_ccl.hpp (included by ffs_submit.hip only) -- strong-pixel compaction and 2D connected components as
+// grid-wide kernels on gfx950: the path of frames too tall for k_frame_chain (kernels_chain.hpp) and the A/B
+// partner of that kernel (ffs_ctx_set_tuning "sparse_stage" = 1).
 //
-// Replaces the reference's host stage (spotfinder/connected_components/connected_components.cc):
-// a std::map of strong pixels, a Boost adjacency_list with edges to k+1 and k+width, and
-// boost::connected_components (DFS => components numbered by their minimum vertex).  Here:
-//   k_emit_list                : strong bit plane -> per-frame list sorted by linear index
-//                                (popcount + wave/block prefix sums; no sort needed)
-//   k_union                    : lock-free union-find, union-by-minimum-index (atomicMin hooks),
-//                                neighbours found by binary search in the sorted list
-//   k_reduce                   : per-component bbox / sums / peak with integer atomics
-//   k_finalize                 : centre of mass, peak-centroid distance, filters
-// The same kernels serve the 3D case (a z-stack of per-frame lists, one extra edge to the same
-// linear index in the next slice, connected_components.cc:352-370).
+// Replaces the reference's host stage (spotfinder/connected_components/connected_components.cc:17-139,207-266):
+//   k_emit_list_w     : strong bit plane -> per-frame list sorted by linear index, runs linked, byte mask 1s
+//   k_union<false>    : kernels_uf.hpp (vertical edges + the row-wrap edge)
+//   k_reduce_roots    : per-component bbox / sums / peak, integer accumulators at the root's list index
+//   k_finalize_roots  : centre of mass, peak-centroid distance, filters, 40-byte wire records
 #pragma once
-#include "ffs_device.h"
+#include "kernels_uf.hpp"
 
 namespace ffsamd {
 
-// ---- block-wide exclusive prefix sum (256 or 1024 threads) ---------------------------------------
-template <int NT>
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_wave, uint32_t& total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += t;
-    }
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < NT / 64; ++w) {
-        const uint32_t c = s_wave[w];
-        if (w < wave) base += c;
-        tot += c;
-    }
-    __syncthreads();
-    total = tot;
-    return base + inc - v;
-}
-
-// ---- compaction ------------------------------------------------------------------------------------
-
-// One block per (tile, frame): bits -> (k, intensity) in raster order; parent[i] = i.
-// The tile's offset in the frame's list is the sum of the counts of the tiles before it: every block
-// adds them up itself (at most a few hundred words from L2) instead of waiting for a scan kernel.
-template <typename PixelT>
-__global__ __launch_bounds__(256) void k_emit_list(const CclArgs a) {
-    __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_base;
-    const int tile = blockIdx.x, frame = blockIdx.y;
-    const uint32_t* counts = a.tile_counts + (uint64_t)frame * a.n_tiles;
-    const uint32_t count = counts[tile];
-    const int y0 = tile * kTileRows;
-    const int rows = min(kTileRows, a.H - y0);
-    uint32_t* row_off = a.row_off + (uint64_t)frame * (a.H + 1);
-    {
-        uint32_t part = 0;
-        for (int t = threadIdx.x; t < tile; t += 256) part += counts[t];
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
-        if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = part;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t base = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-            s_base = base;
-            if (tile == a.n_tiles - 1) {  // the last tile knows the frame's total
-                const uint32_t total = base + count;
-                a.num_strong[frame] = total;
-                row_off[a.H] = min(total, a.cap);
-                if (total > a.cap) atomicOr(a.overflow, 1u);
-            }
-        }
-        __syncthreads();
-    }
-    const uint32_t tile_base = s_base;
-    if (count == 0) {  // block-uniform: empty rows all start where the tile starts
-        if ((int)threadIdx.x < rows) row_off[y0 + threadIdx.x] = min(tile_base, a.cap);
-        return;
-    }
-    const int dpr = a.mpitch >> 2;
-    const int ndw = rows * dpr;
-    uint32_t* words = reinterpret_cast<uint32_t*>(
-        a.bits + (uint64_t)frame * a.plane_frame_stride + (uint64_t)y0 * a.mpitch);
-    const uint8_t* img = (const uint8_t*)a.image + (uint64_t)frame * a.frame_stride;
-    uint32_t* lk = a.list_k + (uint64_t)frame * a.cap;
-    uint32_t* li = a.list_i + (uint64_t)frame * a.cap;
-    uint32_t* par = a.parent + (uint64_t)frame * a.cap;
-    uint8_t* sbytes = a.strong_bytes + (uint64_t)frame * a.bytes_frame_stride;
-    // each thread owns a contiguous run of words, so ONE block scan gives raster order
-    const int per = (ndw + 255) / 256;
-    const int g0 = min((int)threadIdx.x * per, ndw), g1 = min(g0 + per, ndw);
-    uint32_t mine = 0;
-    for (int g = g0; g < g1; ++g) mine += __popc(words[g]);
-    uint32_t total;
-    uint32_t at = tile_base + block_exclusive_scan<256>(mine, s_wave, total);
-    for (int g = g0; g < g1; ++g) {
-        uint32_t w = words[g];
-        if (w && a.clear_bits) words[g] = 0;
-        const int row = g / dpr;
-        if (g - row * dpr == 0) row_off[y0 + row] = min(at, a.cap);  // first word of an image row
-        const int xb = (g - row * dpr) * 32;
-        const int y = y0 + row;
-        while (w) {
-            const int bit = __ffs(w) - 1;
-            w &= w - 1;
-            const int x = xb + bit;
-            if (at < a.cap) {
-                lk[at] = (uint32_t)y * (uint32_t)a.W + (uint32_t)x;
-                li[at] = *reinterpret_cast<const PixelT*>(img + (uint64_t)y * a.pitch
-                                                           + (uint64_t)x * sizeof(PixelT));
-                par[at] = at;
-            }
-            if (a.dense_bytes) sbytes[(uint64_t)y * a.bpitch + (uint32_t)x] = 1;  // the reference kernel's result_strong byte
-            ++at;
-        }
-    }
-}
-template __global__ void k_emit_list<uint16_t>(const CclArgs);
-template __global__ void k_emit_list<uint32_t>(const CclArgs);
 
 
 // The same compaction with ONE WAVE per (tile, frame).  The stage is a chain of dependent memory round
@@ -296,342 +189,6 @@ __global__ __launch_bounds__(64) void k_emit_list_w(const CclArgs a) {
 template __global__ void k_emit_list_w<uint16_t>(const CclArgs);
 template __global__ void k_emit_list_w<uint32_t>(const CclArgs);
 
-// ---- union-find --------------------------------------------------------------------------------------
-
-__device__ __forceinline__ uint32_t ld_parent(const uint32_t* p) {
-    // agent-scope load: bypasses this CU's L1, which other CUs' atomics never refresh
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t v) {
-    uint32_t p = ld_parent(parent + v);
-    while (p != v) {
-        v = p;
-        p = ld_parent(parent + v);
-    }
-    return v;
-}
-
-// Union by minimum index: the root of every tree is its smallest member, so
-// label order = order of the minimum vertex = Boost's DFS discovery order.
-__device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t b) {
-    for (;;) {
-        a = uf_find(parent, a);
-        b = uf_find(parent, b);
-        if (a == b) return;
-        if (a > b) {
-            const uint32_t t = a;
-            a = b;
-            b = t;
-        }
-        const uint32_t old = atomicMin(parent + b, a);  // hook the larger root under the smaller
-        if (old == b) return;
-        b = old;  // somebody else re-parented b meanwhile: retry from there
-    }
-}
-
-// 2D pre-pass: entries whose left neighbour in the list is k - 1 belong to the same horizontal run (the
-// reference's k + 1 edge, row wrap included).  Hook each of them to an earlier member of its run with
-// a plain store -- no atomics, no contention -- so that k_union only has the vertical edges left, and
-// of those only one per pair of overlapping runs.  (The backward walk is capped: pointing at any
-// earlier member of the run keeps the forest valid, parents always being smaller indices.)
-__global__ __launch_bounds__(256) void k_link_runs(const SegArgs a) {
-    const int seg = blockIdx.y;
-    const uint32_t n = min(a.seg_n[seg], (uint32_t)a.seg_stride);
-    const uint32_t* k = a.list_k + (uint64_t)seg * a.seg_stride;
-    uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        if (i == 0 || k[i - 1] + 1 != k[i]) continue;  // a run start keeps parent[i] = i
-        uint32_t j = i - 1;
-        for (int steps = 0; steps < 16 && j > 0 && k[j - 1] + 1 == k[j]; ++steps) --j;
-        parent[i] = j;
-    }
-}
-
-template <bool IS3D>
-__global__ __launch_bounds__(256) void k_union(const SegArgs a) {
-    const int seg = blockIdx.y;
-    const uint32_t n = min(a.seg_n[seg], (uint32_t)a.seg_stride);
-    const uint32_t* k = a.list_k + (uint64_t)seg * a.seg_stride;
-    uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
-    if (!IS3D && a.zero_counts) {
-        for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < a.zero_per_seg; t += gridDim.x * 256)
-            a.zero_counts[(uint64_t)seg * a.zero_per_seg + t] = 0;
-        if (seg == 0 && blockIdx.x == 0 && threadIdx.x == 0 && a.zero_word) *a.zero_word = 0;
-    }
-    uint32_t z = 0;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        uint32_t s_end = n, nb = 0, ne = 0;
-        if (IS3D) {
-            // slice of entry i (slices ascending; advance monotonically within this thread)
-            if (a.zs) z = a.zs[i];
-            while (a.slice_begin[z + 1] <= i) ++z;
-            s_end = a.slice_begin[z + 1];
-            if ((int)z + 1 < a.n_slices) { nb = a.slice_begin[z + 1]; ne = a.slice_begin[z + 2]; }
-        }
-        const uint32_t ki = k[i];
-        // right neighbour: k + 1, with NO row-end check (connected_components.cc:62-70)
-        const bool runs_linked = !IS3D && a.runs_linked;  // k_link_runs did these edges already
-        if (!runs_linked && i + 1 < s_end && k[i + 1] == ki + 1) uf_union(parent, i, i + 1);
-        // runs_linked == 2: k_emit_list_w linked the runs inside each image row; the edge from a row's last
-        // pixel to the next row's first (the reference's k + 1 without a row-end check) is left to do here
-        if (!IS3D && a.runs_linked == 2 && i > 0 && k[i - 1] + 1 == ki && ki % a.W == 0) uf_union(parent, i - 1, i);
-        // neighbour below: k + width (:63, :73-78); it lives in the next image row, whose
-        // list range is known from the compaction (row_off), so the search is a few steps
-        {
-            uint32_t lo = i + 1, hi = min(s_end, i + 1 + a.W);
-            if (!IS3D && a.row_off) {
-                const uint32_t* ro = a.row_off + (uint64_t)seg * (a.H + 1);
-                const uint32_t y = ki / a.W;
-                if (y + 1 < a.H) { lo = max(lo, ro[y + 1]); hi = min(hi, ro[y + 2]); } else hi = lo;
-            }
-            const uint32_t key = ki + a.W;
-            while (lo < hi) {
-                const uint32_t mid = lo + ((hi - lo) >> 1);
-                if (k[mid] < key) lo = mid + 1; else hi = mid;
-            }
-            if (lo < s_end && k[lo] == key) {
-                // with the runs linked, one edge per pair of overlapping runs is enough: the leftmost
-                // overlapping pair has a run start on one side (if neither pixel starts its run, the
-                // pair one column to the left is adjacent too)
-                const bool needed = !runs_linked || i == 0 || k[i - 1] + 1 != ki || lo == 0 || k[lo - 1] + 1 != key;
-                if (needed) uf_union(parent, i, lo);
-            }
-        }
-        if (IS3D && nb < ne) {  // same pixel in the next slice (:352-370)
-            uint32_t lo = nb, hi = ne;
-            while (lo < hi) {
-                const uint32_t mid = lo + ((hi - lo) >> 1);
-                if (k[mid] < ki) lo = mid + 1; else hi = mid;
-            }
-            if (lo < ne && k[lo] == ki) uf_union(parent, i, lo);
-        }
-    }
-}
-template __global__ void k_union<false>(const SegArgs);
-template __global__ void k_union<true>(const SegArgs);
-
-// The same numbering with several workgroups per segment (2D batches: a frame's list can hold 10^5
-// entries, and one workgroup walking it was 24-85 us): kLabelParts parts per segment, k_count_roots
-// counts the roots of every part, k_label_parts adds up the counts of the parts before its own and
-// numbers its roots.  Output identical to k_label.
-constexpr int kLabelParts = 32;
-
-__global__ __launch_bounds__(256) void k_count_roots(const SegArgs a) {
-    __shared__ uint32_t s_wave[4];
-    const int seg = blockIdx.y, part = blockIdx.x;
-    const uint32_t n = min(a.seg_n[seg], (uint32_t)a.seg_stride);
-    const uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
-    const uint32_t per = (n + kLabelParts - 1) / kLabelParts;
-    const uint32_t p0 = min((uint32_t)part * per, n), p1 = min(p0 + per, n);
-    uint32_t mine = 0;
-    for (uint32_t i = p0 + threadIdx.x; i < p1; i += 256) mine += parent[i] == i ? 1u : 0u;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
-    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) a.part_roots[(uint64_t)seg * kLabelParts + part] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-}
-
-__global__ __launch_bounds__(256) void k_label_parts(const SegArgs a) {
-    __shared__ uint32_t s_wave[4];
-    const int seg = blockIdx.y, part = blockIdx.x;
-    const uint32_t n = min(a.seg_n[seg], (uint32_t)a.seg_stride);
-    const uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
-    uint32_t* comp_id = a.comp_id + (uint64_t)seg * a.seg_stride;
-    CompAcc* acc = a.acc + (uint64_t)seg * a.max_comp;
-    const uint32_t* counts = a.part_roots + (uint64_t)seg * kLabelParts;
-    uint32_t before = 0, total = 0;
-    for (int q = 0; q < kLabelParts; ++q) {  // 32 words, the same for every thread
-        const uint32_t v = counts[q];
-        if (q < part) before += v;
-        total += v;
-    }
-    const uint32_t per = (n + kLabelParts - 1) / kLabelParts;
-    const uint32_t p0 = min((uint32_t)part * per, n), p1 = min(p0 + per, n);
-    // each thread owns a contiguous run of the part, so one block scan numbers the roots in list order
-    const uint32_t tper = (p1 - p0 + 255u) / 256u;
-    const uint32_t b0 = min(p0 + threadIdx.x * tper, p1), b1 = min(b0 + tper, p1);
-    uint32_t mine = 0;
-    for (uint32_t i = b0; i < b1; ++i) mine += parent[i] == i ? 1u : 0u;
-    uint32_t running;
-    uint32_t c = before + block_exclusive_scan<256>(mine, s_wave, running);
-    for (uint32_t i = b0; i < b1; ++i) {
-        if (parent[i] != i) continue;
-        comp_id[i] = c;
-        if (c < a.max_comp) {
-            CompAcc z;
-            z.sum_i = z.sum_xi = z.sum_yi = z.sum_zi = 0ull;
-            z.peak = 0ull;
-            z.x_min = 0xFFFFFFFFu; z.x_max = 0u;
-            z.y_min = 0xFFFFFFFFu; z.y_max = 0u;
-            z.z_min = 0x7FFFFFFF; z.z_max = (int32_t)0x80000000;
-            z.num_pixels = 0u;
-            z.root = i;
-            acc[c] = z;
-        }
-        ++c;
-    }
-    if (part == 0 && threadIdx.x == 0) {
-        a.n_comp[seg] = total;
-        if (total > a.max_comp) atomicOr(a.overflow, 2u);
-        uint32_t* sm = a.summary + (uint64_t)seg * 8;
-        for (int q = 0; q < 8; ++q) sm[q] = 0;
-    }
-}
-
-// Per-component sums.  Entries of one component sit close together in the sorted list, so each
-// block first reduces a chunk of 512 consecutive entries into LDS accumulators (components whose
-// root lies inside the chunk have consecutive numbers) and then issues ONE set of global atomics
-// per component instead of one per pixel; entries whose root lies before the chunk go straight
-// to global atomics.  All sums are integers: the result does not depend on arrival order.
-constexpr int kReduceChunk = 512;
-
-struct LdsAcc {
-    unsigned long long sum_i, sum_xi, sum_yi, sum_zi, peak;
-    uint32_t x_min, x_max, y_min, y_max;
-    int32_t z_min, z_max;
-    uint32_t num_pixels, pad;
-};
-
-template <bool IS3D>
-__global__ __launch_bounds__(256) void k_reduce(const SegArgs a) {
-    __shared__ LdsAcc s_acc[kReduceChunk];
-    __shared__ uint32_t s_cmin, s_cmax;
-    const int seg = blockIdx.y;
-    const uint32_t n = min(a.seg_n[seg], (uint32_t)a.seg_stride);
-    const uint32_t* k = a.list_k + (uint64_t)seg * a.seg_stride;
-    const uint32_t* inten = a.list_i + (uint64_t)seg * a.seg_stride;
-    uint32_t* parent = a.parent + (uint64_t)seg * a.seg_stride;
-    const uint32_t* comp_id = a.comp_id + (uint64_t)seg * a.seg_stride;
-    CompAcc* acc = a.acc + (uint64_t)seg * a.max_comp;
-    const int tid = threadIdx.x;
-
-    for (uint32_t base = blockIdx.x * kReduceChunk; base < n; base += gridDim.x * kReduceChunk) {
-        if (tid == 0) { s_cmin = 0xFFFFFFFFu; s_cmax = 0u; }
-        __syncthreads();
-        // 2D: consecutive-k entries form a horizontal run = one component.  The thread of a run's first
-        // entry (runs are also cut every 32 entries and at the chunk start) owns the whole segment: one
-        // root chase and one set of atomics per segment instead of per pixel; the other threads idle.
-        uint32_t ci[2], ri[2], seg_end[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const uint32_t e = (uint32_t)tid + 256u * q;
-            const uint32_t i = base + e;
-            ci[q] = 0xFFFFFFFFu;
-            ri[q] = 0;
-            seg_end[q] = i;
-            const bool owner = i < n && (IS3D || (e & 31u) == 0u || k[i - 1] + 1 != k[i]);
-            if (owner) {
-                uint32_t j = i + 1;
-                if (!IS3D)
-                    while (j < n && (j - base) < (uint32_t)kReduceChunk && ((j - base) & 31u) != 0u && k[j] == k[j - 1] + 1) ++j;
-                seg_end[q] = j;
-                ri[q] = uf_find(parent, i);  // no separate flatten pass: chase to the root here
-                ci[q] = comp_id[ri[q]];
-                if (ri[q] >= base && ci[q] < a.max_comp) {  // root inside this chunk
-                    atomicMin(&s_cmin, ci[q]);
-                    atomicMax(&s_cmax, ci[q]);
-                }
-            }
-        }
-        __syncthreads();
-        const uint32_t cmin = s_cmin, cmax = s_cmax;
-        const uint32_t nslots = cmin <= cmax ? cmax - cmin + 1 : 0;  // <= kReduceChunk
-        for (uint32_t sl = tid; sl < nslots; sl += 256) {
-            LdsAcc z;
-            z.sum_i = z.sum_xi = z.sum_yi = z.sum_zi = z.peak = 0ull;
-            z.x_min = 0xFFFFFFFFu; z.x_max = 0u; z.y_min = 0xFFFFFFFFu; z.y_max = 0u;
-            z.z_min = 0x7FFFFFFF; z.z_max = (int32_t)0x80000000;
-            z.num_pixels = 0; z.pad = 0;
-            s_acc[sl] = z;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const uint32_t i0 = base + tid + 256 * q;
-            const uint32_t c = ci[q];
-            if (seg_end[q] == i0 || c >= a.max_comp) continue;  // not a segment owner (or overflowing label)
-            // the segment's sums in registers
-            uint32_t x_min = 0xFFFFFFFFu, x_max = 0u, y_min = 0xFFFFFFFFu, y_max = 0u, npx = 0u;
-            int32_t z_min = 0x7FFFFFFF, z_max = (int32_t)0x80000000;
-            unsigned long long s_i = 0, s_xi = 0, s_yi = 0, s_zi = 0, pk = 0;
-            for (uint32_t i = i0; i < seg_end[q]; ++i) {
-                const uint32_t ki = k[i];
-                const uint32_t y = ki / a.W, x = ki - y * a.W;
-                const unsigned long long I = inten[i];
-                uint32_t z = 0;
-                if (IS3D) {
-                    int lo = 0, hi = a.n_slices;  // slice containing entry i
-                    while (hi - lo > 1) {
-                        const int mid = (lo + hi) >> 1;
-                        if (a.slice_begin[mid] <= i) lo = mid; else hi = mid;
-                    }
-                    z = (uint32_t)lo;
-                }
-                x_min = min(x_min, x); x_max = max(x_max, x);
-                y_min = min(y_min, y); y_max = max(y_max, y);
-                z_min = min(z_min, (int32_t)z); z_max = max(z_max, (int32_t)z);
-                ++npx;
-                s_i += I;
-                s_xi += (2ull * x + 1ull) * I;
-                s_yi += (2ull * y + 1ull) * I;
-                s_zi += (2ull * z + 1ull) * I;
-                // highest intensity, ties -> smallest (z, y, x) = smallest list index
-                // (connected_components.hpp:125-170, connected_components.cc:143-157)
-                pk = max(pk, (I << 32) | (unsigned long long)(0xFFFFFFFFu - i));
-            }
-            if (ri[q] >= base) {
-                LdsAcc* r = &s_acc[c - cmin];
-                atomicMin(&r->x_min, x_min); atomicMax(&r->x_max, x_max);
-                atomicMin(&r->y_min, y_min); atomicMax(&r->y_max, y_max);
-                if (IS3D) {
-                    atomicMin(&r->z_min, z_min); atomicMax(&r->z_max, z_max);
-                    atomicAdd(&r->sum_zi, s_zi);
-                }
-                atomicAdd(&r->num_pixels, npx);
-                atomicAdd(&r->sum_i, s_i);
-                atomicAdd(&r->sum_xi, s_xi);
-                atomicAdd(&r->sum_yi, s_yi);
-                atomicMax(&r->peak, pk);
-            } else {
-                CompAcc* r = acc + c;
-                atomicMin(&r->x_min, x_min); atomicMax(&r->x_max, x_max);
-                atomicMin(&r->y_min, y_min); atomicMax(&r->y_max, y_max);
-                if (IS3D) {
-                    atomicMin(&r->z_min, z_min); atomicMax(&r->z_max, z_max);
-                    atomicAdd(&r->sum_zi, s_zi);
-                }
-                atomicAdd(&r->num_pixels, npx);
-                atomicAdd(&r->sum_i, s_i);
-                atomicAdd(&r->sum_xi, s_xi);
-                atomicAdd(&r->sum_yi, s_yi);
-                atomicMax(&r->peak, pk);
-            }
-        }
-        __syncthreads();
-        for (uint32_t sl = tid; sl < nslots; sl += 256) {
-            const LdsAcc v = s_acc[sl];
-            if (v.num_pixels == 0) continue;
-            CompAcc* r = acc + cmin + sl;
-            atomicMin(&r->x_min, v.x_min); atomicMax(&r->x_max, v.x_max);
-            atomicMin(&r->y_min, v.y_min); atomicMax(&r->y_max, v.y_max);
-            if (IS3D) {
-                atomicMin(&r->z_min, v.z_min); atomicMax(&r->z_max, v.z_max);
-                atomicAdd(&r->sum_zi, v.sum_zi);
-            }
-            atomicAdd(&r->num_pixels, v.num_pixels);
-            atomicAdd(&r->sum_i, v.sum_i);
-            atomicAdd(&r->sum_xi, v.sum_xi);
-            atomicAdd(&r->sum_yi, v.sum_yi);
-            atomicMax(&r->peak, v.peak);
-        }
-        __syncthreads();
-    }
-}
-template __global__ void k_reduce<false>(const SegArgs);
-
-
 // ---- 2D: reduction with the accumulators at the root (no numbering pass) ---------------------------------
 // k_union leaves every component as a tree whose root is its smallest list index.  k_reduce_roots adds
 // every horizontal run into the accumulator AT that index (LDS first when the root lies in the same chunk
@@ -639,7 +196,6 @@ template __global__ void k_reduce<false>(const SegArgs);
 // in list order = label order (connected_components.cc:91,242: Boost numbers components by their first
 // vertex), each chunk adding up the root counts of the chunks before it.  Replaces k_count_roots +
 // k_label_parts + k_reduce + k_finalize for single frames.
-constexpr int kRootChunk = 512;
 
 struct LdsAcc2 {
     unsigned long long sum_i, sum_xi, sum_yi, peak;
@@ -840,78 +396,5 @@ __global__ __launch_bounds__(256) void k_finalize_roots(const SegArgs a) {
         __syncthreads();
     }
 }
-
-template <bool IS3D>
-__global__ __launch_bounds__(256) void k_finalize(const SegArgs a) {
-    const int seg = blockIdx.y;
-    const uint32_t nc = min(a.n_comp[seg], a.max_comp);
-    const uint32_t* k = a.list_k + (uint64_t)seg * a.seg_stride;
-    const CompAcc* acc = a.acc + (uint64_t)seg * a.max_comp;
-    __shared__ uint32_t s_base;
-    if (threadIdx.x == 0) {
-        uint32_t b = 0;
-        for (int q = 0; q < seg; ++q) b += min(a.n_comp[q], a.max_comp);
-        s_base = b;
-    }
-    __syncthreads();
-    ReflOut* recs = reinterpret_cast<ReflOut*>(a.recs) + s_base;
-    uint32_t* sm = a.summary + (uint64_t)seg * 8;
-    for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < nc; c += gridDim.x * 256) {
-        const CompAcc r = acc[c];
-        ReflOut o;
-        o.x_min = r.x_min; o.x_max = r.x_max; o.y_min = r.y_min; o.y_max = r.y_max;
-        o.z_min = IS3D ? r.z_min : 0; o.z_max = IS3D ? r.z_max : 0;
-        o.num_pixels = (int32_t)r.num_pixels;
-        o.sum_intensity = r.sum_i;
-        // center_of_mass(): double sums of (c + 0.5) * I, quotient narrowed to float
-        // (connected_components.hpp:81-100).  sum (2c+1) I is an exact integer; * 0.5 is exact.
-        const double tot = (double)r.sum_i;
-        const double wx = (double)r.sum_xi * 0.5, wy = (double)r.sum_yi * 0.5;
-        const double wz = IS3D ? (double)r.sum_zi * 0.5 : 0.5 * tot;  // z = 0 for 2D (:247)
-        o.com_x = (float)(wx / tot);
-        o.com_y = (float)(wy / tot);
-        o.com_z = (float)(wz / tot);
-        // (an accumulator nobody added to would decode to index 2^32 - 1: clamp instead of reading 16 GB away)
-        const uint32_t n_entries = min(a.seg_n[seg], (uint32_t)a.seg_stride);
-        const uint32_t pi = min(0xFFFFFFFFu - (uint32_t)(r.peak & 0xFFFFFFFFull), n_entries ? n_entries - 1 : 0u);
-        const uint32_t pk = k[pi];
-        o.peak_y = pk / a.W;
-        o.peak_x = pk - o.peak_y * a.W;
-        o.peak_intensity = (uint32_t)(r.peak >> 32);
-        int pz = 0;
-        if (IS3D) {
-            int lo = 0, hi = a.n_slices;  // slice containing entry pi
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (a.slice_begin[mid] <= pi) lo = mid; else hi = mid;
-            }
-            pz = lo;
-        }
-        o.peak_z = pz;
-        // peak_centroid_distance(): float arithmetic, connected_components.hpp:194-198.
-        // Each product/sum rounds to float (no contraction in this library); the float sqrt is
-        // taken through the correctly rounded double sqrt (double rounding is harmless for sqrt).
-        const float dx = ((float)o.peak_x + 0.5f) - o.com_x;
-        const float dy = ((float)o.peak_y + 0.5f) - o.com_y;
-        const float dz = ((float)pz + 0.5f) - o.com_z;
-        const float s2 = (dx * dx + dy * dy) + dz * dz;
-        o.peak_centroid_distance = (float)__builtin_sqrt((double)s2);
-        uint32_t flags = 0;
-        // filter_reflections(): size first, then separation (connected_components.cc:207-236)
-        if (a.min_spot_size > 0 && r.num_pixels < a.min_spot_size) flags |= 1u;
-        else if (a.max_sep > 0.0f && o.peak_centroid_distance > a.max_sep) flags |= 2u;
-        o.flags = flags;
-        recs[c] = o;
-        // generate_boxes() filter (connected_components.cc:122-138)
-        if (a.min_spot_size == 0 || r.num_pixels >= a.min_spot_size) {
-            atomicAdd(&sm[0], 1u);
-            atomicAdd(&sm[1], r.num_pixels);
-        }
-        if (flags == 0) atomicAdd(&sm[2], 1u);
-        if (flags & 1u) atomicAdd(&sm[3], 1u);
-        if (flags & 2u) atomicAdd(&sm[4], 1u);
-    }
-}
-template __global__ void k_finalize<false>(const SegArgs);
 
 }  // namespace ffsamd

@@ -1,4 +1,4 @@
-// kernels_chain.hpp (included by ffs_api.hip) -- the whole sparse stage of a frame in ONE workgroup.
+// kernels_chain.hpp (included by ffs_submit.hip) -- the whole sparse stage of a frame in ONE workgroup.
 //
 // Why: the sparse stage (compaction -> union-find -> reduction -> records) is a chain of dependent memory round
 // trips over ~10^4 strong pixels per frame.  As four grid-wide kernels it cost the batch their full durations
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
     __syncthreads();
     const uint32_t n = min(total, a.cap);
     const bool in_lds = n <= (uint32_t)kChainLdsEntries;
-    if (A.stop_after == 1) return;
+    FFS_STOP_AFTER(A, 1);
 
     uint32_t* gk = a.list_k + (uint64_t)frame * a.cap;
     uint32_t* gi = a.list_i + (uint64_t)frame * a.cap;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
         }
     }
     __syncthreads();
-    if (A.stop_after == 2) return;
+    FFS_STOP_AFTER(A, 2);
 
     // ---- S: per-row counts -> list offset of the first strong pixel of every row (and of "row H" = n) ------
     {
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
             }
         }
         __syncthreads();
-        if (A.stop_after == 3) return;
+        FFS_STOP_AFTER(A, 3);
 
         // ---- P: pixel values; roots, numbered in list order ---------------------------------------------------------
         // This thread's entries stay in registers through phase R: k, intensity and a 16-bit id (first the root's list
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
         for (int q = 0; q < kChainPer; ++q)
             if (i0 + q < i1) set_id(q, spar[get_id(q)]);
         __syncthreads();   // the forest is dead from here on: its LDS becomes accumulators + record staging
-        if (A.stop_after == 4) return;
+        FFS_STOP_AFTER(A, 4);
 
         // ---- R: kChainSlots components at a time --------------------------------------------------------------
         ChainAcc* s_acc = reinterpret_cast<ChainAcc*>(s_big);
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
             }
         }
         __syncthreads();
-        if (A.stop_after == 3) return;
+        FFS_STOP_AFTER(A, 3);
         for (uint32_t i0 = tid; i0 < n; i0 += kChainThreads) {
             // the thread of a run's first entry (runs are also cut every 32 entries) sums the run in registers
             const uint32_t k0 = gk[i0];

@@ -1,4 +1,4 @@
-// kernels_stack3d.hpp (included by ffs_api.hip) -- rotation sweeps: 3D connected components on the device.
+// kernels_stack3d.hpp (included by ffs_stack3d.hip only) -- rotation sweeps: 3D connected components on the device.
 //
 // What the reference does (spotfinder/connected_components/connected_components.cc:270-470): after the last
 // frame, one host thread copies every slice's 2D graph into one Boost graph, adds an edge for every linear
@@ -14,16 +14,9 @@
 // every strong pixel, its coordinates and the number of its component (the reference's signals_ view, used
 // for the Kabsch-space variances).  Everything on the stack's own stream; no device-wide synchronisation.
 #pragma once
-#include "kernels_ccl.hpp"
+#include "kernels_uf.hpp"
 
 namespace ffsamd {
-
-struct StackSlice {
-    uint32_t src;   // offset in the arrival buffers (k_stack_gather) / in the stream's list of that frame (k_stack_append)
-    uint32_t dst;   // offset in the destination buffers
-    uint32_t n;     // entries
-    uint32_t z;     // k_stack_gather: position of the slice in the stack
-};
 
 // grid (blocks, n_frames): frame f's list (src_k + f * src_stride ...) -> arrival buffers at table[f].dst
 __global__ __launch_bounds__(256) void k_stack_append(const uint32_t* src_k, const uint32_t* src_i, uint64_t src_stride,

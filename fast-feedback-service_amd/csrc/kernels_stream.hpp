@@ -1,4 +1,4 @@
-// kernels_stream.hpp (included by ffs_api.hip) -- the whole dispersion threshold in ONE streaming kernel
+// kernels_stream.hpp (included by ffs_submit.hip) -- the whole dispersion threshold in ONE streaming kernel
 // for 16-bit pixels on gfx950 (CDNA4): `k_stream_u16`.
 //
 // What the reference does: one 7x7 masked window sum per pixel from a shared-memory tile and a float32
@@ -41,77 +41,8 @@
 
 namespace ffsamd {
 
-constexpr int kSOwned = 62;          // lanes 1..62 own output; lanes 0 and 63 are halo
 constexpr int kSQWords = 32;         // queue entry: 0-7 window sums, 8-11 centre pixels (two per word), 12-13 window counts,
                                      // 14 result bits, 15 ginfo, 16-29 column sums of p^2, 30 tag
-constexpr int kInfoExtraRows = 3;    // ginfo row y carries the mask bits of row y and the counts of row y - 3
-
-// ---- tables that depend on the mask alone -------------------------------------------------------------
-// One thread per (group, row).  mmap[y][x] = number of valid pixels in the 7x7 window clipped to the
-// image (the oracle's m, standalone.cc:126-141); ginfo[y][g] byte 0 = mask bits of row y,
-// ginfo[y + 3][g] bytes 1, 2 = min / max of m over the VALID pixels of group g in row y (max = 0: none),
-// byte 3 = the mask bits of row y once more (row y is the centre row when row y + 3 comes in).
-__global__ __launch_bounds__(256) void k_build_maps(const uint8_t* maskbits, uint32_t mpitch, int W, int H, int pitch_px,
-                                                    uint8_t* mmap, uint8_t* ginfo, uint32_t gpitch_bytes) {
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y;
-    if (g * 8 >= pitch_px) return;
-    // 24 mask bits per row: columns 8g-8 .. 8g+15
-    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int dy = -3; dy <= 3; ++dy) {
-        const int yy = y + dy;
-        if (yy < 0 || yy >= H) continue;
-        const uint8_t* row = maskbits + (uint64_t)yy * mpitch;
-        uint32_t b = (uint32_t)row[g] << 8;
-        if (g > 0) b |= row[g - 1];
-        if ((uint32_t)(g + 1) < mpitch) b |= (uint32_t)row[g + 1] << 16;
-        for (int j = 0; j < 8; ++j) cnt[j] += __popc((b >> (j + 5)) & 0x7Fu);  // columns 8g+j-3 .. 8g+j+3
-    }
-    const uint32_t own = maskbits[(uint64_t)y * mpitch + g];
-    uint32_t mn = 255, mx = 0;
-    for (int j = 0; j < 8; ++j) {
-        mmap[(uint64_t)y * pitch_px + g * 8 + j] = (uint8_t)cnt[j];
-        if ((own >> j) & 1u) { mn = min(mn, cnt[j]); mx = max(mx, cnt[j]); }
-    }
-    if (mx == 0) mn = 0;
-    ginfo[(uint64_t)y * gpitch_bytes + g * 4] = (uint8_t)own;
-    ginfo[(uint64_t)(y + kInfoExtraRows) * gpitch_bytes + g * 4 + 1] = (uint8_t)mn;
-    ginfo[(uint64_t)(y + kInfoExtraRows) * gpitch_bytes + g * 4 + 2] = (uint8_t)mx;
-    ginfo[(uint64_t)(y + kInfoExtraRows) * gpitch_bytes + g * 4 + 3] = (uint8_t)own;  // the centre row's mask bits again
-}
-
-// The same tables for 32-bit pixels: lane groups of FOUR pixels (16 bytes), one ginfo dword per group (mask bits
-// in bits 0-3).  The counts are those of the mask alone; the oracle also drops neighbours >= 2^24 from its sums
-// and counts (standalone.cc:78,90) -- k_stream_u32 sends every window that holds such a pixel to the gather path.
-__global__ __launch_bounds__(256) void k_build_maps4(const uint8_t* maskbits, uint32_t mpitch, int W, int H, int pitch_px,
-                                                     uint8_t* mmap, uint8_t* ginfo, uint32_t gpitch_bytes) {
-    const int g = blockIdx.x * 256 + threadIdx.x;   // group of 4 pixels: columns 4g .. 4g+3
-    const int y = blockIdx.y;
-    if (g * 4 >= pitch_px) return;
-    uint32_t cnt[4] = {0, 0, 0, 0};
-    const int byte0 = (g * 4) >> 3, sh = (g * 4) & 7;   // the group's bits sit at bit `sh` (0 or 4) of byte0
-    for (int dy = -3; dy <= 3; ++dy) {
-        const int yy = y + dy;
-        if (yy < 0 || yy >= H) continue;
-        const uint8_t* row = maskbits + (uint64_t)yy * mpitch;
-        uint32_t b = (uint32_t)row[byte0] << 8;
-        if (byte0 > 0) b |= row[byte0 - 1];
-        if ((uint32_t)(byte0 + 1) < mpitch) b |= (uint32_t)row[byte0 + 1] << 16;
-        // bit 8 + sh + j is pixel j of the group; its window is bits (8 + sh + j - 3) .. (8 + sh + j + 3)
-        for (int j = 0; j < 4; ++j) cnt[j] += __popc((b >> (5 + sh + j)) & 0x7Fu);
-    }
-    const uint32_t own = (maskbits[(uint64_t)y * mpitch + byte0] >> sh) & 0xFu;
-    uint32_t mn = 255, mx = 0;
-    for (int j = 0; j < 4; ++j) {
-        mmap[(uint64_t)y * pitch_px + g * 4 + j] = (uint8_t)cnt[j];
-        if ((own >> j) & 1u) { mn = min(mn, cnt[j]); mx = max(mx, cnt[j]); }
-    }
-    if (mx == 0) mn = 0;
-    ginfo[(uint64_t)y * gpitch_bytes + g * 4] = (uint8_t)own;
-    ginfo[(uint64_t)(y + kInfoExtraRows) * gpitch_bytes + g * 4 + 1] = (uint8_t)mn;
-    ginfo[(uint64_t)(y + kInfoExtraRows) * gpitch_bytes + g * 4 + 2] = (uint8_t)mx;
-    ginfo[(uint64_t)(y + kInfoExtraRows) * gpitch_bytes + g * 4 + 3] = (uint8_t)own;
-}
 
 // The oracle's predicate on exact integer window sums, standalone.cc:165-170 operation for operation
 // (the same lines as exact_strong, which gets its sums by gathering the window from memory).
@@ -317,7 +248,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     // other inside their group's lane (the drain is a latency chain, not a throughput problem).
     // Phase 3: the group's lane collects its result byte.
     auto drain = [&]() {
-        const bool have = lane < qn && !(a.dbg & 2);
+        const bool have = lane < qn && !FFS_DBG(a, 2);
         uint32_t todo = 0, row = 0, fe = 0, ge = 0;
         if (have) {
             const uint32_t tag = s_q[30][lane], ln = tag & 63u;
@@ -372,7 +303,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                     todo |= (bf * __builtin_fabsf(bf) > kS * tf) ? (1u << j) : 0u;
                 }
             }
-            if (a.dbg & 4) todo = 0;
+            if (FFS_DBG(a, 4)) todo = 0;
         }
         int T = 0;  // candidates of the whole wave (wave-uniform)
 #pragma unroll
@@ -407,6 +338,9 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                         if (!certain) strong = exact_predicate(a, m, x, y, pv);
                     }
                     if (strong) atomicOr(&s_q[14][e], 1u << j);
+                } else if (!EXT && a.bright_to_plane) {
+                    // sum p^2 may not fit 32 bits: marked as a candidate, k_exact gathers the window and decides
+                    atomicOr(&s_q[14][e], 1u << j);
                 } else {
                     // sum p^2 may not fit 32 bits: k_bright_fix gathers the window and decides (rare)
                     const uint32_t tg = s_q[30][e];
@@ -528,7 +462,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                     const float bf = (float)B, tf = (float)__umul24(xmin, mmin);
                     pass = bf * __builtin_fabsf(bf) > kS * tf;
                 }
-                const bool flag = owned && pass && !(a.dbg & 1);
+                const bool flag = owned && pass && !FFS_DBG(a, 1);
                 if (a.dense_mask) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, so_bytes, 2 /* nt: written once, read much later */);
                 const unsigned long long fm = __builtin_amdgcn_ballot_w64(flag);
                 if (fm) {  // wave-uniform
@@ -686,7 +620,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
 
     int qn = 0;
     auto drain = [&]() {
-        const bool have = lane < qn && !(a.dbg & 2);
+        const bool have = lane < qn && !FFS_DBG(a, 2);
         uint32_t todo = 0, row = 0, fe = 0, ge = 0, info = 0;
         bool big = false;
         if (have) {
@@ -714,7 +648,9 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
         }
         // groups next to a pixel >= 2^24: every valid pixel to the gather path
         if (__ballot(big) != 0ull) {
-            if (big) {
+            if (big && a.bright_to_plane) {
+                s_q[10][lane] = (info >> 24) & 0xFu;   // every valid pixel of the group is a candidate for k_exact
+            } else if (big) {
                 for (uint32_t j = 0; j < 4; ++j) {
                     if (!((info >> (24 + j)) & 1u)) continue;   // (byte 3 = mask bits of the centre row)
                     const uint32_t at = atomicAdd(a.bright_n, 1u);
@@ -813,7 +749,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
                 const uint32_t bl = bighist != 0u ? 1u : 0u;
                 bool near_big = false;
                 if (__ballot(bl != 0u) != 0ull) near_big = (bl | from_left(bl) | from_right(bl)) != 0u && mmax != 0u;
-                const bool flag = owned && (pass || near_big) && !(a.dbg & 1);
+                const bool flag = owned && (pass || near_big) && !FFS_DBG(a, 1);
                 const unsigned long long fm = __builtin_amdgcn_ballot_w64(flag);
                 if (fm) {
                     const int nfl = __popcll(fm);
@@ -857,7 +793,6 @@ template __global__ void k_bright_fix<uint32_t>(const ThresholdArgs);
 
 template __global__ void k_stream_u16<2>(const ThresholdArgs);
 template __global__ void k_stream_u16<2, true>(const ThresholdArgs);
-template __global__ void k_stream_u16<3>(const ThresholdArgs);
 template __global__ void k_stream_u32<2>(const ThresholdArgs);
 
 }  // namespace ffsamd

@@ -58,7 +58,7 @@ class H5Read : public Reader {
     std::vector<Source> src_;
     size_t n_images_ = 0;
     std::array<size_t, 2> shape_{};
-    PixelDType dtype_ = PixelDType::UINT16;
+    h5read_dtype dtype_ = H5READ_DTYPE_UINT16;
     std::vector<uint8_t> mask_;
     std::array<int64_t, 2> trusted_{0, 65535};
     std::optional<float> wavelength_, distance_;
@@ -108,7 +108,7 @@ class H5Read : public Reader {
             const size_t sz = H5Tget_size(type);
             if (H5Tget_class(type) != H5T_INTEGER || (sz != 2 && sz != 4))
                 throw std::runtime_error("Error: only 16- and 32-bit integer pixel data are handled");
-            dtype_ = sz == 2 ? PixelDType::UINT16 : PixelDType::UINT32;
+            dtype_ = sz == 2 ? H5READ_DTYPE_UINT16 : H5READ_DTYPE_UINT32;
             trusted_[1] = sz == 2 ? 65535 : (int64_t)0xFFFFFFFFll;
             H5Tclose(type);
             H5Sclose(space);
@@ -236,7 +236,7 @@ class H5Read : public Reader {
     }
     ChunkCompression get_raw_chunk_compression() override { return BITSHUFFLE_LZ4; }
     size_t get_number_of_images() const override { return n_images_; }
-    PixelDType get_dtype() const override { return dtype_; }
+    h5read_dtype get_dtype() const override { return dtype_; }
     std::array<int64_t, 2> get_trusted_range() const override { return trusted_; }
     std::array<size_t, 2> image_shape() const override { return shape_; }
     std::optional<std::span<const uint8_t>> get_mask() const override {
@@ -251,17 +251,18 @@ class H5Read : public Reader {
 };
 
 std::unique_ptr<Reader> make_h5_reader(const std::string& filename) { return std::make_unique<H5Read>(filename); }
-bool h5_ready_for_read(const std::string& filename) {  // is_ready_for_read<H5Read>, h5read.h:327-336
-    ErrSilence q;
+bool h5_supported() { return true; }
+
+}  // namespace ffshost
+
+template <> bool is_ready_for_read<ffshost::H5Read>(const std::string& filename) {  // h5read.h:327-336
+    ffshost::ErrSilence q;
     hid_t f = H5Fopen(filename.c_str(), H5F_ACC_RDONLY | H5F_ACC_SWMR_READ, H5P_DEFAULT);
     if (f < 0) f = H5Fopen(filename.c_str(), H5F_ACC_RDONLY, H5P_DEFAULT);
     if (f < 0) return false;
     H5Fclose(f);
     return true;
 }
-bool h5_supported() { return true; }
-
-}  // namespace ffshost
 #else
 #include "reader.hpp"
 #include <stdexcept>
@@ -269,7 +270,7 @@ namespace ffshost {
 std::unique_ptr<Reader> make_h5_reader(const std::string&) {
     throw std::runtime_error("HDF5/NeXus input needs an HDF5-enabled build (hdf5.h was not found at build time)");
 }
-bool h5_ready_for_read(const std::string&) { return true; }
 bool h5_supported() { return false; }
 }  // namespace ffshost
+template <> bool is_ready_for_read<ffshost::H5Read>(const std::string&) { return true; }
 #endif

@@ -83,7 +83,7 @@ class SynthRead : public Reader {
     bool reentrant() const override { return true; }  // frames are a pure function of (parameters, index)
     ChunkCompression get_raw_chunk_compression() override { return NONE; }
     size_t get_number_of_images() const override { return n_images_; }
-    PixelDType get_dtype() const override { return p_.pixel_bytes == 2 ? PixelDType::UINT16 : PixelDType::UINT32; }
+    h5read_dtype get_dtype() const override { return p_.pixel_bytes == 2 ? H5READ_DTYPE_UINT16 : H5READ_DTYPE_UINT32; }
     std::array<int64_t, 2> get_trusted_range() const override {
         return {0, p_.pixel_bytes == 2 ? 65535 : (int64_t)0xFFFFFFFFll};
     }
@@ -144,7 +144,7 @@ class CBFRead : public Reader {
         mask_.resize(npx);
         for (size_t i = 0; i < npx; ++i) mask_[i] = img[i] >= 0;
     }
-    PixelDType get_dtype() const override { return PixelDType::UINT16; }
+    h5read_dtype get_dtype() const override { return H5READ_DTYPE_UINT16; }
     // `index` is the driver's offset image number (image_num + --start-index, spotfinder.cc:756) and
     // is used as the file number as it stands.  (The reference adds the start index a second time
     // inside CBFRead, cbfread.cc:87-96, so with --start-index 1 it opens file 2 for image 0.)
@@ -174,7 +174,6 @@ class CBFRead : public Reader {
 std::unique_ptr<Reader> make_cbf_reader(const std::string& t, size_t n, size_t first) {
     return std::make_unique<CBFRead>(t, n, first);
 }
-bool cbf_ready_for_read(const std::string& t) { return fs::exists(expand_template(t, 1)); }  // cbfread.cc:130-134
 
 // ---- /dev/shm directory (spotfinder/shmread.cc) ---------------------------------------------------------
 class SHMRead : public Reader {
@@ -186,7 +185,7 @@ class SHMRead : public Reader {
     std::optional<float> wavelength_;
     std::array<float, 2> beam_center_{}, pixel_size_{}, osc_{};
     float distance_ = 0;
-    PixelDType dtype_ = PixelDType::UINT16;
+    h5read_dtype dtype_ = H5READ_DTYPE_UINT16;
 
     std::string image_path(size_t index) const {
         char b[64];
@@ -202,8 +201,8 @@ class SHMRead : public Reader {
         n_images_ = (size_t)d.at("nimages").number() * (size_t)d.at("ntrigger").number();  // shmread.cc:19-20
         shape_ = {(size_t)d.at("y_pixels_in_detector").number(), (size_t)d.at("x_pixels_in_detector").number()};
         const int depth = (int)d.at("bit_depth_image").number();
-        if (depth == 16) dtype_ = PixelDType::UINT16;
-        else if (depth == 32) dtype_ = PixelDType::UINT32;
+        if (depth == 16) dtype_ = H5READ_DTYPE_UINT16;
+        else if (depth == 32) dtype_ = H5READ_DTYPE_UINT32;
         else throw std::runtime_error("Data is unhandled bit-depth: " + std::to_string(depth) + "-bit");
         trusted_ = {0, (int64_t)d.at("countrate_correction_count_cutoff").number()};
         if (d.contains("wavelength")) wavelength_ = (float)d.at("wavelength").number();
@@ -237,7 +236,7 @@ class SHMRead : public Reader {
     }
     bool reentrant() const override { return true; }  // one file per frame
     ChunkCompression get_raw_chunk_compression() override { return BITSHUFFLE_LZ4; }
-    PixelDType get_dtype() const override { return dtype_; }
+    h5read_dtype get_dtype() const override { return dtype_; }
     size_t get_number_of_images() const override { return n_images_; }
     std::array<size_t, 2> image_shape() const override { return shape_; }
     std::optional<std::span<const uint8_t>> get_mask() const override { return {{mask_.data(), mask_.size()}}; }
@@ -249,8 +248,12 @@ class SHMRead : public Reader {
     std::array<float, 2> get_oscillation() const override { return osc_; }
 };
 std::unique_ptr<Reader> make_shm_reader(const std::string& dir) { return std::make_unique<SHMRead>(dir); }
-bool shm_ready_for_read(const std::string& dir) {  // shmread.cc:90-95
-    return fs::exists(dir + "/start_1") && fs::exists(dir + "/start_4");
-}
 
 }  // namespace ffshost
+
+template <> bool is_ready_for_read<ffshost::SHMRead>(const std::string& dir) {  // shmread.cc:90-95
+    return fs::exists(dir + "/start_1") && fs::exists(dir + "/start_4");
+}
+template <> bool is_ready_for_read<ffshost::CBFRead>(const std::string& t) {  // cbfread.cc:127-134
+    return fs::exists(ffshost::expand_template(t, 1));
+}

@@ -20,6 +20,8 @@
 #include <sstream>
 #include <string>
 #include <thread>
+#include <pthread.h>
+#include <sched.h>
 #include <unistd.h>
 #include <vector>
 
@@ -56,7 +58,7 @@ struct Args {
     int pipe_fd = -1, device = 0;
     std::vector<int> devices;  // --devices / --gpus: the frame queue is dealt to all of them
     std::string algorithm = "dispersion", detector_json;
-    bool cpu_decode = false;
+    bool cpu_decode = false, no_numa_pinning = false;
 };
 
 static void usage() {
@@ -66,7 +68,7 @@ static void usage() {
       "                  [--min-spot-size-3d N] [--max-peak-centroid-separation N] [--start-index N]\n"
       "                  [-t S] [-fd FD] [-a ALGO] [--dmin MIN D] [--dmax MAX D] [-w \xce\xbb] [--detector JSON]\n"
       "                  [-h5] [--output-for-index] [--batch N] [--cpu-decode] [--strict-dtype]\n"
-      "                  [--devices D0,D1,... | --gpus N]\n"
+      "                  [--devices D0,D1,... | --gpus N] [--no-numa-pinning]\n"
       "--devices / --gpus: one context and worker pool per GPU, all pulling frames from the one queue\n"
       "              (-n threads are dealt round-robin to the GPUs, at least one each); rotation sweeps send\n"
       "              their strong-pixel lists to the first GPU's 3D stack (RCCL over xGMI, else peer copies)\n"
@@ -151,6 +153,7 @@ static Args parse_args(int argc, char** argv) {
             while (std::getline(ss, tok, ',')) r.devices.push_back((int)u32(tok, s));
         }
         else if (s == "--strict-dtype") r.strict_dtype = true;
+        else if (s == "--no-numa-pinning") r.no_numa_pinning = true;
         else if (!s.empty() && s[0] == '-' && s.size() > 1) arg_error("Unknown argument: " + s);
         else if (r.file.empty()) r.file = s;
         else arg_error("Maximum number of positional arguments exceeded");
@@ -331,7 +334,7 @@ int main(int argc, char** argv) {
             if (!fs::exists(file) && file.find('#') == std::string::npos)
                 wait_ready(file, [](const std::string& s) { return fs::exists(s); });
             if (fs::is_directory(file)) {
-                wait_ready(file, shm_ready_for_read);
+                wait_ready(file, is_ready_for_read<SHMRead>);
                 reader_ptr = make_shm_reader(file);
             } else if (file.size() > 4 && file.compare(file.size() - 4, 4, ".cbf") == 0) {
                 if (!args.images_set) {
@@ -340,7 +343,7 @@ int main(int argc, char** argv) {
                 }
                 reader_ptr = make_cbf_reader(file, args.images, args.start_index);
             } else {
-                wait_ready(file, h5_ready_for_read);
+                wait_ready(file, is_ready_for_read<H5Read>);
                 reader_ptr = make_h5_reader(file);
             }
         }
@@ -488,7 +491,7 @@ int main(int argc, char** argv) {
 
     std::printf("Dataset type: %s\n", rotation ? "Rotation set" : "Still set");
     ffs_stack3d* stack = nullptr;
-    std::mutex stack_mutex, print_mutex;
+    std::mutex print_mutex;
     if (rotation) FFS_CHECK(ctx, ffs_stack3d_create(ctx, 0, &stack));
 
     std::unique_ptr<PipeHandler> pipe;
@@ -502,8 +505,44 @@ int main(int argc, char** argv) {
     std::map<uint32_t, std::vector<float>> reflection_centers_2d;  // spotfinder.cc:706-708
     std::mutex reflection_centers_2d_mutex;
 
+    // Workers are dealt round-robin to the GPUs; each is kept on the CPUs of its GPU's NUMA node (where the node is known
+    // and leaves it CPUs of this process's affinity set), so that the frames it reads, its pinned staging buffer -- first
+    // touched by hipHostMalloc on this thread -- and the GPU's PCIe root sit on one socket.  --no-numa-pinning turns it off.
+    std::vector<cpu_set_t> node_cpus(n_dev);
+    std::vector<bool> node_known(n_dev, false);
+    if (!args.no_numa_pinning) {
+        cpu_set_t allowed;
+        CPU_ZERO(&allowed);
+        sched_getaffinity(0, sizeof allowed, &allowed);
+        for (uint32_t di = 0; di < n_dev; ++di) {
+            const int node = ffs_device_numa_node(devices[di]);
+            if (node < 0) continue;
+            std::ifstream f("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
+            std::string list;
+            if (!std::getline(f, list)) continue;
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            std::stringstream ss(list);
+            std::string tok;
+            int n_set = 0;
+            while (std::getline(ss, tok, ',')) {
+                const size_t dash = tok.find('-');
+                const int lo = std::atoi(tok.c_str()), hi = dash == std::string::npos ? lo : std::atoi(tok.c_str() + dash + 1);
+                for (int cpu = lo; cpu <= hi && cpu < CPU_SETSIZE; ++cpu)
+                    if (CPU_ISSET(cpu, &allowed)) { CPU_SET(cpu, &set); ++n_set; }
+            }
+            if (n_set > 0) { node_cpus[di] = set; node_known[di] = true; }
+        }
+        if (args.verbose)
+            for (uint32_t di = 0; di < n_dev; ++di)
+                std::printf("GPU %d: NUMA node %d%s\n", devices[di], ffs_device_numa_node(devices[di]),
+                            node_known[di] ? ", workers pinned to its CPUs" : " (workers not pinned)");
+    }
+
     auto worker = [&](int thread_id) {
-        ffs_ctx* ctx = ctxs[(size_t)thread_id % ctxs.size()];  // this worker's GPU (shadows the home context)
+        const size_t di = (size_t)thread_id % ctxs.size();
+        ffs_ctx* ctx = ctxs[di];  // this worker's GPU (shadows the home context)
+        if (node_known[di]) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &node_cpus[di]);
         ffs_stream* s = nullptr;
         if (ffs_stream_create(ctx, &s) != FFS_OK) {
             std::printf("Error: %s\n", ffs_last_error(ctx));
@@ -594,8 +633,8 @@ int main(int argc, char** argv) {
             float tm[5] = {0};
             ffs_stream_timings(s, tm);
             if (rotation) {
-                // key = image number read (rotation_slices[offset_image_num], :913-918)
-                std::lock_guard<std::mutex> lock(stack_mutex);
+                // key = image number read (rotation_slices[offset_image_num], :913-918); the stack has its own lock (the
+                // reference's rotation_slices_mutex), held only while the transfer is enqueued
                 if (ffs_stack3d_add_batch(stack, s) != FFS_OK) { std::printf("Error: %s\n", ffs_last_error(ctx)); failed = 1; break; }
             }
             for (uint32_t i = 0; i < nres; ++i) {

@@ -76,6 +76,7 @@ EXPORTS = [
     "ffs_submit_device", "ffs_ctx_device_layout", "ffs_wait", "ffs_stream_batch_arrays", "ffs_stream_timings",
     "ffs_submit_compressed", "ffs_decode_only", "ffs_stream_spot_centres", "ffs_bench_threshold", "ffs_bench_hbm", "ffs_stream_debug_planes", "ffs_stream_debug_bitplane", "ffs_selftest_sqrt", "ffs_stack3d_create",
     "ffs_stack3d_destroy", "ffs_stack3d_add_batch", "ffs_stack3d_add_slice", "ffs_stack3d_finish", "ffs_stack3d_signals", "ffs_stack3d_last_finish_ms", "ffs_multi_init", "ffs_multi_transport",
+    "ffs_ctx_set_tuning", "ffs_bench_pipeline", "ffs_device_numa_node",
 ]
 
 _lib = None
@@ -98,6 +99,10 @@ def load_library():
         L.ffs_ctx_set_mask.argtypes = [C.c_void_p, C.c_void_p]
         L.ffs_ctx_get_mask.argtypes = [C.c_void_p, C.c_void_p]
         L.ffs_ctx_set_params.argtypes = [C.c_void_p, C.POINTER(Params)]
+        L.ffs_ctx_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong]
+        L.ffs_bench_pipeline.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32,
+                                         C.c_uint32, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.ffs_device_numa_node.argtypes = [C.c_int]
         L.ffs_ctx_apply_resolution_mask.argtypes = [C.c_void_p] + [C.c_float] * 8
         L.ffs_ctx_device_layout.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.ffs_stream_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
@@ -226,6 +231,11 @@ class Context:
                 raise AttributeError(k)
             setattr(self.params, k, v)
         self._check(self._lib.ffs_ctx_set_params(self._h, C.byref(self.params)))
+
+    def set_tuning(self, **kw):
+        """ffs_ctx_set_tuning: A/B partners, fall-backs and capacities (same results either way); see include/ffs_hip.h."""
+        for k, v in kw.items():
+            self._check(self._lib.ffs_ctx_set_tuning(self._h, k.encode(), int(v)))
 
     def selftest_sqrt(self, begin: int, end: int) -> int:
         out = C.c_uint64()
@@ -407,6 +417,20 @@ class Stream:
             self.close()
         except Exception:
             pass
+
+
+def bench_pipeline(streams, dev_ptr: int, pitch_bytes: int, frame_stride_bytes: int, n_frames: int, steps: int,
+                   first_frame_id: int = 0):
+    """ffs_bench_pipeline: `steps` batches through `streams` (one context), natively; -> (boxes, strong pixels) summed."""
+    arr = (C.c_void_p * len(streams))(*[s._h for s in streams])
+    nb, ns = C.c_uint64(), C.c_uint64()
+    streams[0].ctx._check(load_library().ffs_bench_pipeline(arr, len(streams), C.c_void_p(dev_ptr), pitch_bytes, frame_stride_bytes,
+                                                             n_frames, steps, first_frame_id, C.byref(nb), C.byref(ns)))
+    return nb.value, ns.value
+
+
+def device_numa_node(device: int = 0) -> int:
+    return load_library().ffs_device_numa_node(device)
 
 
 def multi_init(devices, transport=None) -> str:

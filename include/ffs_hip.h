@@ -9,12 +9,13 @@
  * exceptions cross this boundary and no torch / HIP types appear in it.
  *
  * Data flow of one batch:
- *   frames (u16/u32, dense host rows or pitched device rows)
- *     -> dispersion candidate kernel      (replaces kernels/thresholding.cu:145-234)
- *     -> exact fp64 predicate kernel      (semantics of baseline/spotfinder/standalone.cc:113-174)
- *     -> strong-pixel compaction
- *     -> union-find connected components  (replaces connected_components.cc:17-139, 238-266)
- *     -> per-frame result records (D2H)
+ *   frames (u16/u32: dense host rows, pitched device rows, or bitshuffle-LZ4 chunks decoded on the GPU)
+ *     -> ONE streaming threshold kernel per batch: exact integer 7x7 window sums, a conservative group
+ *        screen, and the oracle's float64 predicate (baseline/spotfinder/standalone.cc:113-174) decided
+ *        in its drain -- replaces kernels/thresholding.cu:145-234; the strong mask stays a bit plane
+ *     -> ONE sparse launch per batch, a workgroup per frame: strong-pixel compaction, union-find connected
+ *        components, centroids and filters (replaces connected_components.cc:17-139, 207-266)
+ *     -> per-frame counters and 40-byte records written straight into pinned host memory
  */
 #ifndef FFS_HIP_H
 #define FFS_HIP_H
@@ -25,6 +26,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* libffs_hip.so is built with -fvisibility=hidden: what this header declares is all it exports */
+#pragma GCC visibility push(default)
 
 #define FFS_OK 0
 #define FFS_ERR_INVALID (-1)   /* bad argument / state */
@@ -143,6 +147,21 @@ int ffs_ctx_get_mask(ffs_ctx *ctx, uint8_t *host_mask);
 
 int ffs_ctx_set_params(ffs_ctx *ctx, const ffs_params *p);
 
+/* Selects between paths that give the SAME results (A/B partners, fall-backs, capacities that tests shrink) --
+ * per context, never through the environment; nothing here can change a result.  Keys (default):
+ *   "threshold_path"   (0) 0 = windows the streaming kernel cannot vouch for go onto a list (fix-up kernel),
+ *                          1 = they are marked in the plane and an exact kernel filters it (also the fall-back
+ *                          when that list overflows)
+ *   "ext_first_pass"   (2) extended algorithm, 16-bit pixels: 2 = streaming kernel, 0 = plain one-pixel-per-lane kernel
+ *   "sparse_stage"     (2) 2 = one launch per batch, a workgroup per frame; 1 = four grid-wide kernels
+ *   "sched"            (3) 3 = shared dense / sparse / upload HIP streams per context, 0 = one per ffs_stream
+ *                          (before the first stream is created)
+ *   "direct_records"   (1) records written straight into pinned host memory (before the first stream is created)
+ *   "chain_first" (2), "bright_cap" (2^20), "frames_per_group", "target_waves" (16384), "dense_mask" (0),
+ *   "occupancy_bitmap" (1), "decode_in_dense_stream" (1): see DESIGN.md.
+ * The reference has no counterpart (its launch wrapper has one path, spotfinder/spotfinder.cu:148-189). */
+int ffs_ctx_set_tuning(ffs_ctx *ctx, const char *key, long long value);
+
 /* ---- streams: one in-flight batch each (replaces one worker thread's CudaStream +
  *      pinned/device buffers, spotfinder.cc:729-742) --------------------------------------------
  * An ffs_stream owns its buffers and its batch; the HIP streams underneath belong to the context (one for
@@ -213,13 +232,23 @@ int ffs_stream_timings(ffs_stream *s, float ms[5]);
  * FFS_ERR_OVERFLOW (rows written are valid) when wanted > cap.  Needs want_reflections. */
 int ffs_stream_spot_centres(ffs_stream *s, float *rows4, uint32_t cap, uint32_t *n_written);
 
-/* ---- kernel-only entry points (bench.py roofline leg, kernel parity tests) ------------------ */
-/* Runs only the two threshold kernels on device-resident frames, `iters` times back to back
- * on the stream, and returns the average duration of ONE launch of the dominant
- * (candidate) kernel and of the exact kernel, from HIP events on that stream. */
+/* ---- measurement entry points (bench.py roofline leg, tools/) -------------------------------- */
+/* Runs the threshold stage alone on device-resident frames, `iters` times, every launch on the state the hot
+ * path gives it (zeroed counters, empty plane) and returns the average duration of ONE launch of its dense
+ * kernel (ms_dense: the streaming kernel; extended algorithm: its first pass) and of what follows it inside the
+ * stage (ms_rest: the bright-window fix-up; extended: erosion + final pass), each from HIP events that ride on
+ * the dispatches themselves, on the stream the kernels are launched on.  (The reference prints "Kernel: ms" per
+ * image from events around its launch wrapper, spotfinder/spotfinder.cc:1056-1076.) */
 int ffs_bench_threshold(ffs_stream *s, const void *device_pixels, size_t pitch_bytes,
                         size_t frame_stride_bytes, uint32_t n_frames, uint32_t iters,
-                        float *ms_candidate, float *ms_exact);
+                        float *ms_dense, float *ms_rest);
+/* The submit / wait loop of a resident-frames benchmark, natively: `steps` batches of the same device-resident
+ * frames through `n_streams` streams of ONE context, all of them in flight (ffs_submit_device / ffs_wait).  For
+ * drivers with one host thread per GPU (bench.py --single-process, the threading model of
+ * spotfinder/spotfinder.cc:725-752 spread over several devices).  Returns the sums over all frames. */
+int ffs_bench_pipeline(ffs_stream *const *streams, uint32_t n_streams, const void *device_pixels,
+                       size_t pitch_bytes, size_t frame_stride_bytes, uint32_t n_frames, uint32_t steps,
+                       int64_t first_frame_id, uint64_t *n_boxes, uint64_t *n_strong_pixels);
 /* Memory ceiling measured on this device (BASELINE.md section 3 asks for one beside the nominal 8 TB/s): the
  * stream's own buffers are read linearly, 16 B per lane (read_gbps), and read while one 8-byte zero store per
  * 16 bytes read goes to the byte-mask buffer -- the threshold kernel's 2:1 read/write mix with the friendliest
@@ -267,9 +296,14 @@ int ffs_stack3d_finish(ffs_stack3d *st, const ffs_reflection **reflections,
  * frame shape: the batch's strong-pixel lists are packed on their GPU and sent to the stack's GPU -- by RCCL
  * point-to-point over xGMI when ffs_multi_init() could load librccl and build the communicators, else by
  * peer copies.  `devices`: the GPUs in use (duplicates allowed); transport: "rccl", "peer" or NULL (= the
- * FFS_GATHER environment variable, default "rccl").  ffs_multi_transport(): "rccl", "peer" or "none". */
+ * FFS_GATHER environment variable, default "rccl").  ffs_multi_transport(): "rccl", "peer" or "none".
+ * Call it before the first batch is added to a stack, not while batches are being added.  A frame that
+ * overflowed its stream's lists reaches the stack from any GPU (its list goes up from the host, as on one GPU). */
 int ffs_multi_init(const int *devices, int n_devices, const char *transport);
 const char *ffs_multi_transport(void);
+/* NUMA node the GPU hangs off (sysfs), -1 if unknown: where a driver should keep the worker threads that feed
+ * it (the reference pins nothing: one device, spotfinder.cc:725-742). */
+int ffs_device_numa_node(int device);
 /* Device time of the last ffs_stack3d_finish (upload of the slice table to the labels of every strong pixel), ms. */
 int ffs_stack3d_last_finish_ms(const ffs_stack3d *st, float *ms);
 /* Per-signal view of the last ffs_stack3d_finish: every strong pixel of the stack in the reference's
@@ -280,6 +314,8 @@ int ffs_stack3d_last_finish_ms(const ffs_stack3d *st, float *ms);
  * until the next finish / destroy. */
 int ffs_stack3d_signals(ffs_stack3d *st, const uint32_t **x, const uint32_t **y, const int32_t **z,
                         const uint32_t **intensity, const int32_t **reflection, uint64_t *n);
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,26 @@ def test_hip_library_exports_every_declared_symbol(ffs):
     assert sorted(api.EXPORTS) == declared, "python binding list out of sync with the header"
 
 
+def test_hip_library_exports_no_other_function():
+    """Built with -fvisibility=hidden: the C ABI of include/ffs_hip.h is every FUNCTION the library exports (the kernels'
+    launch handles are data symbols the HIP runtime registers)."""
+    import subprocess
+    so = os.path.join(ROOT, "fast-feedback-service_amd", "libffs_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    funcs = sorted(ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "Tt")
+    assert funcs == _declared("ffs_hip.h"), [f for f in funcs if not f.startswith("ffs_")]
+
+
+def test_product_library_has_no_experiment_switch():
+    """The timing experiments that break results (phases switched off, kernels stopped half way) are compiled only with
+    -DFFS_EXPERIMENTS (make experiments -> libffs_hip_exp.so): the product library neither reads their environment
+    variables nor carries their kernel."""
+    so = open(os.path.join(ROOT, "fast-feedback-service_amd", "libffs_hip.so"), "rb").read()
+    for needle in (b"FFS_EXP_", b"FFS_K1_DEBUG", b"FFS_CHAIN_SKIP", b"FFS_CHAIN_STOP", b"FFS_DUMMY", b"k_dummy_spin",
+                   b"FFS_K1_VARIANT", b"FFS_CCL", b"FFS_SCHED", b"FFS_EMIT"):
+        assert needle not in so, needle
+
+
 def test_synth_library_exports_every_declared_symbol():
     from ffs_amd import synth
     lib = synth.lib()

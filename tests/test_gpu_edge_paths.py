@@ -8,10 +8,9 @@ from util import assert_frame_matches_oracle, make_frame
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2"])
+@pytest.mark.parametrize("path", [0, 1])
 @pytest.mark.parametrize("kind", ["single_photons", "uniform_noise", "stripes", "saturated_blocks"])
-def test_dense_candidate_frames(ffs, kind, variant, monkeypatch):
-    monkeypatch.setenv("FFS_K1_VARIANT", variant)
+def test_dense_candidate_frames(ffs, kind, path):
     rng = np.random.default_rng(hash(kind) % 1000)
     H, W = 300, 1300
     if kind == "single_photons":       # every photon passes the signal test: ~3 % candidates
@@ -28,6 +27,7 @@ def test_dense_candidate_frames(ffs, kind, variant, monkeypatch):
             img[y:y + rng.integers(1, 6), x:x + rng.integers(1, 6)] = rng.integers(9000, 65536)
     mask = (rng.random((H, W)) > 0.01).astype(np.uint8)
     ctx = ffs.Context(W, H, np.uint16, max_strong_per_frame=W * H)
+    ctx.set_tuning(threshold_path=path)
     ctx.set_mask(mask)
     ctx.set_params(want_strong_mask=1, want_strong_list=1)
     fr = ctx.stream().process(img)[0]
@@ -87,20 +87,20 @@ def test_bad_arguments_are_rejected(ffs):
     assert st.wait()[0].num_strong_pixels == 0
 
 
-@pytest.mark.parametrize("direct", ["1", "0"])
-def test_many_components_per_frame_both_record_paths(ffs, direct, monkeypatch):
+@pytest.mark.parametrize("direct", [1, 0])
+def test_many_components_per_frame_both_record_paths(ffs, direct):
     """Thousands of components per frame: more than the 256 per frame the copy path brings back
     speculatively (so its top-up copy runs) and enough to exercise the direct-to-host path too."""
     from util import assert_frame_matches_oracle
-    monkeypatch.setenv("FFS_DIRECT_RECS", direct)
     rng = np.random.default_rng(8)
     H, W = 300, 400
     frames = rng.poisson(0.05, (2, H, W)).astype(np.uint16)          # lonely photons: thousands of tiny components
     frames[rng.random((2, H, W)) < 0.01] += 9
     mask = np.ones((H, W), np.uint8)
     ctx = ffs.Context(W, H, np.uint16, max_batch=2)
+    ctx.set_tuning(direct_records=direct)                               # (before the first stream)
     ctx.set_params(min_spot_size=1, want_strong_list=1, max_peak_centroid_separation=50.0)
-    st = ctx.stream()                                                   # (the env var is read here)
+    st = ctx.stream()
     for rep in range(2):                                                # 2nd pass: speculative size has grown
         res = st.process(frames)
         for fr, img in zip(res, frames):
@@ -172,11 +172,11 @@ def test_default_capacity_overflow_full_size_lists(ffs):
 
 
 @pytest.mark.parametrize("dtype", [np.uint16, np.uint32])
-def test_bright_window_list_overflow_falls_back(ffs, dtype, monkeypatch):
+def test_bright_window_list_overflow_falls_back(ffs, dtype):
     """Windows whose sums leave the streaming kernel's exact range (16-bit: sum p >= 65536; 32-bit: a pixel
     >= 2^24 nearby) go onto a list for the gather kernel.  With the list shrunk to 8 entries it overflows, and
-    the batch must come back right all the same (re-run through the two-kernel path inside ffs_wait)."""
-    monkeypatch.setenv("FFS_BRIGHT_CAP", "8")
+    the batch must come back right all the same (re-run inside ffs_wait with those windows marked in the plane as
+    candidates for the exact kernel)."""
     rng = np.random.default_rng(12)
     H, W = 240, 400
     img = rng.poisson(3.0, (H, W)).astype(dtype)
@@ -186,6 +186,7 @@ def test_bright_window_list_overflow_falls_back(ffs, dtype, monkeypatch):
         img[y:y + rng.integers(1, 5), x:x + rng.integers(1, 5)] = rng.integers(top // 2, top + 1)
     mask = (rng.random((H, W)) > 0.01).astype(np.uint8)
     ctx = ffs.Context(W, H, dtype, max_batch=2)
+    ctx.set_tuning(bright_cap=8)
     ctx.set_mask(mask)
     ctx.set_params(want_strong_mask=1, want_strong_list=1)
     st = ctx.stream()
@@ -196,18 +197,18 @@ def test_bright_window_list_overflow_falls_back(ffs, dtype, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [np.uint16, np.uint32])
-@pytest.mark.parametrize("group", ["1", "3"])
-def test_super_row_groups(ffs, dtype, group, monkeypatch):
+@pytest.mark.parametrize("group", [1, 3])
+def test_super_row_groups(ffs, dtype, group):
     """The streaming kernels lay the frames of a batch side by side in one super row, as many as keep a group's
-    buffers below 2 GiB (58 Eiger-16M frames); a batch beyond that is cut into several groups.  FFS_K1_GROUP
-    forces small groups so that the cut (3 + 3 + 2 frames, and one frame per group) is exercised on small frames."""
-    monkeypatch.setenv("FFS_K1_GROUP", group)
+    buffers below 2 GiB (58 Eiger-16M frames); a batch beyond that is cut into several groups.  Tuning
+    "frames_per_group" forces small groups so that the cut (3 + 3 + 2 frames, and one frame per group) is exercised on small frames."""
     W, H, B = 333, 77, 8
     frames, mask = [], None
     for i in range(B):
         img, mask = make_frame(W=W, H=H, dtype=dtype, seed=40 + i, n_spots=12, masked=True)
         frames.append(img)
     ctx = ffs.Context(W, H, dtype, max_batch=B)
+    ctx.set_tuning(frames_per_group=group)
     ctx.set_mask(mask)
     ctx.set_params(want_strong_mask=1, want_strong_list=1)
     st = ctx.stream()
@@ -217,15 +218,14 @@ def test_super_row_groups(ffs, dtype, group, monkeypatch):
         assert_frame_matches_oracle(fr, img, mask)
 
 
-@pytest.mark.parametrize("ccl", ["0", "1", "2"])
-@pytest.mark.parametrize("sched", ["0", "3"])
-def test_sparse_stage_variants_agree(ffs, ccl, sched, monkeypatch):
-    """FFS_CCL: 2 = one launch per batch, a workgroup per frame (k_frame_chain: forest in LDS up to 20480 strong
-    pixels, global arrays beyond), 1 = four grid-wide kernels, 0 = round 1's numbered components; FFS_SCHED: shared
-    dense / sparse / upload streams per context (3) or one stream per ffs_stream (0).  Every combination must give
-    the oracle's result: a sparse frame, a frame beyond the LDS forest, an empty frame and a frame with a row-wrap pair."""
-    monkeypatch.setenv("FFS_CCL", ccl)
-    monkeypatch.setenv("FFS_SCHED", sched)
+@pytest.mark.parametrize("ccl", [1, 2])
+@pytest.mark.parametrize("sched", [0, 3])
+@pytest.mark.parametrize("path", [0, 1])
+def test_sparse_stage_variants_agree(ffs, ccl, sched, path):
+    """Tuning "sparse_stage": 2 = one launch per batch, a workgroup per frame (k_frame_chain: forest in LDS up to 20480
+    strong pixels, global arrays beyond), 1 = four grid-wide kernels; "sched": shared dense / sparse / upload streams per
+    context (3) or one stream per ffs_stream (0); "threshold_path".  Every combination must give the oracle's result: a
+    sparse frame, a frame beyond the LDS forest, an empty frame and a frame with a row-wrap pair."""
     rng = np.random.default_rng(21)
     W, H = 640, 480
     sparse, mask = make_frame(W=W, H=H, seed=31, n_spots=40)
@@ -239,6 +239,7 @@ def test_sparse_stage_variants_agree(ffs, ccl, sched, monkeypatch):
     frames = np.stack([sparse, dense, empty, wrap])
     ones = np.ones((H, W), np.uint8)
     ctx = ffs.Context(W, H, np.uint16, max_batch=4, max_strong_per_frame=60000)
+    ctx.set_tuning(sparse_stage=ccl, sched=sched, threshold_path=path)
     ctx.set_params(want_strong_mask=1, want_strong_list=1, min_spot_size=1, max_peak_centroid_separation=3.0)
     st = ctx.stream()
     for rep in range(2):                                           # (second pass: every buffer has been used once)

@@ -54,9 +54,11 @@ def random_case(seed):
 
 
 @pytest.mark.parametrize("seed", range(240))
-def test_random_case(ffs, seed):
+def test_random_case(ffs, seed, tuning=None):
     W, H, dtype, frames, mask, prm, algo, flavour, max_valid, compressed = random_case(seed)
     ctx = ffs.Context(W, H, dtype, max_batch=len(frames))
+    if tuning:
+        ctx.set_tuning(**tuning)
     ctx.set_mask(mask)
     ctx.set_params(algorithm=algo, extended_flavour=flavour, max_valid=max_valid, want_strong_mask=1, want_strong_list=1,
                    want_reflections=1, **prm)
@@ -152,9 +154,7 @@ def test_random_chunks_decode(ffs, seed):
 
 
 @pytest.mark.parametrize("seed", range(0, 240, 6))
-def test_random_case_alternative_kernels(ffs, seed, monkeypatch):
-    """The same sweep through the A/B variants that are not the default: per-pixel-signal candidate
-    kernels (both pixel widths) and the one-pixel-per-lane extended first pass."""
-    monkeypatch.setenv("FFS_K1_VARIANT", "0")
-    monkeypatch.setenv("FFS_EXT_VARIANT", "0")
-    test_random_case(ffs, seed)
+def test_random_case_alternative_kernels(ffs, seed):
+    """The same sweep through the paths that are not the default: bright windows marked in the plane for the exact
+    kernel (both pixel widths), the one-pixel-per-lane extended first pass, the four grid-wide sparse kernels."""
+    test_random_case(ffs, seed, tuning=dict(threshold_path=1, ext_first_pass=0, sparse_stage=1))

@@ -120,15 +120,15 @@ def test_config1_plumbing_frames(ffs):
         assert cc.num_strong_pixels > 500
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2"])
-def test_candidate_kernel_variants(ffs, variant, monkeypatch):
-    """Both candidate-kernel variants (per-pixel test / group screen + LDS queue) must give the
+@pytest.mark.parametrize("path", [0, 1])
+def test_threshold_paths(ffs, path):
+    """Both threshold paths (bright windows -> list -> fix-up kernel / -> plane -> exact kernel) must give the
     oracle's result; frames chosen so the lane-group queue wraps many times per wave."""
-    monkeypatch.setenv("FFS_K1_VARIANT", variant)
     rng = np.random.default_rng(99)
     H, W = 700, 1100
     mask = _mask(rng, H, W, dead=300)
     ctx = ffs.Context(W, H, np.uint16, max_batch=2)
+    ctx.set_tuning(threshold_path=path)
     ctx.set_mask(mask)
     ctx.set_params(want_strong_mask=1, want_strong_list=1)
     frames = np.stack([_spotty(rng, H, W, 0.05, 400, peak=2000), _spotty(rng, H, W, 8.0, 3000, peak=800)])
@@ -261,6 +261,42 @@ def test_stack3d_fed_from_two_contexts(ffs, transport, monkeypatch):
     assert (n_calc, fs, fp) == (want.n_calculated, want.n_filtered_size, want.n_filtered_sep)
     assert_reflections_equal(refl, want.reflections)
     assert len(refl) > 5
+
+
+@pytest.mark.parametrize("transport", ["peer", "rccl"])
+def test_stack3d_takes_an_overflowing_frame_from_the_second_context(ffs, transport, monkeypatch):
+    """A frame with more strong pixels than the stream's lists hold (an ice ring) is absorbed by ffs_wait on any GPU; its
+    list lives on the host afterwards.  When that stream belongs to ANOTHER context than the 3D stack, the batch must
+    still reach the stack: the frames that fitted are packed and sent device to device, the overflow frame's list goes up
+    from the host -- one such frame landing on GPU 1-7 must not end a sweep the single-GPU path finishes."""
+    from oracle import oracle as O
+    from ffs_amd import synth
+    from util import assert_reflections_equal
+    monkeypatch.setenv("FFS_GATHER", transport)
+    ffs.multi_init([0, 0], transport)
+    W, H, NZ = 200, 120, 8
+    p = synth.sweep_params(seed=91, n_frames=NZ, n_spots=30, width=W, height=H)
+    frames = synth.frames(p, range(NZ)).copy()
+    rng = np.random.default_rng(5)
+    for z in (3, 6):                                        # both land in batches of the second context (z // 2 odd)
+        frames[z][rng.random((H, W)) < 0.5] += 400          # ~50 % strong pixels: far beyond the lists' 600 entries
+    ctxs = [ffs.Context(W, H, np.uint16, max_batch=2, max_strong_per_frame=600) for _ in range(2)]
+    for c in ctxs:
+        c.set_params(want_strong_list=1, min_spot_size_3d=4)
+    streams = [c.stream() for c in ctxs]
+    stack = ffs.Stack3D(ctxs[0])
+    slices = [None] * NZ
+    for b, z0 in enumerate(range(0, NZ, 2)):
+        st = streams[b % 2]
+        res = st.process(frames[z0:z0 + 2], first_frame_id=z0)
+        stack.add_batch(st)
+        for j, r in enumerate(res):
+            slices[z0 + j] = (r.strong_k.copy(), r.strong_intensity.copy())
+    assert len(slices[3][0]) > 5000 and len(slices[6][0]) > 5000 and len(slices[2][0]) < 600
+    refl, n_calc, fs, fp = stack.finish()
+    want = O.cc3d(slices, W, H, 4, 2.0)
+    assert (n_calc, fs, fp) == (want.n_calculated, want.n_filtered_size, want.n_filtered_sep)
+    assert_reflections_equal(refl, want.reflections)
 
 
 def test_resolution_mask_matches_oracle_on_eiger_geometry(ffs):
