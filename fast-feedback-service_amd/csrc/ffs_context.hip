@@ -1,5 +1,7 @@
 // ffs_context.hip -- contexts, masks, parameters and tuning, streams (see ffs_internal.hpp for the map of the library).
 // The C ABI is declared in include/ffs_hip.h; every entry point there names the reference interface it replaces.
+#include <sys/mman.h>
+
 #include "ffs_internal.hpp"
 #include "kernels_mask.hpp"
 
@@ -106,7 +108,7 @@ extern "C" int ffs_ctx_create(int device, uint32_t width, uint32_t height, int p
     const uint64_t npx = (uint64_t)width * height;
     c->cap = max_strong ? max_strong : (uint32_t)std::min<uint64_t>(npx, 1u << 18);
     c->cap = (uint32_t)std::min<uint64_t>(c->cap, npx);
-    c->max_comp = std::min<uint32_t>(c->cap, 1u << 16);
+    c->max_comp = std::min<uint32_t>(c->cap, 1u << 14);   // (a frame with more is run again with room for it, as for the lists)
     c->n_tiles = ((int)height + kTileRows - 1) / kTileRows;
     ffs_default_params(&c->params);
     if (hipSetDevice(device) != hipSuccess) {
@@ -122,6 +124,25 @@ extern "C" int ffs_ctx_create(int device, uint32_t width, uint32_t height, int p
         g_create_error = std::string("hipMalloc(mask): ") + hipGetErrorString(e);
         ffs_ctx_destroy(c);
         return FFS_ERR_NOMEM;
+    }
+    // the hot path's code object is loaded here, not by the first worker's first stream (~30 ms), and k_frame_chain's
+    // dynamic LDS is asked for once per device
+    c->chain_ok = chain_prepare_device();
+    {   // ... and so are the context's shared HIP streams (a hardware queue takes milliseconds to create): DESIGN.md section 3.4
+        int lo = 0, hi = 0;
+        hipError_t es = hipDeviceGetStreamPriorityRange(&lo, &hi);  // (least, greatest)
+        if (es == hipSuccess) es = hipStreamCreateWithPriority(&c->dense_st, hipStreamNonBlocking, (lo + hi) / 2);
+        if (es == hipSuccess) es = hipStreamCreateWithFlags(&c->up_st, hipStreamNonBlocking);
+        for (auto& sp : c->sparse_st)
+            if (es == hipSuccess) es = hipStreamCreateWithPriority(&sp, hipStreamNonBlocking, hi);
+        if (es == hipSuccess)
+            for (auto& e : c->chain_ev)
+                if (es == hipSuccess) es = hipEventCreate(&e);
+        if (es != hipSuccess) {
+            g_create_error = std::string("creating the context's HIP streams: ") + hipGetErrorString(es);
+            ffs_ctx_destroy(c);
+            return FFS_ERR_DEVICE;
+        }
     }
     *out = c;
     int rc = ffs_ctx_set_mask(c, nullptr);
@@ -146,6 +167,7 @@ extern "C" void ffs_ctx_destroy(ffs_ctx* c) {
     if (c->up_st) (void)hipStreamDestroy(c->up_st);
     for (auto st : c->sparse_st) if (st) (void)hipStreamDestroy(st);
     for (auto e : c->chain_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& pb : c->pinned_pool) pinned_free(pb);
     delete c;
 }
 
@@ -277,14 +299,17 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     if (s->st2 && s->st2 != s->st) { (void)hipStreamSynchronize(s->st2); if (!s->st2_shared) (void)hipStreamDestroy(s->st2); }
     // (d_n_comp, d_summary and d_overflow live inside the d_num_strong allocation)
     if (s->h_pack_tab) (void)hipHostFree(s->h_pack_tab);
-    void* dev[] = {s->d_occ, s->d_pack_k, s->d_pack_i, s->d_pack_tab, s->d_acc2, s->d_chunk_roots, s->d_bright, s->d_comp, s->d_tab, s->d_dplane,
-                   s->d_eplane, s->d_row_off, s->d_img, s->d_bits, s->d_sbytes, s->d_tile_counts, s->d_num_strong, s->d_list_k, s->d_list_i,
-                   s->d_parent, s->d_recs};
+    // (the stream's device buffers are one slab; what is allocated on first use is freed by itself)
+    void* dev[] = {s->d_slab, s->d_pack_k, s->d_pack_i, s->d_pack_tab, s->d_comp, s->d_tab, s->d_dplane, s->d_eplane};
     for (void* p : dev)
         if (p) (void)hipFree(p);
-    void* host[] = {s->h_tab, s->h_img, s->h_counts, s->h_recs, s->h_list_k, s->h_list_i, s->h_mask};
+    void* host[] = {s->h_tab, s->h_counts, s->h_recs, s->h_list_k, s->h_list_i, s->h_mask};
     for (void* p : host)
         if (p) (void)hipHostFree(p);
+    if (s->h_img) {   // kept for the next stream of the context
+        std::lock_guard<std::mutex> lock(s->ctx->stream_mu);
+        s->ctx->pinned_pool.push_back(s->h_img_buf);
+    }
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
     if (s->ev_pack) (void)hipEventDestroy(s->ev_pack);
@@ -327,55 +352,57 @@ int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uint32_t m
     // (Measured and dropped: CU masks for the two stages, a stream per batch for the sparse work, two dense streams.)
     {
         std::lock_guard<std::mutex> lock(c->stream_mu);
-        if (c->tune.sched >= 3) {
-            int lo = 0, hi = 0;
-            STREAM_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (least, greatest)
-            if (!c->dense_st) STREAM_TRY(hipStreamCreateWithPriority(&c->dense_st, hipStreamNonBlocking, (lo + hi) / 2));
+        if (c->tune.sched >= 3) {   // (the shared streams were created with the context)
             s->st = c->dense_st;
             s->st_shared = true;
-            if (!c->up_st) STREAM_TRY(hipStreamCreateWithFlags(&c->up_st, hipStreamNonBlocking));
             s->st_up = c->up_st;
-            const int j = c->n_streams_made & 1;
-            if (!c->sparse_st[j]) STREAM_TRY(hipStreamCreateWithPriority(&c->sparse_st[j], hipStreamNonBlocking, hi));
-            s->st2 = c->sparse_st[j];
+            s->st2 = c->sparse_st[c->n_streams_made & 1];
             s->st2_shared = true;
         } else {
             STREAM_TRY(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
             s->st2 = s->st;
         }
         ++c->n_streams_made;
-        if (!c->chain_ev[0])
-            for (auto& e : c->chain_ev) STREAM_TRY(hipEventCreate(&e));
-        if (!c->chain_ok) c->chain_ok = chain_prepare_device();   // (else: the four grid-wide kernels)
     }
     if (!s->st_up) s->st_up = s->st;
     for (auto& e : s->ev) STREAM_TRY(hipEventCreate(&e));
-    STREAM_TRY(dmalloc(&s->d_img, B * L.frame_stride));
-    STREAM_TRY(dmalloc(&s->d_bits, B * L.plane_frame_stride));
-    STREAM_TRY(dmalloc(&s->d_sbytes, B * L.bytes_frame_stride));
-    STREAM_TRY(dmalloc(&s->d_tile_counts, tile_counts_bytes(s)));
-    STREAM_TRY(dmalloc(&s->d_occ, B * (size_t)occ_frame_words(L) * 4));
-    STREAM_TRY(dmalloc(&s->d_bright, (size_t)kBrightCap * sizeof(uint2)));
-
-    // per-frame counters in the layout of h_counts, so that one copy brings them all back:
-    // [B] strong pixels | [B] components | [B][8] summary | [1] overflow / error flag
-    STREAM_TRY(dmalloc(&s->d_num_strong, (B * 10 + 1) * 4));
-    s->d_n_comp = s->d_num_strong + B;
-    s->d_summary = s->d_num_strong + 2 * B;
-    s->d_overflow = s->d_num_strong + 10 * B;
-    STREAM_TRY(dmalloc(&s->d_row_off, B * (size_t)(L.H + 1) * 4));
-    STREAM_TRY(dmalloc(&s->d_list_k, B * (size_t)s->cap * 4));
-    STREAM_TRY(dmalloc(&s->d_list_i, B * (size_t)s->cap * 4));
-    STREAM_TRY(dmalloc(&s->d_parent, B * (size_t)s->cap * 4));
-    STREAM_TRY(dmalloc(&s->d_acc2, B * (size_t)s->cap * sizeof(CompAcc2)));
-    STREAM_TRY(dmalloc(&s->d_chunk_roots, B * (size_t)(s->cap / 512 + 1) * 4));
-    STREAM_TRY(dmalloc(&s->d_recs, B * (size_t)s->max_comp * sizeof(ReflOut)));
-    // raw frames, or bitshuffle-LZ4 chunks (which can exceed the raw size by < 1 % when incompressible)
-    s->h_img_bytes = B * ((size_t)L.W * L.H * c->pixel_bytes + (size_t)L.W * L.H * c->pixel_bytes / 128 + 4096);
-    STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_img), s->h_img_bytes, hipHostMallocDefault));
+    {   // ONE device allocation per stream, carved up: hipMalloc is cheap here, but every hipFree costs ~0.25 ms and a
+        // driver that closes 16 streams at the end of a run paid 16 x 20 of them (tools/ubench/alloc_cost.hip)
+        size_t at = 0;
+        auto carve = [&](size_t bytes) { const size_t o = at; at += (bytes + 255) & ~(size_t)255; return o; };
+        const size_t o_img = carve(B * L.frame_stride), o_bits = carve(B * L.plane_frame_stride), o_sbytes = carve(B * L.bytes_frame_stride);
+        const size_t o_counts = carve(tile_counts_bytes(s)), o_occ = carve(B * (size_t)occ_frame_words(L) * 4);
+        const size_t o_bright = carve((size_t)kBrightCap * sizeof(uint2));
+        // per-frame counters in the layout of h_counts, so that one copy brings them all back:
+        // [B] strong pixels | [B] components | [B][8] summary | [1] overflow / error flag
+        const size_t o_ns = carve((B * 10 + 1) * 4), o_row = carve(B * (size_t)(L.H + 1) * 4);
+        const size_t o_k = carve(B * (size_t)s->cap * 4), o_i = carve(B * (size_t)s->cap * 4), o_par = carve(B * (size_t)s->cap * 4);
+        const size_t o_acc = carve(B * (size_t)s->cap * sizeof(CompAcc2)), o_roots = carve(B * (size_t)(s->cap / 512 + 1) * 4);
+        const size_t o_recs = carve(B * (size_t)s->max_comp * sizeof(WireRec2));
+        STREAM_TRY(dmalloc(&s->d_slab, at));
+        uint8_t* base = s->d_slab;
+        s->d_img = base + o_img;
+        s->d_bits = base + o_bits;
+        s->d_sbytes = base + o_sbytes;
+        s->d_tile_counts = reinterpret_cast<uint32_t*>(base + o_counts);
+        s->d_occ = reinterpret_cast<uint32_t*>(base + o_occ);
+        s->d_bright = reinterpret_cast<uint2*>(base + o_bright);
+        s->d_num_strong = reinterpret_cast<uint32_t*>(base + o_ns);
+        s->d_n_comp = s->d_num_strong + B;
+        s->d_summary = s->d_num_strong + 2 * B;
+        s->d_overflow = s->d_num_strong + 10 * B;
+        s->d_row_off = reinterpret_cast<uint32_t*>(base + o_row);
+        s->d_list_k = reinterpret_cast<uint32_t*>(base + o_k);
+        s->d_list_i = reinterpret_cast<uint32_t*>(base + o_i);
+        s->d_parent = reinterpret_cast<uint32_t*>(base + o_par);
+        s->d_acc2 = reinterpret_cast<CompAcc2*>(base + o_acc);
+        s->d_chunk_roots = reinterpret_cast<uint32_t*>(base + o_roots);
+        s->d_recs = reinterpret_cast<ReflOut*>(base + o_recs);
+    }
+    // (the pinned staging area for frames / chunks is allocated on first use: ensure_host_staging)
     STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), (B * 11 + 1) * 4, hipHostMallocDefault));  // (+ [B] per-frame flags, k_frame_chain)
     std::memset(s->h_counts, 0, (B * 11 + 1) * 4);
-    STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_recs), B * (size_t)s->max_comp * sizeof(ReflOut),
+    STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_recs), B * (size_t)s->max_comp * sizeof(WireRec2),
                              hipHostMallocDefault));
     // The sparse kernels write the (few MB of) records and the counters straight into these pinned, device-visible
     // buffers: no copy follows them.  Tuning "direct_records" = 0 keeps the device buffers + copies (A/B).
@@ -399,11 +426,103 @@ int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uint32_t m
     return FFS_OK;
 }
 
+size_t default_staging_bytes(const ffs_stream* s) {
+    // raw frames, or bitshuffle-LZ4 chunks (which can exceed the raw size by < 1 % when incompressible)
+    const size_t frame = (size_t)s->ctx->L.W * s->ctx->L.H * s->ctx->pixel_bytes;
+    return (size_t)s->max_batch * (frame + frame / 128 + 4096);
+}
+
+PinnedBuf pinned_alloc(size_t bytes) {
+    PinnedBuf b;
+    constexpr size_t kHuge = (size_t)2 << 20;
+    const size_t len = (bytes + kHuge - 1) / kHuge * kHuge + kHuge;
+    void* base = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (base != MAP_FAILED) {
+        uint8_t* p = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(base) + kHuge - 1) / kHuge * kHuge);
+        (void)madvise(p, len - kHuge, MADV_HUGEPAGE);
+        for (size_t o = 0; o < bytes; o += 4096) p[o] = 0;   // first touch here: on the calling thread's NUMA node
+        if (hipHostRegister(p, (bytes + 4095) & ~(size_t)4095, hipHostRegisterDefault) == hipSuccess) {
+            b.p = p;
+            b.bytes = bytes;
+            b.map_base = base;
+            b.map_len = len;
+            return b;
+        }
+        (void)hipGetLastError();
+        munmap(base, len);
+    }
+    uint8_t* p = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&p), bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return b;
+    }
+    b.p = p;
+    b.bytes = bytes;
+    return b;
+}
+
+void pinned_free(PinnedBuf& b) {
+    if (!b.p) return;
+    if (b.map_base) {
+        (void)hipHostUnregister(b.p);
+        munmap(b.map_base, b.map_len);
+    } else {
+        (void)hipHostFree(b.p);
+    }
+    b = PinnedBuf{};
+}
+
+int ensure_host_staging(ffs_stream* s, size_t bytes) {
+    ffs_ctx* c = s->ctx;
+    if (s->h_img && s->h_img_bytes >= bytes) return FFS_OK;
+    if (s->busy) {
+        c->err = "the stream's host buffer cannot grow while a batch is in flight";
+        return FFS_ERR_INVALID;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    {
+        std::lock_guard<std::mutex> lock(c->stream_mu);
+        if (s->h_img) {
+            c->pinned_pool.push_back(s->h_img_buf);
+            s->h_img = nullptr;
+            s->h_img_bytes = 0;
+            s->h_img_buf = PinnedBuf{};
+        }
+        int best = -1;   // the smallest pooled buffer that is large enough
+        for (size_t i = 0; i < c->pinned_pool.size(); ++i)
+            if (c->pinned_pool[i].bytes >= bytes && (best < 0 || c->pinned_pool[i].bytes < c->pinned_pool[(size_t)best].bytes)) best = (int)i;
+        if (best >= 0) {
+            s->h_img_buf = c->pinned_pool[(size_t)best];
+            c->pinned_pool.erase(c->pinned_pool.begin() + best);
+        } else if (!c->pinned_pool.empty()) {   // nothing fits: give one too-small buffer back rather than hoarding both
+            pinned_free(c->pinned_pool.back());
+            c->pinned_pool.pop_back();
+        }
+    }
+    if (!s->h_img_buf.p) s->h_img_buf = pinned_alloc(bytes);   // (outside the lock: page faults of several threads run side by side)
+    if (!s->h_img_buf.p) {
+        c->err = "allocation of the stream's pinned staging buffer (" + std::to_string(bytes >> 20) + " MiB) failed";
+        return FFS_ERR_NOMEM;
+    }
+    s->h_img = s->h_img_buf.p;
+    s->h_img_bytes = s->h_img_buf.bytes;
+    return FFS_OK;
+}
+
 extern "C" int ffs_stream_host_buffer(ffs_stream* s, void** ptr, size_t* bytes) {
     if (!s) return FFS_ERR_INVALID;
+    if (!s->h_img) {
+        const int rc = ensure_host_staging(s, default_staging_bytes(s));
+        if (rc != FFS_OK) return rc;
+    }
     if (ptr) *ptr = s->h_img;
     if (bytes) *bytes = s->h_img_bytes;
     return FFS_OK;
+}
+
+extern "C" int ffs_stream_reserve_host(ffs_stream* s, size_t bytes) {
+    if (!s || bytes == 0) return FFS_ERR_INVALID;
+    return ensure_host_staging(s, bytes);
 }
 
 // ---- guarded entry points (the mask conversions grow std::vectors) ---------------------------------------------

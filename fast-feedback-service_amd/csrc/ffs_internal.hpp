@@ -77,6 +77,18 @@ struct Tuning {
 
 struct ffs_stack3d;
 
+// A staging area the DMA engines can read: anonymous memory on transparent huge pages, registered with the runtime
+// (tools/ubench/pin_cost.hip: 17 ms per 256 MB against 54 + 26 ms to allocate and free the same with hipHostMalloc, same
+// 57 GB/s to the device); hipHostMalloc when registering is refused.
+struct PinnedBuf {
+    uint8_t* p = nullptr;      // the usable area (2 MiB aligned when mapped)
+    size_t bytes = 0;
+    void* map_base = nullptr;  // mmap'ed region (null: p came from hipHostMalloc)
+    size_t map_len = 0;
+};
+PinnedBuf pinned_alloc(size_t bytes);   // p == nullptr on failure
+void pinned_free(PinnedBuf& b);
+
 struct ffs_ctx {
     int device = 0;
     Tuning tune;
@@ -96,6 +108,10 @@ struct ffs_ctx {
     int n_streams_made = 0;
     std::mutex stream_mu;            // guards the lazy creation of the shared streams, the stack pool and the event ring
     std::vector<ffs_stack3d*> stack_pool;   // destroyed 3D stacks kept with their buffers for the next sweep (stream_mu)
+    // Pinned host memory costs ~170 ms per GB to allocate and ~100 ms per GB to free, and the runtime serialises both
+    // across threads (tools/ubench/alloc_cost.hip): the staging buffers of destroyed streams are kept for the next
+    // stream of the context and freed with it (stream_mu).
+    std::vector<struct PinnedBuf> pinned_pool;
     std::atomic<int> inflight{0};    // batches between submit and wait, over all ffs_streams of the context
     // Start events of the sparse launches (they ride on the dispatch): the next streaming kernel lets the newest one get
     // its CUs first.  The events belong to the CONTEXT (created with the first stream, destroyed with the context), so a
@@ -132,7 +148,8 @@ struct ffs_stream {
     bool st_shared = false;      // st is the context's dense stream (not ours to destroy)
     hipStream_t st2 = nullptr;   // compaction + connected components + D2H; == st unless the context has sparse streams
     hipEvent_t ev[7] = {};   // [6]: the compressed chunks and their block table are on the device
-    // device
+    // device (one allocation, d_slab, carved up at creation; the buffers of rarely used paths are allocated on first use)
+    uint8_t* d_slab = nullptr;
     uint8_t* d_img = nullptr;
     uint8_t* d_bits = nullptr;
     uint8_t* d_sbytes = nullptr;
@@ -155,8 +172,10 @@ struct ffs_stream {
     uint32_t* d_chunk_roots = nullptr;
     ReflOut* d_recs = nullptr;
     // pinned host
-    uint8_t* h_img = nullptr;
+    uint8_t* h_img = nullptr;      // pinned staging: allocated on first use (ensure_host_staging), sized by what is asked for
     size_t h_img_bytes = 0;
+    PinnedBuf h_img_buf;           // ... and how it was obtained
+    size_t d_comp_bytes = 0;
     uint32_t* h_counts = nullptr;  // [max_batch] num_strong | [max_batch] n_comp | [max_batch*8] summary | [1] overflow | [max_batch] per-frame flags
     ReflOut* h_recs = nullptr;
     uint32_t* d_occ = nullptr;     // [max_batch][occ_frame_words] occupancy of the strong plane (one bit per 16-byte segment)
@@ -246,6 +265,8 @@ static hipError_t dmalloc(T** p, size_t n_bytes) {
 // ---- functions one unit calls in another ----------------------------------------------------------------------
 // ffs_context.hip
 int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uint32_t max_comp, ffs_stream** out);
+int ensure_host_staging(ffs_stream* s, size_t bytes);   // pinned staging of at least `bytes` (contents are not kept when it grows)
+size_t default_staging_bytes(const ffs_stream* s);      // max_batch raw frames (+ the slack incompressible chunks need)
 // ffs_submit.hip
 bool chain_prepare_device();   // asks for k_frame_chain's dynamic LDS on the current device; false: use the four kernels
 ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t pitch, size_t fstride, uint32_t n_frames);

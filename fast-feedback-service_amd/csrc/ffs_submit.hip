@@ -469,7 +469,7 @@ extern "C" int ffs_submit(ffs_stream* s, const void* host_pixels, uint32_t n_fra
 
 static int ensure_decode_buffers(ffs_stream* s) {
     ffs_ctx* c = s->ctx;
-    if (s->d_comp) return FFS_OK;
+    if (s->d_tab) return FFS_OK;
     const size_t es = c->pixel_bytes, nelem = (size_t)c->L.W * c->L.H;
     // bitshuffle's blocking (bshuf_default_block_size, and the loop of bshuf_blocked_wrap_fun)
     const size_t block = (size_t)kDecBlockBytes / es;
@@ -479,7 +479,7 @@ static int ensure_decode_buffers(ffs_stream* s) {
     s->dec_last = (uint32_t)(rem >= 8 ? rem / 8 * 8 : block);
     s->dec_tail = (uint32_t)(rem % 8);
     const size_t tab_bytes = (size_t)s->max_batch * (s->dec_blocks + 1) * sizeof(uint2);
-    if (dmalloc(&s->d_comp, s->h_img_bytes + 64) != hipSuccess || dmalloc(&s->d_tab, tab_bytes) != hipSuccess
+    if (dmalloc(&s->d_tab, tab_bytes) != hipSuccess
         || hipHostMalloc(reinterpret_cast<void**>(&s->h_tab), tab_bytes, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         c->err = "allocation of the compressed-chunk buffers failed";
@@ -533,12 +533,12 @@ static int stage_chunks(ffs_stream* s, const void* const* chunks, const size_t* 
         }
         lo &= ~(size_t)15;
     } else {
+        size_t need = 0;
+        for (uint32_t f = 0; f < n; ++f) need += (chunk_bytes[f] + 15) & ~(size_t)15;
+        rc = ensure_host_staging(s, need + need / 4 + 4096);   // (grows with headroom; kept from then on)
+        if (rc != FFS_OK) return rc;
         size_t cur = 0;
         for (uint32_t f = 0; f < n; ++f) {
-            if (cur + chunk_bytes[f] > s->h_img_bytes) {
-                c->err = "ffs_submit_compressed: the batch's chunks exceed the staging buffer";
-                return FFS_ERR_INVALID;
-            }
             std::memcpy(s->h_img + cur, chunks[f], chunk_bytes[f]);
             base[f] = cur;
             cur = (cur + chunk_bytes[f] + 15) & ~(size_t)15;
@@ -548,6 +548,21 @@ static int stage_chunks(ffs_stream* s, const void* const* chunks, const size_t* 
     if (hi > 0xFFFFFFF0ull) {
         c->err = "ffs_submit_compressed: more than 4 GiB of chunks in one batch";
         return FFS_ERR_INVALID;
+    }
+    if (s->d_comp_bytes < hi + 64) {   // the device side of the staging area follows its size (hipMalloc is cheap)
+        if (s->d_comp) {
+            HIP_TRY(c, hipStreamSynchronize(s->st_up));
+            (void)hipFree(s->d_comp);
+            s->d_comp = nullptr;
+        }
+        const size_t want = std::max(hi + hi / 4 + 4096, s->h_img_bytes) + 64;
+        if (dmalloc(&s->d_comp, want) != hipSuccess) {
+            (void)hipGetLastError();
+            s->d_comp_bytes = 0;
+            c->err = "allocation of the device buffer for compressed chunks failed";
+            return FFS_ERR_NOMEM;
+        }
+        s->d_comp_bytes = want;
     }
     HIP_TRY(c, hipMemcpyAsync(s->d_comp + lo, s->h_img + lo, hi - lo, hipMemcpyHostToDevice, s->st_up));
     return FFS_OK;

@@ -58,7 +58,7 @@ struct Args {
     int pipe_fd = -1, device = 0;
     std::vector<int> devices;  // --devices / --gpus: the frame queue is dealt to all of them
     std::string algorithm = "dispersion", detector_json;
-    bool cpu_decode = false, no_numa_pinning = false;
+    bool cpu_decode = false, no_numa_pinning = false, single_buffer = false, all_threads = false;
 };
 
 static void usage() {
@@ -68,10 +68,12 @@ static void usage() {
       "                  [--min-spot-size-3d N] [--max-peak-centroid-separation N] [--start-index N]\n"
       "                  [-t S] [-fd FD] [-a ALGO] [--dmin MIN D] [--dmax MAX D] [-w \xce\xbb] [--detector JSON]\n"
       "                  [-h5] [--output-for-index] [--batch N] [--cpu-decode] [--strict-dtype]\n"
-      "                  [--devices D0,D1,... | --gpus N] [--no-numa-pinning]\n"
+      "                  [--devices D0,D1,... | --gpus N] [--no-numa-pinning] [--single-buffer] [--all-threads]\n"
       "--devices / --gpus: one context and worker pool per GPU, all pulling frames from the one queue\n"
       "              (-n threads are dealt round-robin to the GPUs, at least one each); rotation sweeps send\n"
       "              their strong-pixel lists to the first GPU's 3D stack (RCCL over xGMI, else peer copies)\n"
+      "--all-threads: every one of the -n threads feeds the GPU (default: at most eight per GPU when chunks are decoded there)\n"
+      "--single-buffer: one batch per worker at a time (default: two, the next is read while the first is on the GPU)\n"
       "--cpu-decode: decompress bitshuffle-LZ4 chunks on the worker thread (the reference's way) instead\n"
       "              of sending them to the GPU as they are\n"
       "FILE: NXmx .nxs/.h5 (needs an HDF5 build), a /dev/shm directory, a ####.cbf template, or\n"
@@ -154,6 +156,8 @@ static Args parse_args(int argc, char** argv) {
         }
         else if (s == "--strict-dtype") r.strict_dtype = true;
         else if (s == "--no-numa-pinning") r.no_numa_pinning = true;
+        else if (s == "--single-buffer") r.single_buffer = true;
+        else if (s == "--all-threads") r.all_threads = true;
         else if (!s.empty() && s[0] == '-' && s.size() > 1) arg_error("Unknown argument: " + s);
         else if (r.file.empty()) r.file = s;
         else arg_error("Maximum number of positional arguments exceeded");
@@ -416,9 +420,9 @@ int main(int argc, char** argv) {
     std::signal(SIGINT, stop_processing);
 
     // ---- device context -------------------------------------------------------------------------------
-    const uint32_t batch = args.batch ? args.batch : std::max<uint32_t>(1, std::min<uint32_t>(8, num_images / std::max(1u, args.threads)));
+    const uint32_t batch = args.batch ? args.batch : std::max<uint32_t>(1, std::min<uint32_t>(4, num_images / std::max(1u, args.threads)));
     std::printf("Image:       %4u x %4u = %u px\n", width, height, width * height);
-    std::printf("GPU batches: %u frames per submit, one stream per CPU thread\n", batch);
+    std::printf("GPU batches: %u frames per submit, %s per worker\n", batch, args.single_buffer ? "one batch in flight" : "two batches in flight");
     std::printf("Running with %u CPU threads\n", args.threads);
 
     // One context per GPU (the reference has one device, -d: src/ffs/cuda_arg_parser.cc:30-61).  With
@@ -539,109 +543,92 @@ int main(int argc, char** argv) {
                             node_known[di] ? ", workers pinned to its CPUs" : " (workers not pinned)");
     }
 
+    // Every worker owns TWO streams and fills one while the other's batch is on the GPU: reading a batch of chunks from the
+    // frame source and the device work of the batch before it overlap inside the worker, not only across workers (the
+    // reference: one frame per thread, read, copy, kernel and host post-processing in sequence, spotfinder.cc:751-1008).
+    struct Slot {
+        ffs_stream* s = nullptr;
+        uint8_t* host = nullptr;       // the stream's pinned staging area (allocated on first use)
+        size_t host_bytes = 0;
+        std::vector<const void*> chunk_ptr;
+        std::vector<size_t> chunk_len;
+        bool in_flight = false;
+    };
     auto worker = [&](int thread_id) {
         const size_t di = (size_t)thread_id % ctxs.size();
         ffs_ctx* ctx = ctxs[di];  // this worker's GPU (shadows the home context)
         if (node_known[di]) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &node_cpus[di]);
-        ffs_stream* s = nullptr;
-        if (ffs_stream_create(ctx, &s) != FFS_OK) {
-            std::printf("Error: %s\n", ffs_last_error(ctx));
-            failed = 1;
-            return;
+        Slot slots[2];
+        const int n_slots = args.single_buffer ? 1 : 2;
+        const auto t_stream = std::chrono::steady_clock::now();
+        auto close_all = [&]() { for (Slot& q : slots) if (q.s) { ffs_stream_destroy(q.s); q.s = nullptr; } };
+        for (int k = 0; k < n_slots; ++k) {
+            if (ffs_stream_create(ctx, &slots[k].s) != FFS_OK) {
+                std::printf("Error: %s\n", ffs_last_error(ctx));
+                failed = 1;
+                close_all();
+                return;
+            }
+            slots[k].chunk_ptr.resize(batch);
+            slots[k].chunk_len.resize(batch);
         }
-        void* host_v = nullptr;
-        size_t host_bytes = 0;
-        ffs_stream_host_buffer(s, &host_v, &host_bytes);
-        uint8_t* host = static_cast<uint8_t*>(host_v);
+        if (args.verbose) {
+            std::lock_guard<std::mutex> lock(print_mutex);
+            std::printf("Thread %2d: streams ready after %.0f ms (%.0f ms since the start)\n", thread_id,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_stream).count(),
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - all_start).count());
+        }
         const size_t frame_bytes = (size_t)width * height * bytes_per_pixel;
         std::vector<uint8_t> raw(frame_bytes * (bytes_per_pixel == 2 ? 2 : 1) + 4096);
         // bitshuffle-LZ4 chunks go to the GPU as they are (read straight into the pinned staging buffer)
         // unless the pixels are needed on the host (--writeout) or --cpu-decode asks for the reference's way
         const bool gpu_decode = reader.get_raw_chunk_compression() == Reader::BITSHUFFLE_LZ4 && !args.cpu_decode
                                 && !args.writeout;
-        std::vector<const void*> chunk_ptr(batch);
-        std::vector<size_t> chunk_len(batch);
-        auto last_received = std::chrono::steady_clock::now();
-        while (!g_stop.load() && !failed.load()) {
-            const uint32_t first = next_image.fetch_add(batch);  // a run of frames instead of one (:752)
-            if (first >= num_images) break;
-            const uint32_t n = std::min(batch, num_images - first);
-            uint32_t got = 0;
-            size_t cursor = 0;  // gpu_decode: fill position in the pinned buffer
-            for (; got < n && !g_stop.load(); ++got) {
-                const uint32_t image_num = first + got;
-                const uint32_t offset_image_num = image_num + args.start_index;  // :756
-                std::span<uint8_t> chunk;
-                {
-                    // readers are not thread-safe in general (:763-765); those that say they are skip the lock
-                    std::unique_lock<std::mutex> lock(reader_mutex, std::defer_lock);
-                    if (!reader.reentrant()) lock.lock();
-                    const auto w0 = std::chrono::steady_clock::now();
-                    while (!reader.is_image_available(offset_image_num) && !g_stop.load()) {
-                        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - last_received).count();
-                        if (waited > args.timeout) {  // :776-787
-                            std::printf("Timeout waiting for image %u\n", offset_image_num);
-                            g_stop.store(true);
-                            break;
-                        }
-                        std::this_thread::sleep_for(100ms);
-                    }
-                    if (g_stop.load()) break;
-                    last_received = std::chrono::steady_clock::now();
-                    time_waiting_acc.fetch_add(std::chrono::duration<double>(last_received - w0).count());
-                    for (;;) {  // zero-length reads on /dev/shm: retry (:805-821)
-                        chunk = gpu_decode ? reader.get_raw_chunk(offset_image_num, {host + cursor, host_bytes - cursor})
-                                           : reader.get_raw_chunk(offset_image_num, raw);
-                        if (chunk.size() != 0) break;
-                        std::printf("\033[1mRace Condition?!?? Got buffer size 0 for image %u. Sleeping.\033[0m\n", image_num);
-                        std::this_thread::sleep_for(100ms);
-                    }
-                }
-                if (gpu_decode) {
-                    chunk_ptr[got] = chunk.data();
-                    chunk_len[got] = chunk.size();
-                    cursor = (size_t)(chunk.data() - host) + ((chunk.size() + 63) & ~(size_t)63);
-                    continue;
-                }
-                uint8_t* dst = host + (size_t)got * frame_bytes;  // decode outside the lock (:823-842)
-                switch (reader.get_raw_chunk_compression()) {
-                case Reader::BITSHUFFLE_LZ4:
-                    if (chunk.size() < 12 || bshuf_decompress_lz4(chunk.data() + 12, chunk.size() - 12, dst, (size_t)width * height, bytes_per_pixel) < 0) {
-                        std::printf("Error: corrupt bitshuffle-LZ4 chunk for image %u\n", image_num);
-                        failed = 1;
-                    }
-                    break;
-                case Reader::BYTE_OFFSET_32:
-                    if (bytes_per_pixel == 2) byte_offset_decompress(chunk.data(), chunk.size(), reinterpret_cast<uint16_t*>(dst), (size_t)width * height);
-                    else byte_offset_decompress(chunk.data(), chunk.size(), reinterpret_cast<uint32_t*>(dst), (size_t)width * height);
-                    break;
-                case Reader::NONE:
-                    std::memcpy(dst, chunk.data(), std::min(chunk.size(), frame_bytes));
-                    break;
-                }
-            }
-            if (got == 0 || failed.load()) break;
-            const ffs_frame_result* res = nullptr;
-            uint32_t nres = 0;
-            const int sub = gpu_decode ? ffs_submit_compressed(s, chunk_ptr.data(), chunk_len.data(), got, first)
-                                       : ffs_submit(s, host, got, first);
-            if (sub != FFS_OK || ffs_wait(s, &res, &nres) != FFS_OK) {
+        // The pinned staging area is what a worker's set-up costs (~170 ms per GB, serialised over all threads by the runtime):
+        // decoded frames need `batch` frames of it; chunks that the GPU decodes need `batch` CHUNKS, sized once the first one
+        // has been seen (+ 25 %), and a batch that does not fit is cut short -- the area then grows for the next one.
+        size_t chunk_estimate = 0;
+        auto take_host = [&](Slot& S, size_t want) {
+            void* v = nullptr;
+            if (ffs_stream_reserve_host(S.s, want) != FFS_OK || ffs_stream_host_buffer(S.s, &v, &S.host_bytes) != FFS_OK) {
                 std::printf("Error: %s\n", ffs_last_error(ctx));
                 failed = 1;
-                break;
+                return false;
+            }
+            S.host = static_cast<uint8_t*>(v);
+            return true;
+        };
+
+        double t_wait = 0, t_emit = 0;
+        // wait for a slot's batch and hand out its results (the reference's post-processing of one image, :901-1087)
+        auto collect = [&](Slot& S) -> bool {
+            if (!S.in_flight) return true;
+            S.in_flight = false;
+            const ffs_frame_result* res = nullptr;
+            uint32_t nres = 0;
+            const auto t_w0 = std::chrono::steady_clock::now();
+            const int wrc = ffs_wait(S.s, &res, &nres);
+            t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w0).count();
+            const auto t_e0 = std::chrono::steady_clock::now();
+            struct EmitTimer { double& acc; std::chrono::steady_clock::time_point t0;
+                               ~EmitTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } emit_timer{t_emit, t_e0};
+            if (wrc != FFS_OK) {
+                std::printf("Error: %s\n", ffs_last_error(ctx));
+                failed = 1;
+                return false;
             }
             float tm[5] = {0};
-            ffs_stream_timings(s, tm);
+            ffs_stream_timings(S.s, tm);
             if (rotation) {
                 // key = image number read (rotation_slices[offset_image_num], :913-918); the stack has its own lock (the
                 // reference's rotation_slices_mutex), held only while the transfer is enqueued
-                if (ffs_stack3d_add_batch(stack, s) != FFS_OK) { std::printf("Error: %s\n", ffs_last_error(ctx)); failed = 1; break; }
+                if (ffs_stack3d_add_batch(stack, S.s) != FFS_OK) { std::printf("Error: %s\n", ffs_last_error(ctx)); failed = 1; return false; }
             }
             for (uint32_t i = 0; i < nres; ++i) {
                 const ffs_frame_result& r = res[i];
                 const uint32_t image_num = (uint32_t)r.frame_id;
                 if (args.writeout && r.strong_mask) {  // :937-994
-                    const uint8_t* px = host + (size_t)i * frame_bytes;
+                    const uint8_t* px = S.host + (size_t)i * frame_bytes;
                     std::vector<uint8_t> img((size_t)width * height * 3);
                     for (size_t k = 0; k < (size_t)width * height; ++k) {
                         const float v = bytes_per_pixel == 2 ? (float)reinterpret_cast<const uint16_t*>(px)[k]
@@ -720,12 +707,143 @@ int main(int argc, char** argv) {
                 }
                 completed += 1;
             }
+            return true;
+        };
+
+        auto last_received = std::chrono::steady_clock::now();
+        uint32_t run_first = 0, run_n = 0, run_done = 0;   // the run of frame numbers this worker took, and how far it is through it
+        int cur = 0;
+        double t_read = 0, t_submit = 0;   // (-v: where this worker's time went)
+        uint32_t n_batches = 0;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        while (!g_stop.load() && !failed.load()) {
+            if (run_done >= run_n) {
+                run_first = next_image.fetch_add(batch);  // a run of frames instead of one (:752)
+                if (run_first >= num_images) break;
+                run_n = std::min(batch, num_images - run_first);
+                run_done = 0;
+            }
+            Slot& S = slots[cur];
+            if (!collect(S)) break;   // (only with --single-buffer: otherwise the slot was collected after the other's submit)
+            if (!gpu_decode && !S.host && !take_host(S, (size_t)batch * frame_bytes)) break;
+            const uint32_t first = run_first + run_done;
+            const uint32_t n = run_n - run_done;
+            uint32_t got = 0;
+            size_t cursor = 0;  // gpu_decode: fill position in the pinned buffer
+            bool cut_short = false;
+            const auto t_fill = now();
+            for (; got < n && !g_stop.load() && !cut_short; ++got) {
+                const uint32_t image_num = first + got;
+                const uint32_t offset_image_num = image_num + args.start_index;  // :756
+                std::span<uint8_t> chunk;
+                {
+                    // readers are not thread-safe in general (:763-765); those that say they are skip the lock
+                    std::unique_lock<std::mutex> lock(reader_mutex, std::defer_lock);
+                    if (!reader.reentrant()) lock.lock();
+                    const auto w0 = std::chrono::steady_clock::now();
+                    while (!reader.is_image_available(offset_image_num) && !g_stop.load()) {
+                        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - last_received).count();
+                        if (waited > args.timeout) {  // :776-787
+                            std::printf("Timeout waiting for image %u\n", offset_image_num);
+                            g_stop.store(true);
+                            break;
+                        }
+                        std::this_thread::sleep_for(100ms);
+                    }
+                    if (g_stop.load()) break;
+                    last_received = std::chrono::steady_clock::now();
+                    time_waiting_acc.fetch_add(std::chrono::duration<double>(last_received - w0).count());
+                    for (;;) {  // zero-length reads on /dev/shm: retry (:805-821)
+                        if (gpu_decode && S.host) {
+                            chunk = reader.get_raw_chunk(offset_image_num, {S.host + cursor, S.host_bytes - cursor});
+                            if (chunk.size() != 0 && chunk.size() >= S.host_bytes - cursor && S.host_bytes - cursor < raw.size()) {
+                                // the read filled what was left of the staging area: the chunk may be cut.  With frames already
+                                // in this batch, send those and start the next batch with this one; else the area is too small
+                                if (got > 0) { cut_short = true; break; }
+                                if (!take_host(S, std::min(S.host_bytes * 2 + (size_t)batch * 4096, (size_t)batch * raw.size()))) break;
+                                continue;
+                            }
+                        } else {
+                            chunk = reader.get_raw_chunk(offset_image_num, raw);
+                        }
+                        if (chunk.size() != 0) break;
+                        std::printf("\033[1mRace Condition?!?? Got buffer size 0 for image %u. Sleeping.\033[0m\n", image_num);
+                        std::this_thread::sleep_for(100ms);
+                    }
+                }
+                if (failed.load()) break;
+                if (cut_short) break;   // (this frame starts the next batch)
+                if (gpu_decode && !S.host) {   // this slot's first chunk: now the staging area can be sized
+                    if (!chunk_estimate) chunk_estimate = ((chunk.size() + chunk.size() / 4 + 4096) + 63) & ~(size_t)63;
+                    if (!take_host(S, std::min((size_t)batch * std::max(chunk_estimate, chunk.size() + 64), (size_t)batch * raw.size()))) break;
+                    std::memcpy(S.host, chunk.data(), chunk.size());
+                    chunk = {S.host, chunk.size()};
+                }
+                if (gpu_decode) {
+                    S.chunk_ptr[got] = chunk.data();
+                    S.chunk_len[got] = chunk.size();
+                    cursor = (size_t)(chunk.data() - S.host) + ((chunk.size() + 63) & ~(size_t)63);
+                    continue;
+                }
+                uint8_t* dst = S.host + (size_t)got * frame_bytes;  // decode outside the lock (:823-842)
+                switch (reader.get_raw_chunk_compression()) {
+                case Reader::BITSHUFFLE_LZ4:
+                    if (chunk.size() < 12 || bshuf_decompress_lz4(chunk.data() + 12, chunk.size() - 12, dst, (size_t)width * height, bytes_per_pixel) < 0) {
+                        std::printf("Error: corrupt bitshuffle-LZ4 chunk for image %u\n", image_num);
+                        failed = 1;
+                    }
+                    break;
+                case Reader::BYTE_OFFSET_32:
+                    if (bytes_per_pixel == 2) byte_offset_decompress(chunk.data(), chunk.size(), reinterpret_cast<uint16_t*>(dst), (size_t)width * height);
+                    else byte_offset_decompress(chunk.data(), chunk.size(), reinterpret_cast<uint32_t*>(dst), (size_t)width * height);
+                    break;
+                case Reader::NONE:
+                    std::memcpy(dst, chunk.data(), std::min(chunk.size(), frame_bytes));
+                    break;
+                }
+            }
+            if (got == 0 || failed.load()) break;
+            run_done += got;
+            const auto t_sub = now();
+            t_read += secs(t_fill, t_sub);
+            const int sub = gpu_decode ? ffs_submit_compressed(S.s, S.chunk_ptr.data(), S.chunk_len.data(), got, first)
+                                       : ffs_submit(S.s, S.host, got, first);
+            if (sub != FFS_OK) {
+                std::printf("Error: %s\n", ffs_last_error(ctx));
+                failed = 1;
+                break;
+            }
+            S.in_flight = true;
+            t_submit += secs(t_sub, now());
+            ++n_batches;
+            // the batch before this one has had a whole read's time on the GPU: hand out its results now
+            if (n_slots == 2 && !collect(slots[cur ^ 1])) break;
+            cur = (cur + 1) % n_slots;
         }
-        ffs_stream_destroy(s);
+        for (int k = 0; k < n_slots; ++k)   // the older batch first
+            if (!failed.load()) collect(slots[(cur + k) % n_slots]);
+        const auto t_c0 = now();
+        close_all();
+        if (args.verbose) {
+            std::lock_guard<std::mutex> lock(print_mutex);
+            std::printf("Thread %2d: %u batches; reading %.0f ms, submit calls %.0f ms, waiting for the GPU %.0f ms, results out %.0f ms, "
+                        "closing streams %.0f ms; done %.0f ms after the start\n", thread_id, n_batches, t_read * 1e3, t_submit * 1e3, t_wait * 1e3,
+                        t_emit * 1e3, secs(t_c0, now()) * 1e3, secs(all_start, now()) * 1e3);
+        }
     };
     {
+        // How many of the -n threads feed the GPUs.  The reference needs one thread per frame in flight because its threads
+        // decompress (service.py passes --threads 40); here a worker only moves chunks from the frame source into pinned
+        // memory and two batches per worker are in flight, so eight per GPU saturate PCIe (tools/cli_profile.sh: 8 workers
+        // 3.6-4.0 k frames/s, 12: 3.1 k, 40: 1.6 k -- beyond eight they only contend for the runtime's locks).  Threads that
+        // decompress on the host (--cpu-decode, CBF, --writeout) are all used.
+        uint32_t n_workers = args.threads;
+        const bool chunks_to_gpu = reader.get_raw_chunk_compression() == Reader::BITSHUFFLE_LZ4 && !args.cpu_decode && !args.writeout;
+        if (chunks_to_gpu && !args.all_threads) n_workers = std::min<uint32_t>(n_workers, 8 * n_dev);
+        if (args.verbose && n_workers != args.threads) std::printf("Workers: %u of the %u threads feed the GPU(s)\n", n_workers, args.threads);
         std::vector<std::thread> threads;
-        for (uint32_t t = 0; t < args.threads; ++t) threads.emplace_back(worker, (int)t);
+        for (uint32_t t = 0; t < n_workers; ++t) threads.emplace_back(worker, (int)t);
         for (auto& t : threads) t.join();
     }
     if (failed.load()) return 1;

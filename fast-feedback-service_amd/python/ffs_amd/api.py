@@ -76,7 +76,7 @@ EXPORTS = [
     "ffs_submit_device", "ffs_ctx_device_layout", "ffs_wait", "ffs_stream_batch_arrays", "ffs_stream_timings",
     "ffs_submit_compressed", "ffs_decode_only", "ffs_stream_spot_centres", "ffs_bench_threshold", "ffs_bench_hbm", "ffs_stream_debug_planes", "ffs_stream_debug_bitplane", "ffs_selftest_sqrt", "ffs_stack3d_create",
     "ffs_stack3d_destroy", "ffs_stack3d_add_batch", "ffs_stack3d_add_slice", "ffs_stack3d_finish", "ffs_stack3d_signals", "ffs_stack3d_last_finish_ms", "ffs_multi_init", "ffs_multi_transport",
-    "ffs_ctx_set_tuning", "ffs_bench_pipeline", "ffs_device_numa_node",
+    "ffs_ctx_set_tuning", "ffs_bench_pipeline", "ffs_device_numa_node", "ffs_stream_reserve_host",
 ]
 
 _lib = None
@@ -103,6 +103,7 @@ def load_library():
         L.ffs_bench_pipeline.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32,
                                          C.c_uint32, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.ffs_device_numa_node.argtypes = [C.c_int]
+        L.ffs_stream_reserve_host.argtypes = [C.c_void_p, C.c_size_t]
         L.ffs_ctx_apply_resolution_mask.argtypes = [C.c_void_p] + [C.c_float] * 8
         L.ffs_ctx_device_layout.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.ffs_stream_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
@@ -275,8 +276,13 @@ class Stream:
         p, n = C.c_void_p(), C.c_size_t()
         self.ctx._check(self._lib.ffs_stream_host_buffer(self._h, C.byref(p), C.byref(n)))
         frames = self.ctx.max_batch * self.ctx.H * self.ctx.W * self.ctx.dtype.itemsize  # (+ slack for chunks)
+        assert n.value >= frames, "the staging area was reserved smaller than max_batch frames (reserve_host)"
         buf = (C.c_uint8 * frames).from_address(p.value)
         return np.frombuffer(buf, dtype=self.ctx.dtype).reshape(self.ctx.max_batch, self.ctx.H, self.ctx.W)
+
+    def reserve_host(self, nbytes: int):
+        """Size the pinned staging area before its first use (ffs_stream_reserve_host), e.g. for chunks instead of frames."""
+        self.ctx._check(self._lib.ffs_stream_reserve_host(self._h, nbytes))
 
     def host_bytes(self) -> np.ndarray:
         """The same staging area as bytes, including its slack (for compressed chunks placed in it)."""

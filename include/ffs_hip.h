@@ -176,6 +176,12 @@ void ffs_stream_destroy(ffs_stream *s);
  * reference's workers decompress into their pinned host_image (spotfinder.cc:731, :828-842),
  * then pass the same pointer to ffs_submit(). */
 int ffs_stream_host_buffer(ffs_stream *s, void **ptr, size_t *bytes);
+/* The staging area is pinned memory, which costs ~170 ms per GB to allocate (and the runtime serialises the
+ * allocations of all threads): it is allocated on first use, max_batch raw frames by default.  A producer of
+ * compressed chunks that knows it needs less (max_batch chunks, not max_batch frames) says so BEFORE its first
+ * ffs_stream_host_buffer(); a later call with a larger size grows the area (contents are not kept; not while a
+ * batch is in flight).  Staging areas of destroyed streams are reused by the context's next streams. */
+int ffs_stream_reserve_host(ffs_stream *s, size_t bytes);
 
 /* cudaMemcpy2DAsync H2D + call_do_spotfinding_dispersion + D2H + ConnectedComponents
  * (spotfinder.cc:846-905), for n_frames dense host frames (each W*H pixels, consecutive).
