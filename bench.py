@@ -568,6 +568,7 @@ def main():
                          "(the C++ driver's model) instead of one rank per GPU")
     ap.add_argument("--dry-run", action="store_true", help="rehearse launcher + gather plumbing on CPU (gloo), no GPU")
     ap.add_argument("--launch-timeout", type=float, default=1500.0)
+    ap.add_argument("--tune", default="", help="ffs_ctx_set_tuning pairs for A/B runs, 'key=value,key=value' (results are the same)")
     args = ap.parse_args()
 
     launched = "WORLD_SIZE" in os.environ
@@ -619,6 +620,8 @@ def main():
     frames, mask = make_inputs(args.workload, n_unique, rank)
 
     ctx = ffs_amd.Context(W, H, dt, max_batch=B, device=local_rank)
+    if args.tune:
+        ctx.set_tuning(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune.split(",") if kv})
     ctx.set_mask(mask)
     ext = args.algorithm == "dispersion_extended"
     ctx.set_params(want_reflections=1, algorithm=1 if ext else 0)

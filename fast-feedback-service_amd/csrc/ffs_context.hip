@@ -265,7 +265,7 @@ extern "C" int ffs_ctx_set_tuning(ffs_ctx* c, const char* key, long long value) 
     bool ok = true;
     if (k == "threshold_path") { if ((ok = in(0, 1))) t.threshold_path = (int)value; }
     else if (k == "ext_first_pass") { if ((ok = value == 0 || value == 2)) t.ext_first_pass = (int)value; }
-    else if (k == "sparse_stage") { if ((ok = in(1, 2))) t.sparse_stage = (int)value; }
+    else if (k == "sparse_stage") { if ((ok = in(1, 3))) t.sparse_stage = (int)value; }
     else if (k == "sched") { if ((ok = (value == 0 || value == 3) && c->n_streams_made == 0)) t.sched = (int)value; }
     else if (k == "chain_first") { if ((ok = in(0, 64))) t.chain_first = (int)value; }
     else if (k == "bright_cap") { if ((ok = in(0, kBrightCap))) t.bright_cap = (int)value; }
@@ -275,6 +275,8 @@ extern "C" int ffs_ctx_set_tuning(ffs_ctx* c, const char* key, long long value) 
     else if (k == "occupancy_bitmap") { if ((ok = in(0, 1))) t.occupancy_bitmap = (int)value; }
     else if (k == "direct_records") { if ((ok = in(0, 1) && c->n_streams_made == 0)) t.direct_records = (int)value; }
     else if (k == "decode_in_dense_stream") { if ((ok = in(0, 1))) t.decode_in_dense_stream = (int)value; }
+    else if (k == "rows_ahead") { if ((ok = in(2, 4))) t.rows_ahead = (int)value; }
+    else if (k == "ccl_grid") { if ((ok = in(1, 1024))) t.ccl_grid = (int)value; }
     else {
         c->err = "ffs_ctx_set_tuning: unknown key '" + k + "'";
         return FFS_ERR_INVALID;

@@ -56,7 +56,8 @@ struct Tuning {
     int threshold_path = 0;     // 0: bright windows -> list -> k_bright_fix; 1: bright windows -> plane -> k_exact (also the
                                 //    fall-back when the list overflows)
     int ext_first_pass = 2;     // extended algorithm, 16-bit pixels: 2 = streaming kernel, 0 = k_ext_first
-    int sparse_stage = 2;       // 2 = one launch per batch, a workgroup per frame (k_frame_chain); 1 = four grid-wide kernels
+    int sparse_stage = 2;       // one launch per batch, a workgroup per frame (k_frame_chain): 3 = always, 2 = unless the stream's previous
+                                //    batch held a frame beyond its LDS forest; 1 = four grid-wide kernels
     int sched = 3;              // 3 = the context's streams share one dense, two sparse and one upload HIP stream; 0 = one HIP stream per ffs_stream
     int chain_first = 2;        // while at most n batches are in flight the sparse launch does the bright fix-up and the next
                                 //    streaming kernel waits for its start; 0 = never
@@ -68,6 +69,7 @@ struct Tuning {
     int direct_records = 1;     // records and counters are written straight into pinned host memory
     int decode_in_dense_stream = 1;   // the decode kernel runs in the dense kernels' stream (0: in the upload stream)
     int ccl_grid = 32;          // workgroups per frame of the grid-wide sparse kernels
+    int rows_ahead = 2;         // rows of loads a wave of the 16-bit streaming kernel keeps in flight (2, 3 or 4)
 #ifdef FFS_EXPERIMENTS
     struct Exp {
         int k1_debug = 0, chain_skip = 0, chain_stop = 0, dummy_us = 0, dummy_wg = 32, dummy_threads = 1024, dummy_lds = 0;

@@ -117,8 +117,12 @@ static dim3 stream_grid(const ThresholdArgs& a, uint32_t n_frames) {
 // Start and stop events ride on the dispatch itself (its completion signal): no marker packets around it.
 static void launch_stream(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames, hipEvent_t start, hipEvent_t stop) {
     const dim3 grid = stream_grid(a, n_frames);
-    if (s->ctx->pixel_bytes == 4) hipExtLaunchKernelGGL(k_stream_u32<2>, grid, dim3(64), 0, s->st, start, stop, 0, a);
-    else hipExtLaunchKernelGGL((k_stream_u16<2>), grid, dim3(64), 0, s->st, start, stop, 0, a);
+    if (s->ctx->pixel_bytes == 4 && a.dense_mask) hipExtLaunchKernelGGL((k_stream_u32<2, true>), grid, dim3(64), 0, s->st, start, stop, 0, a);
+    else if (s->ctx->pixel_bytes == 4) hipExtLaunchKernelGGL((k_stream_u32<2, false>), grid, dim3(64), 0, s->st, start, stop, 0, a);
+    else if (a.dense_mask) hipExtLaunchKernelGGL((k_stream_u16<2, false, true>), grid, dim3(64), 0, s->st, start, stop, 0, a);
+    else if (s->ctx->tune.rows_ahead == 3) hipExtLaunchKernelGGL((k_stream_u16<3, false, false>), grid, dim3(64), 0, s->st, start, stop, 0, a);
+    else if (s->ctx->tune.rows_ahead >= 4) hipExtLaunchKernelGGL((k_stream_u16<4, false, false>), grid, dim3(64), 0, s->st, start, stop, 0, a);
+    else hipExtLaunchKernelGGL((k_stream_u16<2, false, false>), grid, dim3(64), 0, s->st, start, stop, 0, a);
 }
 static void launch_bright_fix(ffs_stream* s, const ThresholdArgs& a, hipStream_t st) {
     if (s->ctx->pixel_bytes == 4) hipLaunchKernelGGL(k_bright_fix<uint32_t>, dim3(32), dim3(256), 0, st, a);
@@ -144,7 +148,8 @@ static void launch_ext_first(ffs_stream* s, const ThresholdArgs& a, uint32_t n_f
         // the kernel writes the non-zero bytes of the first-pass plane; the bright-list count sits behind the tile counts
         (void)hipMemsetAsync(a.dplane, 0, (size_t)n_frames * a.plane_frame_stride, s->st);
         (void)hipMemsetAsync(a.tile_counts, 0, tile_counts_bytes(s), s->st);
-        hipExtLaunchKernelGGL((k_stream_u16<2, true>), stream_grid(a, n_frames), dim3(64), 0, s->st, start, stop, 0, a);
+        if (a.dense_mask) hipExtLaunchKernelGGL((k_stream_u16<2, true, true>), stream_grid(a, n_frames), dim3(64), 0, s->st, start, stop, 0, a);
+        else hipExtLaunchKernelGGL((k_stream_u16<2, true, false>), stream_grid(a, n_frames), dim3(64), 0, s->st, start, stop, 0, a);
         hipLaunchKernelGGL((k_bright_fix<uint16_t, true>), dim3(32), dim3(256), 0, s->st, a);
         return;
     }
@@ -247,6 +252,15 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
     // The whole sparse stage in one launch, one workgroup per frame (kernels_chain.hpp) ...
     bool will_chain = c->tune.sparse_stage >= 2 && L.H <= 65535 && c->chain_ok && s->direct_recs && s->h_counts_dev
                       && c->n_tiles <= kChainMaxTiles && L.H <= kChainMaxRows;
+    // ... as long as the frames' strong pixels fit its LDS forest.  A frame beyond that runs the same stages on global arrays
+    // inside its one workgroup (2.8 ms for 32 frames of 61 k strong pixels, the extended algorithm on the bench frames),
+    // where the four grid-wide kernels spread the work over the machine: the path of this batch follows what the stream's
+    // previous batch held (data that is dense stays dense; a single dense frame costs one slow batch).
+    if (will_chain && c->tune.sparse_stage == 2 && s->n_frames > 0) {
+        uint32_t prev_max = 0;
+        for (uint32_t f = 0; f < s->n_frames; ++f) prev_max = std::max(prev_max, s->h_counts[f]);
+        if (prev_max > (uint32_t)kChainLdsEntries) will_chain = false;
+    }
 #ifdef FFS_EXPERIMENTS
     if (c->tune.exp.chain_skip) will_chain = false;
 #endif
@@ -321,8 +335,8 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
     ca.occ_frame_words = occ_frame_words(L);
     ca.occ_spr = L.mpitch / 16;
     // only the streaming kernels and their fix-up keep the bitmap (path 1: a superset of the final plane, which is fine)
-    ca.use_occ = (streamed && c->tune.occupancy_bitmap) ? 1 : 0;
-    s->occ_dirty = streamed && !(ca.use_occ && will_chain);   // nobody consumes (and clears) the bits the streaming kernel sets
+    ca.use_occ = c->tune.occupancy_bitmap ? 1 : 0;   // (kept by the streaming kernels, their fix-up and the extended algorithm's final pass)
+    s->occ_dirty = !(ca.use_occ && will_chain);      // nobody consumes (and clears) the bits this batch sets
 
     SegArgs sa{};
     sa.list_k = s->d_list_k;

@@ -121,16 +121,14 @@ __device__ __forceinline__ uint32_t dpp_shl_add(uint32_t from_neighbour, uint32_
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)from_neighbour, 0x130, 0xf, 0xf, true) + addend;
 }
 
-struct RowRegsS {
-    uint4 raw;      // 8 pixels
-    uint32_t info;  // ginfo dword
-};
 
 // EXT = true: the first pass of the extended algorithm.  Same stream, ring, sums and queue; the group screen is a
 // float32 upper bound of a = m y - x^2 - x (m - 1) against a lower bound of c (largest sum p^2 and smallest sum p of
 // the group's eight windows), the drain decides "dispersion above background" exactly for every valid pixel of a
 // queued group, and the plane written (its non-zero bytes; the host zeroes it before the launch) is a.dplane.
-template <int KAHEAD, bool EXT = false>
+// DENSE: the byte mask is zero-filled too (somebody asked for it); a template parameter so that the hot path carries neither
+// the stores nor their branch.
+template <int KAHEAD, bool EXT = false, bool DENSE = false>
 __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     __shared__ uint32_t s_q[kSQWords][kQCap];
     __shared__ uint16_t s_list[kQCap * 8];  // drain: (queue entry << 3 | pixel) of every candidate pixel
@@ -176,54 +174,73 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     const int total = (yb1 - yb0) + 6;  // incoming rows yb0-3 .. yb1+2
     const float kS = a.kS;
 
-    uint32_t ring[7][4];   // masked pixels of the last seven rows, two per register as loaded
+    // Ring of NS = 7 + KAHEAD row slots, row i in slot i % NS: the seven rows of the window AND the rows in flight.  A row's
+    // 16 bytes are loaded straight into its slot, masked there in place when the row comes in, and the slot of the row that
+    // leaves the window (i - 7) is the one row i + KAHEAD is loaded into -- after the vertical update has read it.  No
+    // register is ever copied (a seven-slot ring with the loads landing elsewhere cost four v_mov per row).
+    constexpr int NS = 7 + KAHEAD;
+    uint32_t ring[NS][4];  // masked pixels, two per register as loaded
+    uint32_t rinfo[NS];    // ginfo dword that came with the row
     uint32_t col[8], colq[8];
     uint32_t M[4] = {0, 0, 0, 0};  // pair masks of the current mask byte
     uint32_t mprev = 0;
-    RowRegsS pre[7];
 #pragma unroll
-    for (int s = 0; s < 7; ++s) {
+    for (int s = 0; s < NS; ++s) {
+        rinfo[s] = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) ring[s][q] = 0;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) { col[j] = 0; colq[j] = 0; }
+    // lanes that own output, as a wave mask (scalar): the flag ballot below is the compare's own mask ANDed with it
+    const unsigned long long owned_mask = __builtin_amdgcn_ballot_w64(owned);
 
-    auto fetch = [&](RowRegsS& dst, int i) {
+    // Loads of incoming row i.  Rows outside the image must count as zeros: their ginfo dword says "nothing valid" (the table's
+    // rows H .. H + 2 hold no mask bits, rows above the image are killed below), so the pixels they bring are masked off in
+    // mask_row like any masked pixel -- the pixel load itself only has to stay inside the buffer (row clamped: two scalar
+    // instructions instead of a chain of compares and selects per load).
+    auto fetch = [&](int slot, int i) {
         const int yin = yb0 - 3 + i;
-        const bool in_rows = (i < total) & (yin >= 0);            // wave-uniform (scalar ALU)
-        const bool ok_img = in_rows & (yin < a.H);
-        const bool ok_info = in_rows & (yin < a.H + kInfoExtraRows);
-        const uint32_t row = ok_info ? (uint32_t)yin : 0u;
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_img, off_px | (ok_img ? 0u : kOob), (ok_img ? row : 0u) * a.pitch, 0);
-        dst.raw = make_uint4(v[0], v[1], v[2], v[3]);
-        dst.info = __builtin_amdgcn_raw_buffer_load_b32(r_info, off_info | (ok_info ? 0u : kOob), row * a.gpitch, 0);
+        const uint32_t prow = (uint32_t)min(max(yin, 0), a.H - 1);
+        const uint32_t irow = (uint32_t)min(max(yin, 0), a.H + kInfoExtraRows - 1);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_img, off_px, prow * a.pitch, 0);
+        ring[slot][0] = v[0]; ring[slot][1] = v[1]; ring[slot][2] = v[2]; ring[slot][3] = v[3];
+        rinfo[slot] = __builtin_amdgcn_raw_buffer_load_b32(r_info, off_info | (yin < 0 ? kOob : 0u), irow * a.gpitch, 0);
     };
 
-    // incoming row -> four registers of two masked pixels each
-    auto unpack = [&](const RowRegsS& r, uint32_t (&P)[4]) {
-        const uint32_t mb = r.info & 0xFFu;
-        if (__ballot(mb != mprev) != 0ull) {  // wave-uniform; rare (module edges, dead pixels)
+    // the incoming row's four registers of two pixels each, masked in place
+    auto mask_row = [&](int slot, int slot_before) {
+        // the pair masks change only where the mask byte differs from the row above: module edges, dead pixels.  One compare
+        // of the whole dwords tells "nothing changed" (the byte is part of it); only then is the byte itself looked at.
+        if (__ballot(rinfo[slot] != rinfo[slot_before]) != 0ull) {  // wave-uniform; rare
+            const uint32_t mb = rinfo[slot] & 0xFFu;
+            if (__ballot(mb != mprev) != 0ull) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                M[q] = ((uint32_t)__builtin_amdgcn_sbfe((int)mb, 2 * q, 1) & 0xFFFFu)
-                     | ((uint32_t)__builtin_amdgcn_sbfe((int)mb, 2 * q + 1, 1) & 0xFFFF0000u);
-            mprev = mb;
+                for (int q = 0; q < 4; ++q)
+                    M[q] = ((uint32_t)__builtin_amdgcn_sbfe((int)mb, 2 * q, 1) & 0xFFFFu)
+                         | ((uint32_t)__builtin_amdgcn_sbfe((int)mb, 2 * q + 1, 1) & 0xFFFF0000u);
+                mprev = mb;
+            }
         }
-        P[0] = r.raw.x & M[0]; P[1] = r.raw.y & M[1]; P[2] = r.raw.z & M[2]; P[3] = r.raw.w & M[3];
-        // keep the masked words opaque: otherwise the compiler merges `raw & M & 0xFFFF` into a three-operand
-        // v_bitop3 per pair instead of taking the low half as an SDWA select of the word it already has
-#pragma unroll
-        for (int q = 0; q < 4; ++q) asm("" : "+v"(P[q]));
-    };
-
-    // vertical running sums: add the incoming row, retire the row that left the 7-row window.  The
-    // half-word operands are meant to become SDWA selects (v_sub_u32_sdwa / v_add_u32_sdwa), the product a
-    // v_mad_i32_i24: four instructions per pixel, nothing to unpack.
-    auto push = [&](int s, const uint32_t (&P)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint32_t wn = P[q], wo = ring[s][q];
+            ring[slot][q] &= M[q];
+            // keep the masked words opaque: otherwise the compiler merges `raw & M & 0xFFFF` into a three-operand
+            // v_bitop3 per pair instead of taking the low half as an SDWA select of the word it already has
+            asm("" : "+v"(ring[slot][q]));
+        }
+    };
+
+    // vertical running sums: add the incoming row (slot s), retire the row that left the 7-row window (slot so).  The
+    // half-word operands are meant to become SDWA selects (v_sub_u32_sdwa / v_add_u32_sdwa), the product a
+    // v_mad_i32_i24: four instructions per pixel, nothing to unpack.
+    // (Measured and dropped in round 3: no sum of squares in the stream at all, the ~0.6 % of pixels that pass the signal test
+    // gathering their 49 pixels from L2 in the drain -- v_dot2_u32_u16 per pixel pair; 16 of 77 instructions per row less,
+    // but every drain then waits for memory: 410 us per 32 Eiger frames against 311.)
+    auto push = [&](int s, int so) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t wn = ring[s][q], wo = ring[so][q];
             {
                 const int32_t t = (int32_t)((wn & 0xFFFFu) - (wo & 0xFFFFu));
                 const int32_t u = (int32_t)((wn & 0xFFFFu) + (wo & 0xFFFFu));
@@ -236,7 +253,6 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                 col[2 * q + 1] += (uint32_t)t;
                 colq[2 * q + 1] += (uint32_t)__mul24(t, u);
             }
-            ring[s][q] = wn;
         }
     };
 
@@ -368,30 +384,29 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     };
 
 #pragma unroll
-    for (int s = 0; s < KAHEAD; ++s) fetch(pre[s], s);
+    for (int s = 0; s < KAHEAD; ++s) fetch(s, s);
 
-    // warm-up: rows 0..5 of the band's input only fill the window
+    // warm-up: rows 0..5 of the band's input only fill the window (their "outgoing" slots hold zeros)
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
-        uint32_t P[4];
-        unpack(pre[s], P);
-        fetch(pre[(s + KAHEAD) % 7], s + KAHEAD);
-        push(s, P);
+        mask_row(s, (s + NS - 1) % NS);   // (row 0: against the zeroed slot before it)
+        push(s, (s + KAHEAD) % NS);
+        fetch((s + KAHEAD) % NS, s + KAHEAD);
     }
 
-    for (int base = 6;; base += 7) {
+    for (int base = 6;; base += NS) {
 #pragma unroll
-        for (int t = 0; t < 7; ++t) {
-            const int s = (6 + t) % 7;   // slot of incoming row i (i % 7 == s)
-            const int sc = (s + 4) % 7;  // slot of the centre row i - 3
+        for (int t = 0; t < NS; ++t) {
+            const int s = (6 + t) % NS;        // slot of incoming row i (i % NS == s)
+            const int so = (s + KAHEAD) % NS;  // slot of the row that leaves the window, i - 7; row i + KAHEAD is loaded into it
+            const int sc = (s + NS - 3) % NS;  // slot of the centre row i - 3
             const int i = base + t;
             if (i >= total) goto rows_done;
             {
-                uint32_t P[4];
-                const uint32_t info = pre[s].info;   // carries the counts of the centre row
-                unpack(pre[s], P);
-                fetch(pre[(s + KAHEAD) % 7], i + KAHEAD);
-                push(s, P);
+                const uint32_t info = rinfo[s];   // carries the counts of the centre row
+                mask_row(s, (s + NS - 1) % NS);
+                push(s, so);
+                fetch(so, i + KAHEAD);
 
                 // horizontal 7-tap over the column sums c[-3..10] = L5 L6 L7 c0..c7 R0 R1 R2, from pair sums;
                 // every neighbour value rides on an add
@@ -436,15 +451,17 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                     // background through): d_j = [mmax y_j - x_j (x_j + mmin - 1)] (1 + 2^-20) - kB x_j sqrt(2 (mmin - 1)),
                     // a pixel can only pass the first pass where d_j >= 0; the lane keeps the largest d_j
                     const uint32_t ys[8] = {y0, y1, y2, y3, y4, y5, y6, y7};
-                    const float mxf = (float)mmax, mm1 = (float)mmin - 1.0f;
-                    const float kq = a.kB * __builtin_amdgcn_sqrtf(2.0f * mm1);
+                    // d_j = c1 y_j - x_j (x_j + c2) with c1 = mmax (1 + 2^-19) and c2 = (mmin - 1 + kB sqrt(2 (mmin - 1))) (1 - 2^-21): an upper
+                    // bound of a_j - c_j in float32 whatever the five roundings do (each within 2^-24 of a term no larger than
+                    // c1 y_j or x_j (x_j + c2); the two factors grant 2^-19 and 2^-21 of them) -- seven instructions per pixel
+                    const float mm1 = (float)mmin - 1.0f;
+                    const float c1 = (float)mmax * 1.0000019073486328125f;
+                    const float c2 = (mm1 + a.kB * __builtin_amdgcn_sqrtf(2.0f * mm1)) * 0.99999952316284179688f;
                     float dmax = -1.0f;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float xf = (float)Wn[j], yf = (float)ys[j];
-                        const float t0 = mxf * yf;
-                        const float af = t0 - xf * (xf + mm1);
-                        dmax = __builtin_fmaxf(dmax, (af + t0 * 9.5367431640625e-07f) - kq * xf);
+                        dmax = __builtin_fmaxf(dmax, c1 * yf - xf * (xf + c2));
                     }
                     const uint32_t xmax = max(max(max(max(Wn[0], Wn[1]), Wn[2]), max(max(Wn[3], Wn[4]), Wn[5])), max(Wn[6], Wn[7]));
                     pass = mmax != 0u && (dmax >= 0.0f || xmax >= 65536u);
@@ -460,18 +477,21 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                     }
                     const int32_t B = (int32_t)__umul24(mmax, pmax) - (int32_t)xmin;
                     const float bf = (float)B, tf = (float)__umul24(xmin, mmin);
-                    pass = bf * __builtin_fabsf(bf) > kS * tf;
+                    float lhs = bf * __builtin_fabsf(bf);
+                    asm("" : "+v"(lhs));   // (keeps the two products apart: packed, v_pk_mul_f32 costs a v_mov and a double-rate slot)
+                    pass = lhs > kS * tf;
                 }
-                const bool flag = owned && pass && !FFS_DBG(a, 1);
-                if (a.dense_mask) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, so_bytes, 2 /* nt: written once, read much later */);
-                const unsigned long long fm = __builtin_amdgcn_ballot_w64(flag);
+                if constexpr (DENSE) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, so_bytes, 2 /* nt: written once, read much later */);
+                // (the compare's mask ANDed with a scalar: no VALU instruction turns the flag back into a mask)
+                const unsigned long long fm = FFS_DBG(a, 1) ? 0ull : (__builtin_amdgcn_ballot_w64(pass) & owned_mask);
+                const bool flag = pass && owned;
                 if (fm) {  // wave-uniform
                     const int nfl = __popcll(fm);
                     if (qn + nfl > kQCap) drain();
                     // the group's 14 column sums of p^2 (own 8 + 3 from each neighbour lane)
                     const uint32_t QL5 = from_left(colq[5]), QL6 = from_left(colq[6]), QL7 = from_left(colq[7]);
                     const uint32_t QR0 = from_right(colq[0]), QR1 = from_right(colq[1]), QR2 = from_right(colq[2]);
-                    if (flag) {
+                    if (flag && !FFS_DBG(a, 32)) {
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
                         const int e = qn + (int)rank;   // < kQCap: after a drain qn = 0 and nfl <= 62
 #pragma unroll
@@ -529,7 +549,7 @@ constexpr int kS4Words = 32;  // queue entry: 0-3 window sums, 4-7 centre pixels
                               // 11 tag (bit 31: neighbourhood holds a pixel >= 2^24), 12-21 / 22-31 low / high words of the
                               // column sums of p^2 (L1 L2 L3 c0..c3 R0 R1 R2)
 
-template <int KAHEAD>
+template <int KAHEAD, bool DENSE = false>
 __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
     __shared__ uint32_t s_q[kS4Words][kQCap];
     __shared__ uint16_t s_list[kQCap * 4];
@@ -570,51 +590,55 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
     const int total = (yb1 - yb0) + 6;
     const float kS = a.kS;
 
-    uint32_t ring[7][4];
+    // ring of NS = 7 + KAHEAD row slots, loads landing in their slot and masked in place (see k_stream_u16)
+    constexpr int NS = 7 + KAHEAD;
+    uint32_t ring[NS][4];
+    uint32_t rinfo[NS];
     uint32_t col[4];
     long long colq[4];   // sum p^2 over the 7 rows, exact (49 * 2^48 < 2^63)
     uint32_t M[4] = {0, 0, 0, 0};  // 0 / ~0 per pixel of the current mask nibble
     uint32_t mprev = 0;
-    uint32_t bighist = 0;          // bit s: the row in ring slot s holds a valid pixel >= 2^24 in this lane
-    RowRegsS pre[7];
+    uint32_t bighist = 0;          // bit s: the row in ring slot s (a row of the window) holds a valid pixel >= 2^24 in this lane
 #pragma unroll
-    for (int s = 0; s < 7; ++s) {
+    for (int s = 0; s < NS; ++s) {
+        rinfo[s] = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) ring[s][q] = 0;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { col[j] = 0; colq[j] = 0; }
+    const unsigned long long owned_mask = __builtin_amdgcn_ballot_w64(owned);
 
-    auto fetch = [&](RowRegsS& dst, int i) {
+    auto fetch = [&](int slot, int i) {   // (rows outside the image: masked off through their ginfo dword, see k_stream_u16)
         const int yin = yb0 - 3 + i;
-        const bool in_rows = (i < total) & (yin >= 0);
-        const bool ok_img = in_rows & (yin < a.H);
-        const bool ok_info = in_rows & (yin < a.H + kInfoExtraRows);
-        const uint32_t row = ok_info ? (uint32_t)yin : 0u;
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_img, off_px | (ok_img ? 0u : kOob), (ok_img ? row : 0u) * a.pitch, 0);
-        dst.raw = make_uint4(v[0], v[1], v[2], v[3]);
-        dst.info = __builtin_amdgcn_raw_buffer_load_b32(r_info, off_info | (ok_info ? 0u : kOob), row * a.gpitch, 0);
+        const uint32_t prow = (uint32_t)min(max(yin, 0), a.H - 1);
+        const uint32_t irow = (uint32_t)min(max(yin, 0), a.H + kInfoExtraRows - 1);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_img, off_px, prow * a.pitch, 0);
+        ring[slot][0] = v[0]; ring[slot][1] = v[1]; ring[slot][2] = v[2]; ring[slot][3] = v[3];
+        rinfo[slot] = __builtin_amdgcn_raw_buffer_load_b32(r_info, off_info | (yin < 0 ? kOob : 0u), irow * a.gpitch, 0);
     };
 
-    auto unpack = [&](const RowRegsS& r, uint32_t (&P)[4]) {
-        const uint32_t mb = r.info & 0xFu;
-        if (__ballot(mb != mprev) != 0ull) {
+    auto mask_row = [&](int slot, int slot_before) {
+        if (__ballot(rinfo[slot] != rinfo[slot_before]) != 0ull) {  // wave-uniform; rare
+            const uint32_t mb = rinfo[slot] & 0xFu;
+            if (__ballot(mb != mprev) != 0ull) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) M[q] = (uint32_t)__builtin_amdgcn_sbfe((int)mb, q, 1);
-            mprev = mb;
+                for (int q = 0; q < 4; ++q) M[q] = (uint32_t)__builtin_amdgcn_sbfe((int)mb, q, 1);
+                mprev = mb;
+            }
         }
-        P[0] = r.raw.x & M[0]; P[1] = r.raw.y & M[1]; P[2] = r.raw.z & M[2]; P[3] = r.raw.w & M[3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ring[slot][q] &= M[q];
     };
 
-    auto push = [&](int s, const uint32_t (&P)[4]) {
-        const uint32_t big = ((P[0] | P[1]) | (P[2] | P[3])) >> 24 ? 1u : 0u;
-        bighist = (bighist & ~(1u << s)) | (big << s);
+    auto push = [&](int s, int so) {
+        const uint32_t big = ((ring[s][0] | ring[s][1]) | (ring[s][2] | ring[s][3])) >> 24 ? 1u : 0u;
+        bighist = (bighist & ~((1u << s) | (1u << so))) | (big << s);   // (slot so leaves the window)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int32_t t = (int32_t)(P[q] - ring[s][q]), u = (int32_t)(P[q] + ring[s][q]);  // |t|, u < 2^25 (a pixel >= 2^24 sends its windows to the gather path)
+            const int32_t t = (int32_t)(ring[s][q] - ring[so][q]), u = (int32_t)(ring[s][q] + ring[so][q]);  // |t|, u < 2^25 (a pixel >= 2^24 sends its windows to the gather path)
             col[q] += (uint32_t)t;
             colq[q] += (long long)t * (long long)u;   // p_in^2 - p_out^2: one v_mad_i64_i32
-            ring[s][q] = P[q];
         }
     };
 
@@ -702,28 +726,27 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
     };
 
 #pragma unroll
-    for (int s = 0; s < KAHEAD; ++s) fetch(pre[s], s);
+    for (int s = 0; s < KAHEAD; ++s) fetch(s, s);
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
-        uint32_t P[4];
-        unpack(pre[s], P);
-        fetch(pre[(s + KAHEAD) % 7], s + KAHEAD);
-        push(s, P);
+        mask_row(s, (s + NS - 1) % NS);
+        push(s, (s + KAHEAD) % NS);
+        fetch((s + KAHEAD) % NS, s + KAHEAD);
     }
 
-    for (int base = 6;; base += 7) {
+    for (int base = 6;; base += NS) {
 #pragma unroll
-        for (int t = 0; t < 7; ++t) {
-            const int s = (6 + t) % 7;
-            const int sc = (s + 4) % 7;
+        for (int t = 0; t < NS; ++t) {
+            const int s = (6 + t) % NS;
+            const int so = (s + KAHEAD) % NS;
+            const int sc = (s + NS - 3) % NS;
             const int i = base + t;
             if (i >= total) goto rows_done;
             {
-                uint32_t P[4];
-                const uint32_t info = pre[s].info;
-                unpack(pre[s], P);
-                fetch(pre[(s + KAHEAD) % 7], i + KAHEAD);
-                push(s, P);
+                const uint32_t info = rinfo[s];
+                mask_row(s, (s + NS - 1) % NS);
+                push(s, so);
+                fetch(so, i + KAHEAD);
 
                 // column sums c[-3..6] = L1 L2 L3 c0..c3 R0 R1 R2; every neighbour value rides on an add
                 const uint32_t s01 = col[0] + col[1], s23 = col[2] + col[3];
@@ -737,7 +760,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
                 Wn[3] = dpp_shl_add(col[2], TR);
 
                 const int yout = __builtin_amdgcn_readfirstlane(yb0 + (i - 6));
-                if (a.dense_mask) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, (uint32_t)yout * a.bpitch, 2);
+                if constexpr (DENSE) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, r_sb, off_byte_st, (uint32_t)yout * a.bpitch, 2);
 
                 const uint32_t xmin = min(min(min(Wn[0], Wn[1]), Wn[2]), Wn[3]);
                 const uint32_t pmax = max(max(max(ring[sc][0], ring[sc][1]), ring[sc][2]), ring[sc][3]);
@@ -749,8 +772,9 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
                 const uint32_t bl = bighist != 0u ? 1u : 0u;
                 bool near_big = false;
                 if (__ballot(bl != 0u) != 0ull) near_big = (bl | from_left(bl) | from_right(bl)) != 0u && mmax != 0u;
-                const bool flag = owned && (pass || near_big) && !FFS_DBG(a, 1);
-                const unsigned long long fm = __builtin_amdgcn_ballot_w64(flag);
+                const bool want = pass || near_big;
+                const unsigned long long fm = FFS_DBG(a, 1) ? 0ull : (__builtin_amdgcn_ballot_w64(want) & owned_mask);
+                const bool flag = want && owned;
                 if (fm) {
                     const int nfl = __popcll(fm);
                     if (qn + nfl > kQCap) drain();
@@ -791,8 +815,13 @@ template __global__ void k_bright_fix<uint16_t>(const ThresholdArgs);
 template __global__ void k_bright_fix<uint16_t, true>(const ThresholdArgs);
 template __global__ void k_bright_fix<uint32_t>(const ThresholdArgs);
 
-template __global__ void k_stream_u16<2>(const ThresholdArgs);
-template __global__ void k_stream_u16<2, true>(const ThresholdArgs);
-template __global__ void k_stream_u32<2>(const ThresholdArgs);
+template __global__ void k_stream_u16<2, false, false>(const ThresholdArgs);
+template __global__ void k_stream_u16<3, false, false>(const ThresholdArgs);
+template __global__ void k_stream_u16<4, false, false>(const ThresholdArgs);
+template __global__ void k_stream_u16<2, false, true>(const ThresholdArgs);
+template __global__ void k_stream_u16<2, true, false>(const ThresholdArgs);
+template __global__ void k_stream_u16<2, true, true>(const ThresholdArgs);
+template __global__ void k_stream_u32<2, false>(const ThresholdArgs);
+template __global__ void k_stream_u32<2, true>(const ThresholdArgs);
 
 }  // namespace ffsamd

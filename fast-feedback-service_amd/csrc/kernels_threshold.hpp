@@ -222,6 +222,15 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
         const uint32_t w = s_words[g];
         gwords[g] = w;
         cnt += __popc(w);
+        if constexpr (MODE == 1) {
+            // the extended algorithm's final plane: its occupancy bitmap (one bit per 16-byte segment of a plane row) lets the
+            // sparse stage read only the segments that hold something, as after the streaming kernels
+            if (w) {
+                const int row = g / dpr;
+                const uint32_t ob = (uint32_t)(y0 + row) * a.occ_spr + (uint32_t)((g - row * dpr) >> 2);
+                atomicOr(a.occ + (uint64_t)frame * a.occ_frame_words + (ob >> 5), 1u << (ob & 31u));
+            }
+        }
     }
     if (cnt) atomicAdd(&s_strong, cnt);
     __syncthreads();

@@ -153,7 +153,8 @@ int ffs_ctx_set_params(ffs_ctx *ctx, const ffs_params *p);
  *                          1 = they are marked in the plane and an exact kernel filters it (also the fall-back
  *                          when that list overflows)
  *   "ext_first_pass"   (2) extended algorithm, 16-bit pixels: 2 = streaming kernel, 0 = plain one-pixel-per-lane kernel
- *   "sparse_stage"     (2) 2 = one launch per batch, a workgroup per frame; 1 = four grid-wide kernels
+ *   "sparse_stage"     (2) one launch per batch, a workgroup per frame: 3 = always, 2 = unless the stream's previous batch
+ *                          held a frame with more strong pixels than that workgroup's LDS holds; 1 = four grid-wide kernels
  *   "sched"            (3) 3 = shared dense / sparse / upload HIP streams per context, 0 = one per ffs_stream
  *                          (before the first stream is created)
  *   "direct_records"   (1) records written straight into pinned host memory (before the first stream is created)

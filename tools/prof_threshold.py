@@ -21,7 +21,12 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--unique", type=int, default=4, help="unique synthetic frames (cycled)")
     ap.add_argument("--workload", default="eiger16m")
-    ap.add_argument("--variants", default="1", help="comma list of FFS_K1_VARIANT values to A/B")
+    ap.add_argument("--paths", default="0", help="comma list of tuning threshold_path values to A/B (0 = bright list, 1 = bright plane + exact kernel)")
+    ap.add_argument("--exp", default="", help="comma list of FFS_EXP_K1_DEBUG values (experiments build only: FFS_HIP_LIB=.../libffs_hip_exp.so); "
+                                              "1 = no group ever flagged, 2 = drains do nothing, 4 = no exact predicate, 8/16 = dense mask off/on")
+    ap.add_argument("--dense", action="store_true", help="ask for the dense byte mask (want_strong_mask)")
+    ap.add_argument("--tune", default="", help="A/B over tuning sets, ';'-separated, each 'key=value,key=value' (ffs_ctx_set_tuning), e.g. "
+                                               "'rows_ahead=2;rows_ahead=3;rows_ahead=4'")
     ap.add_argument("--rounds", type=int, default=1)
     ap.add_argument("--algorithm", default="dispersion", choices=["dispersion", "dispersion_extended"])
     ap.add_argument("--decode", action="store_true", help="also run the bitshuffle-LZ4 decode kernel on the batch")
@@ -35,7 +40,7 @@ def main():
     def make_ctx():
         c = ffs_amd.Context(W, H, dt, max_batch=B)
         c.set_mask(mask)
-        c.set_params(algorithm=1 if args.algorithm == "dispersion_extended" else 0)
+        c.set_params(algorithm=1 if args.algorithm == "dispersion_extended" else 0, want_strong_mask=1 if args.dense else 0)
         return c
 
     ctx = make_ctx()
@@ -45,7 +50,9 @@ def main():
         host[i, :, :W] = frames[i % len(frames)]
     d = torch.from_numpy(host.view(np.uint8).reshape(-1)).cuda()
     alg = float(W) * H * bpp * B
-    variants = [int(v) for v in args.variants.split(",")]
+    variants = [("path", int(v)) for v in args.paths.split(",")] if not args.exp else [("exp", int(v)) for v in args.exp.split(",")]
+    if args.tune:
+        variants = [("tune", t) for t in args.tune.split(";")]
     if args.decode:
         from ffs_amd import bslz4
         st = ctx.stream()
@@ -56,17 +63,22 @@ def main():
         print(f"decode: {ms*1e3:.1f} us/launch, {raw/ms/1e6:.0f} GB/s of pixels written, "
               f"{sum(c.size for c in chunks)/ms/1e6:.0f} GB/s of chunks read, batch {B}", flush=True)
         del st
-    # the knobs are read when a context is created: one context (and stream) per variant
+    # one context (and stream) per variant: tuning is per context, the experiment switches are read when a context is created
     streams = {}
-    for v in variants:
-        os.environ["FFS_K1_VARIANT"] = str(v)
+    for kind, v in variants:
+        if kind == "exp":
+            os.environ["FFS_EXP_K1_DEBUG"] = str(v)
         c = make_ctx()
-        streams[v] = (c, c.stream())
+        if kind == "path":
+            c.set_tuning(threshold_path=v)
+        if kind == "tune":
+            c.set_tuning(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in v.split(",") if kv})
+        streams[(kind, v)] = (c, c.stream())
     for rnd in range(args.rounds):          # interleaved A/B rounds in one process
-        for v in variants:
-            a, b = streams[v][1].bench_threshold(d.data_ptr(), pitch, fstride, B, args.iters)
-            print(f"round {rnd} variant {v}: k_candidates {a*1e3:.1f} us/launch ({alg/a/1e6:.0f} GB/s algorithmic, "
-                  f"{alg/a/1e6/8000:.3f} of 8 TB/s), k_exact {b*1e3:.1f} us/launch, batch {B}", flush=True)
+        for key in variants:
+            a, b = streams[key][1].bench_threshold(d.data_ptr(), pitch, fstride, B, args.iters)
+            print(f"round {rnd} {key[0]} {key[1]}: dense kernel {a*1e3:.1f} us/launch ({alg/a/1e6:.0f} GB/s algorithmic, "
+                  f"{alg/a/1e6/8000:.3f} of 8 TB/s), rest of the stage {b*1e3:.1f} us/launch, batch {B}", flush=True)
 
 
 if __name__ == "__main__":
