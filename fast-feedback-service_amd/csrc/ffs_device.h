@@ -63,6 +63,10 @@ struct ThresholdArgs {
     double nsig_b, nsig_s, threshold;
     double nsig_b2, nsig_s2;   // squares (float64), for the square-root-free form of the predicate
     long long max_valid;       // < 0: no test
+    // integer form of the predicate (kernels_stream.hpp: int_predicate): usable when nsig_b^2 and nsig_s^2 are integers
+    int int_pred;              // 1: ib2 / is2 / thr_floor are valid
+    uint32_t ib2, is2;         // nsig_b^2, nsig_s^2
+    uint32_t thr_floor;        // floor(threshold): for an integer pixel p, p > threshold <=> p > floor(threshold)
     int bright_to_plane;       // streaming kernels: 0 = bright windows go onto bright_list (k_bright_fix decides them);
                                // 1 = they are marked in the plane as candidates and the exact kernel filters the plane
     // extended dispersion (kernels_extended.hpp)

@@ -48,6 +48,14 @@ ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t pitch, 
     a.nsig_s2 = p.nsig_s * p.nsig_s;
     a.threshold = p.threshold;
     a.max_valid = p.max_valid;
+    {
+        const double b2 = p.nsig_b * p.nsig_b, s2 = p.nsig_s * p.nsig_s;
+        a.int_pred = (b2 == std::floor(b2) && s2 == std::floor(s2) && b2 <= 1024.0 && s2 <= 1024.0 && p.threshold < 2147483648.0
+                      && std::sqrt(b2) == p.nsig_b && std::sqrt(s2) == p.nsig_s) ? 1 : 0;   // (integer nsig: the squares are exact)
+        a.ib2 = a.int_pred ? (uint32_t)b2 : 0u;
+        a.is2 = a.int_pred ? (uint32_t)s2 : 0u;
+        a.thr_floor = a.int_pred ? (uint32_t)std::floor(p.threshold) : 0u;
+    }
     // bright windows (sum p >= 65536; 32-bit pixels >= 2^24): onto the list k_bright_fix works off, or -- tuning
     // "threshold_path" = 1, and whenever that list overflowed (ffs_wait re-runs the batch) -- into the plane as candidates
     a.bright_to_plane = s->force_path >= 0 ? s->force_path : c->tune.threshold_path;

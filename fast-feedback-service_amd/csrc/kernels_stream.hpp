@@ -88,6 +88,37 @@ __device__ __forceinline__ bool exact_predicate_nosqrt(const ThresholdArgs& a, u
     return disp_yes && sig_yes;
 }
 
+// The same decision in integers, for integer nsig_b, nsig_s (the defaults 6 and 3) and a window whose sums fit: x < 65536, so
+// y < 2^32 and everything below stays inside 64 bits.  a = m y - x (x + m - 1) and b = m p - x are the oracle's a and b exactly;
+// c^2 = nsig_b^2 x^2 2 (m - 1) and d^2 = nsig_s^2 x m are integers here, so the comparisons of the squares are exact, and
+// whenever they differ by at least 16 the sides themselves differ by more than 2^-46 relative -- far beyond what the oracle's
+// three roundings of c and d (2^-51) can turn around.  Closer than that (ties: 2 (m - 1) or x m a perfect square): `certain`
+// is false and the caller evaluates exact_predicate.  A fifth of the float64 form's issue slots (v_mad_u64_u32 instead of
+// chains of v_mul_f64 / v_fma_f64 and conversions).
+__device__ __forceinline__ bool int_predicate(const ThresholdArgs& a, uint32_t m, uint32_t x, uint32_t y, uint32_t pc, bool& certain) {
+    certain = true;
+    if (!((int)m >= a.min_count && pc > a.thr_floor)) return false;
+    if (a.max_valid >= 0 && (long long)pc > a.max_valid) return false;
+    const unsigned long long my = (unsigned long long)m * y;                 // < 2^38
+    const unsigned long long xx = (unsigned long long)x * (x + m - 1u);      // < 2^33
+    const int32_t bv = (int32_t)__umul24(m, pc) - (int32_t)x;                // |b| < 2^22
+    if (my <= xx || bv <= 0) return false;                                   // a <= 0 or b <= 0, and c, d >= 0
+    const unsigned long long av = my - xx;
+    const unsigned long long c2 = (unsigned long long)(a.ib2 * 2u * (m - 1u)) * (unsigned long long)(x * x);   // < 2^17 2^32
+    bool disp_yes = true, disp_close = false;
+    if (av < (1ull << 25)) {                                                  // (beyond: a^2 >= 2^50 > c^2)
+        const unsigned long long a2 = (unsigned long long)(uint32_t)av * (uint32_t)av;
+        disp_yes = a2 > c2;
+        disp_close = (a2 > c2 ? a2 - c2 : c2 - a2) < 16ull;
+    }
+    const unsigned long long b2 = (unsigned long long)(uint32_t)bv * (uint32_t)bv;   // < 2^44
+    const unsigned long long d2 = (unsigned long long)a.is2 * __umul24(x, m);       // x m < 2^22
+    const bool sig_yes = b2 > d2;
+    const bool sig_close = (b2 > d2 ? b2 - d2 : d2 - b2) < 16ull;
+    certain = !(disp_close || sig_close);
+    return disp_yes && sig_yes;
+}
+
 // First pass of the extended algorithm (baseline.cpp:468-473): the dispersion half alone, a > c, for a valid
 // centre with at least min_count pixels in its window (and, with the device kernels' rule, a centre pixel not
 // above max_valid).  Square-root-free with the same certification as above; dispersion_only() is the fall-back.
@@ -350,7 +381,8 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                         strong = dispersion_only_nosqrt(a, m, x, y, certain);
                         if (!certain) strong = dispersion_only(a, m, x, y);
                     } else {
-                        strong = exact_predicate_nosqrt(a, m, x, y, pv, certain);
+                        if (a.int_pred) strong = int_predicate(a, m, x, y, pv, certain);   // (wave-uniform)
+                        else strong = exact_predicate_nosqrt(a, m, x, y, pv, certain);
                         if (!certain) strong = exact_predicate(a, m, x, y, pv);
                     }
                     if (strong) atomicOr(&s_q[14][e], 1u << j);
