@@ -431,22 +431,24 @@ def bench_single_process(args):
     import ffs_amd
     n = args.gpus
     have = torch.cuda.device_count()
-    if have < n:
-        print(f"bench.py --single-process: --gpus {n} asked for, {have} GPU(s) visible", file=sys.stderr)
+    # --devices 0,0: a rehearsal with several contexts on one GPU (the one-GPU boxes of the pool)
+    devs = [int(t) for t in args.devices.split(",")] if args.devices else list(range(n))
+    if len(devs) != n or max(devs) >= have:
+        print(f"bench.py --single-process: --gpus {n} asked for, {have} GPU(s) visible (devices {devs})", file=sys.stderr)
         return 3
     W, H, dt, bytes_per_px = WORKLOADS[args.workload]
     B = args.batch
-    transport = ffs_amd.api.multi_init(list(range(n)))
+    transport = ffs_amd.api.multi_init(devs)
     gpus = []
     for d in range(n):
         frames, mask = make_inputs(args.workload, B, d)
-        ctx = ffs_amd.Context(W, H, dt, max_batch=B, device=d)
+        ctx = ffs_amd.Context(W, H, dt, max_batch=B, device=devs[d])
         ctx.set_mask(mask)
         ctx.set_params(want_reflections=1, algorithm=1 if args.algorithm == "dispersion_extended" else 0)
         pitch, fstride = ctx.device_layout()
         host = np.zeros((B, H, pitch // np.dtype(dt).itemsize), dt)
         host[:, :, :W] = frames
-        d_frames = torch.from_numpy(host.view(np.uint8).reshape(-1)).to(torch.device("cuda", d))
+        d_frames = torch.from_numpy(host.view(np.uint8).reshape(-1)).to(torch.device("cuda", devs[d]))
         del host, frames
         gpus.append({"ctx": ctx, "streams": [ctx.stream() for _ in range(max(1, args.streams))], "buf": d_frames,
                      "pitch": pitch, "fstride": fstride})
@@ -463,13 +465,13 @@ def bench_single_process(args):
         th = [threading.Thread(target=work, args=(d,)) for d in range(n)]
         for t in th:
             t.start()
-        for d in range(n):
+        for d in set(devs):
             torch.cuda.synchronize(d)
         start.wait()
         t0 = time.perf_counter()
         for t in th:
             t.join()
-        for d in range(n):
+        for d in set(devs):
             torch.cuda.synchronize(d)
         return time.perf_counter() - t0, res
 
@@ -488,8 +490,8 @@ def bench_single_process(args):
         "dtype": "u16" if dt == np.uint16 else "u32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {W}x{H} {np.dtype(dt).name}, 7x7 dispersion window, {B} frames/step/GPU resident "
                                "in HBM, spots+centroids returned to host", "frames_per_step_per_gpu": B, "streams": args.streams,
-                   "parallelism": f"single process, {n} contexts (ffs_multi_init, transport for rotation lists: {transport}), one host "
-                                  "thread per GPU, no data-path collective",
+                   "parallelism": f"single process, {n} contexts on devices {devs} (ffs_multi_init, transport for rotation lists: "
+                                  f"{transport}), one host thread per context, no data-path collective",
                    "spots_per_frame": round(sum(r[0] for r in last) / max(1, n * args.steps * B), 1),
                    "strong_pixels_per_frame": round(sum(r[1] for r in last) / max(1, n * args.steps * B), 1)},
         "repetitions": {"n": len(times), "ms_per_step": [round(t / args.steps * 1e3, 4) for t in times], "value_from": "median"},
@@ -566,6 +568,7 @@ def main():
     ap.add_argument("--single-process", action="store_true",
                     help="--gpus N driven from ONE process: a context and a host thread per GPU behind ffs_multi_init "
                          "(the C++ driver's model) instead of one rank per GPU")
+    ap.add_argument("--devices", default="", help="--single-process: device index of every context, e.g. 0,0 to rehearse two contexts on one GPU")
     ap.add_argument("--dry-run", action="store_true", help="rehearse launcher + gather plumbing on CPU (gloo), no GPU")
     ap.add_argument("--launch-timeout", type=float, default=1500.0)
     ap.add_argument("--tune", default="", help="ffs_ctx_set_tuning pairs for A/B runs, 'key=value,key=value' (results are the same)")

@@ -21,6 +21,7 @@
 #include <string>
 #include <thread>
 #include <pthread.h>
+#include <sys/resource.h>
 #include <sched.h>
 #include <unistd.h>
 #include <vector>
@@ -58,7 +59,7 @@ struct Args {
     int pipe_fd = -1, device = 0;
     std::vector<int> devices;  // --devices / --gpus: the frame queue is dealt to all of them
     std::string algorithm = "dispersion", detector_json;
-    bool cpu_decode = false, no_numa_pinning = false, single_buffer = false, all_threads = false;
+    bool cpu_decode = false, no_numa_pinning = false, single_buffer = false, all_threads = false, read_only = false;
 };
 
 static void usage() {
@@ -157,6 +158,7 @@ static Args parse_args(int argc, char** argv) {
         else if (s == "--strict-dtype") r.strict_dtype = true;
         else if (s == "--no-numa-pinning") r.no_numa_pinning = true;
         else if (s == "--single-buffer") r.single_buffer = true;
+        else if (s == "--read-only") r.read_only = true;   // diagnostic: frames are read into the staging buffers and not submitted
         else if (s == "--all-threads") r.all_threads = true;
         else if (!s.empty() && s[0] == '-' && s.size() > 1) arg_error("Unknown argument: " + s);
         else if (r.file.empty()) r.file = s;
@@ -279,6 +281,7 @@ static std::string fmt_num(T v) { std::ostringstream o; o << v; return o.str(); 
     } while (0)
 
 int main(int argc, char** argv) {
+    const auto process_start = std::chrono::steady_clock::now();
     std::printf("Spotfinder version: %s\n", FFS_VERSION);
     Args args = parse_args(argc, argv);
     const std::string file = args.file;
@@ -504,6 +507,8 @@ int main(int argc, char** argv) {
     const auto all_start = std::chrono::steady_clock::now();
     std::atomic<uint32_t> next_image{0};
     std::atomic<uint32_t> completed{0};
+    std::mutex retired_mutex;
+    std::vector<ffs_stream*> retired_streams;   // the workers' streams, destroyed after the summary
     std::atomic<double> time_waiting_acc{0.0};
     std::atomic<int> failed{0};
     std::map<uint32_t, std::vector<float>> reflection_centers_2d;  // spotfinder.cc:706-708
@@ -713,7 +718,7 @@ int main(int argc, char** argv) {
         auto last_received = std::chrono::steady_clock::now();
         uint32_t run_first = 0, run_n = 0, run_done = 0;   // the run of frame numbers this worker took, and how far it is through it
         int cur = 0;
-        double t_read = 0, t_submit = 0;   // (-v: where this worker's time went)
+        double t_read = 0, t_submit = 0, t_chunk = 0;   // (-v: where this worker's time went; t_chunk = inside get_raw_chunk)
         uint32_t n_batches = 0;
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
@@ -756,7 +761,9 @@ int main(int argc, char** argv) {
                     time_waiting_acc.fetch_add(std::chrono::duration<double>(last_received - w0).count());
                     for (;;) {  // zero-length reads on /dev/shm: retry (:805-821)
                         if (gpu_decode && S.host) {
+                            const auto c0 = now();
                             chunk = reader.get_raw_chunk(offset_image_num, {S.host + cursor, S.host_bytes - cursor});
+                            t_chunk += secs(c0, now());
                             if (chunk.size() != 0 && chunk.size() >= S.host_bytes - cursor && S.host_bytes - cursor < raw.size()) {
                                 // the read filled what was left of the staging area: the chunk may be cut.  With frames already
                                 // in this batch, send those and start the next batch with this one; else the area is too small
@@ -807,6 +814,7 @@ int main(int argc, char** argv) {
             run_done += got;
             const auto t_sub = now();
             t_read += secs(t_fill, t_sub);
+            if (args.read_only) { ++n_batches; completed += got; cur = (cur + 1) % n_slots; continue; }
             const int sub = gpu_decode ? ffs_submit_compressed(S.s, S.chunk_ptr.data(), S.chunk_len.data(), got, first)
                                        : ffs_submit(S.s, S.host, got, first);
             if (sub != FFS_OK) {
@@ -824,12 +832,17 @@ int main(int argc, char** argv) {
         for (int k = 0; k < n_slots; ++k)   // the older batch first
             if (!failed.load()) collect(slots[(cur + k) % n_slots]);
         const auto t_c0 = now();
-        close_all();
+        {   // every result is out: the streams' buffers are released after the totals are printed, not on the clock
+            // (eight workers' hipFree / hipHostUnregister calls take turns in the runtime: 35-45 ms for 16 streams)
+            std::lock_guard<std::mutex> lock(retired_mutex);
+            for (Slot& q : slots) if (q.s) { retired_streams.push_back(q.s); q.s = nullptr; }
+        }
         if (args.verbose) {
             std::lock_guard<std::mutex> lock(print_mutex);
-            std::printf("Thread %2d: %u batches; reading %.0f ms, submit calls %.0f ms, waiting for the GPU %.0f ms, results out %.0f ms, "
-                        "closing streams %.0f ms; done %.0f ms after the start\n", thread_id, n_batches, t_read * 1e3, t_submit * 1e3, t_wait * 1e3,
-                        t_emit * 1e3, secs(t_c0, now()) * 1e3, secs(all_start, now()) * 1e3);
+            std::printf("Thread %2d: %u batches; reading %.0f ms (%.0f ms of it in get_raw_chunk), submit calls %.0f ms, waiting for the GPU %.0f ms, results out %.0f ms, "
+                        "done %.0f ms after the start\n", thread_id, n_batches, t_read * 1e3, t_chunk * 1e3, t_submit * 1e3, t_wait * 1e3,
+                        t_emit * 1e3, secs(all_start, now()) * 1e3);
+            (void)t_c0;
         }
     };
     {
@@ -849,11 +862,14 @@ int main(int argc, char** argv) {
     if (failed.load()) return 1;
 
     // ---- 3D connected components (spotfinder.cc:1099-1148) ------------------------------------------
+    const auto t_joined = std::chrono::steady_clock::now();
+    if (args.verbose) std::printf("Workers joined %.0f ms after the start\n", std::chrono::duration<double>(t_joined - all_start).count() * 1e3);
     if (rotation) {
         std::printf("Processing 3D spots\n");
         const ffs_reflection* refl = nullptr;
         uint32_t n = 0, n_calc = 0, f_size = 0, f_sep = 0;
         FFS_CHECK(ctx, ffs_stack3d_finish(stack, &refl, &n, &n_calc, &f_size, &f_sep));
+        if (args.verbose) std::printf("3D finish: %.1f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_joined).count() * 1e3);
         std::printf("Calculated %u spots\n", n_calc);  // connected_components.cc:453-454
         if (f_size > 0) std::printf("Filtered %u spots with size < %u pixels\n", f_size, prm.min_spot_size_3d);
         if (f_sep > 0) std::printf("Filtered %u spots with peak-centroid distance > %s\n", f_sep, fmt_num(prm.max_peak_centroid_separation).c_str());
@@ -897,6 +913,7 @@ int main(int argc, char** argv) {
                 }
             }
         }
+        if (args.verbose) std::printf("3D analysis in all: %.1f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_joined).count() * 1e3);
         std::printf("3D spot analysis complete\n");
         ffs_stack3d_destroy(stack);
     } else if (args.save_h5) {  // :1265-1306
@@ -922,10 +939,19 @@ int main(int argc, char** argv) {
     const uint32_t done = completed.load();
     std::printf("\n%d images in %.2f s (\033[1;34m%.2f GBps\033[0m) (\033[1;34m%.1f fps\033[0m)\n", (int)done, total,
                 (double)width * height * bytes_per_pixel * done / total / 1e9, done / total);
+    if (args.verbose) {   // CPU seconds against wall seconds: under a cgroup CPU quota, threads beyond it stall everyone
+        struct rusage ru{};
+        getrusage(RUSAGE_SELF, &ru);
+        const double user = ru.ru_utime.tv_sec + ru.ru_utime.tv_usec * 1e-6, sys = ru.ru_stime.tv_sec + ru.ru_stime.tv_usec * 1e-6;
+        const double since_launch = std::chrono::duration<double>(std::chrono::steady_clock::now() - process_start).count();
+        std::printf("CPU time of the process: %.2f s user + %.2f s system over %.2f s since launch (%.1f cores busy on average)\n", user, sys,
+                    since_launch, (user + sys) / since_launch);
+    }
     const double time_waiting = time_waiting_acc.load();
     if (time_waiting < 10) std::printf("Total time waiting for images to appear: %.0f ms\n", time_waiting * 1000);
     else std::printf("Total time waiting for images to appear: %.2f s\n", time_waiting);
     pipe.reset();
+    for (ffs_stream* st : retired_streams) ffs_stream_destroy(st);
     for (ffs_ctx* cx : ctxs) ffs_ctx_destroy(cx);
     return 0;
 }

@@ -346,3 +346,17 @@ def test_several_device_contexts_share_the_frame_queue(tmp_path, transport):
 def test_unknown_device_in_list_is_refused(tmp_path):
     p = subprocess.run([SPOTFINDER, "synth:tiny:2", "--devices", "0,99"], capture_output=True, text=True, cwd=tmp_path)
     assert p.returncode == 1 and "device 99 does not exist" in p.stdout
+
+
+def test_bench_single_process_leg_with_two_contexts_on_one_gpu():
+    """bench.py --gpus 2 --single-process: one process, a context and a host thread per GPU, each inside the native submit /
+    wait loop (ffs_bench_pipeline).  Rehearsed with both contexts on GPU 0 and the small workload."""
+    import json
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-process", "--devices", "0,0",
+                        "--workload", "plumbing1k", "--batch", "4", "--steps", "6", "--warmup", "2", "--reps", "2"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["n_contexts_seen"] == 2 and d["value"] > 0
+    assert d["config"]["spots_per_frame"] > 10 and d["config"]["strong_pixels_per_frame"] > 100

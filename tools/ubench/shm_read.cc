@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
     const int n_files = argc > 2 ? atoi(argv[2]) : 1000;
 #ifdef WITH_HIP
     (void)hipSetDevice(0); (void)hipFree(nullptr);
-    const int n_modes = 5;
+    const int n_modes = 6;
 #else
     const int n_modes = 3;
 #endif
@@ -28,16 +28,41 @@ int main(int argc, char** argv) {
         for (int nt : {1, 4, 8, 16, 32}) {
             std::atomic<int> next{0};
             std::atomic<size_t> bytes{0};
+#ifdef WITH_HIP
+            std::atomic<bool> stop_dma{false};
+            std::vector<char*> bufs(nt, nullptr);
+            std::thread dma;
+            if (mode == 5) {
+                dma = std::thread([&] {
+                    (void)hipSetDevice(0);
+                    void* d = nullptr;
+                    (void)hipMalloc(&d, 40u << 20);
+                    hipStream_t st;
+                    (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+                    size_t moved = 0;
+                    const auto t0 = std::chrono::steady_clock::now();
+                    while (!stop_dma.load()) {
+                        for (int t = 0; t < nt; ++t)
+                            if (bufs[t]) { (void)hipMemcpyAsync(d, bufs[t], 30u << 20, hipMemcpyHostToDevice, st); moved += 30u << 20; }
+                        (void)hipStreamSynchronize(st);
+                    }
+                    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    printf("   (DMA beside it: %.1f GB/s)\n", moved / s / 1e9);
+                    (void)hipFree(d);
+                });
+            }
+#endif
             const auto t0 = std::chrono::steady_clock::now();
             std::vector<std::thread> th;
             for (int t = 0; t < nt; ++t)
-                th.emplace_back([&] {
+                th.emplace_back([&, t] {
                     const size_t cap = 40u << 20;
                     char* buf = (char*)mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
                     madvise(buf, cap, MADV_HUGEPAGE);
                     memset(buf, 0, cap);
 #ifdef WITH_HIP
-                    if (mode == 3) (void)hipHostRegister(buf, cap, hipHostRegisterDefault);
+                    if (mode == 3 || mode == 5) (void)hipHostRegister(buf, cap, hipHostRegisterDefault);
+                    if (mode == 5) bufs[t] = buf;
                     char* hb = nullptr;
                     if (mode == 4) { (void)hipHostMalloc((void**)&hb, cap, 0); buf = hb; }
 #endif
@@ -65,14 +90,18 @@ int main(int argc, char** argv) {
                     }
                     bytes += got_all;
 #ifdef WITH_HIP
+                    if (mode == 5) return;   // (the DMA thread may still be reading from it: left mapped)
                     if (mode == 3) (void)hipHostUnregister(buf);
                     if (mode == 4) { (void)hipHostFree(hb); return; }
 #endif
                     munmap(buf, cap);
                 });
             for (auto& t : th) t.join();
+#ifdef WITH_HIP
+            if (mode == 5) { stop_dma = true; dma.join(); }
+#endif
             const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            printf("%-22s %2d threads: %.1f GB/s (%.0f files/s)\n", mode == 0 ? "read()" : mode == 1 ? "mmap + memcpy" : mode == 2 ? "mmap(POPULATE) + memcpy" : mode == 3 ? "read() -> registered" : "read() -> hipHostMalloc", nt,
+            printf("%-22s %2d threads: %.1f GB/s (%.0f files/s)\n", mode == 0 ? "read()" : mode == 1 ? "mmap + memcpy" : mode == 2 ? "mmap(POPULATE) + memcpy" : mode == 3 ? "read() -> registered" : mode == 4 ? "read() -> hipHostMalloc" : "read() -> registered + DMA", nt,
                    bytes.load() / s / 1e9, n_files / s);
         }
     return 0;
