@@ -70,6 +70,8 @@ struct Tuning {
     int decode_in_dense_stream = 1;   // the decode kernel runs in the dense kernels' stream (0: in the upload stream)
     int ccl_grid = 32;          // workgroups per frame of the grid-wide sparse kernels
     int rows_ahead = 2;         // rows of loads a wave of the 16-bit streaming kernel keeps in flight (2, 3 or 4)
+    int chain_runs = 1;         // sparse_stage 2: frames beyond the LDS forest of pixels stay in the one launch when their RUNS fit
+                                //    (16-bit pixels, rows up to 16383 pixels); 0 = such batches take the four grid-wide kernels
 #ifdef FFS_EXPERIMENTS
     struct Exp {
         int k1_debug = 0, chain_skip = 0, chain_stop = 0, dummy_us = 0, dummy_wg = 32, dummy_threads = 1024, dummy_lds = 0;
@@ -138,6 +140,8 @@ struct ffs_stream {
     ffs_stream* big = nullptr;               // one-frame stream with room for frames that exceed cap / max_comp
     std::vector<OverflowFrame> ovf;          // such frames of the last batch, re-run on `big`
     int force_path = -1;                     // >= 0: threshold path of the next enqueue (bright-list overflow -> 1)
+    bool force_grid = false;                 // the next enqueue takes the grid-wide sparse kernels (a frame's runs overflowed the one launch)
+    bool runs_overflowed = false;            // ... and dense batches of this stream keep taking them
     uint32_t *d_pack_k = nullptr, *d_pack_i = nullptr;  // a batch's lists packed end to end for another device's 3D stack
     StackSlice *d_pack_tab = nullptr, *h_pack_tab = nullptr;
     hipEvent_t ev_pack = nullptr;            // the packed lists are ready on the source device

@@ -15,8 +15,9 @@
 bool chain_prepare_device() {   // more than 64 KB of dynamic LDS has to be asked for, per device
     const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
     const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
+    const hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
     (void)hipGetLastError();
-    return e1 == hipSuccess && e2 == hipSuccess;
+    return e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess;
 }
 
 ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t pitch, size_t fstride, uint32_t n_frames) {
@@ -264,11 +265,18 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
     // inside its one workgroup (2.8 ms for 32 frames of 61 k strong pixels, the extended algorithm on the bench frames),
     // where the four grid-wide kernels spread the work over the machine: the path of this batch follows what the stream's
     // previous batch held (data that is dense stays dense; a single dense frame costs one slow batch).
+    // Denser frames of 16-bit pixels stay in the one launch while their RUNS fit LDS (kernels_chain.hpp, the RUNS instantiation:
+    // 61 k strong pixels are 12 k runs on the bench frames of the extended algorithm); a frame with more runs than that raises
+    // flag 16, ffs_wait() runs the batch again through the grid-wide kernels and the stream stays with them for dense batches.
+    const bool runs_ok = c->pixel_bytes == 2 && L.W <= kChainRunMaxW && c->tune.chain_runs != 0 && !s->runs_overflowed;
+    bool dense_batch = false;
     if (will_chain && c->tune.sparse_stage == 2 && s->n_frames > 0) {
         uint32_t prev_max = 0;
         for (uint32_t f = 0; f < s->n_frames; ++f) prev_max = std::max(prev_max, s->h_counts[f]);
-        if (prev_max > (uint32_t)kChainLdsEntries) will_chain = false;
+        dense_batch = prev_max > (uint32_t)kChainLdsEntries;
+        if (dense_batch && !runs_ok) will_chain = false;
     }
+    if (s->force_grid) will_chain = false;
 #ifdef FFS_EXPERIMENTS
     if (c->tune.exp.chain_skip) will_chain = false;
 #endif
@@ -382,11 +390,13 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
         A.t = ta;
         A.fix_bright = chain_first ? 1 : 0;
         A.fix_done = s->d_tile_counts + tile_counts_bytes(s) / 4 - 2;
+        A.runs_ok = runs_ok ? 1 : 0;
         {
             // the launch's start event belongs to the context (ffs_internal.hpp); published under the lock the waiting side takes
             std::lock_guard<std::mutex> lock(c->stream_mu);
             const int slot = (int)(c->chain_ev_next.fetch_add(1) % ffs_ctx::kChainEvents);
-            if (c->pixel_bytes == 2) hipExtLaunchKernelGGL(k_frame_chain<uint16_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
+            if (c->pixel_bytes == 2 && dense_batch && runs_ok) hipExtLaunchKernelGGL((k_frame_chain<uint16_t, true>), dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
+            else if (c->pixel_bytes == 2) hipExtLaunchKernelGGL(k_frame_chain<uint16_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
             else hipExtLaunchKernelGGL(k_frame_chain<uint32_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
             if (aside) c->chain_ev_newest.store(slot);
         }

@@ -63,6 +63,16 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
             if (rc != FFS_OK) return rc;
             return ffs_wait_impl(s, results, n_results);
         }
+        if (overflow & 16u) {
+            // a dense frame with more runs than the one-launch sparse stage holds in LDS (kernels_chain.hpp): the batch again, its
+            // sparse stage as the four grid-wide kernels; the stream's later dense batches go there directly
+            s->runs_overflowed = true;
+            s->force_grid = true;
+            int rc = enqueue_batch(s, s->cur_img, s->cur_pitch, s->cur_fstride, s->n_frames, &s->batch_params);
+            s->force_grid = false;
+            if (rc != FFS_OK) return rc;
+            return ffs_wait_impl(s, results, n_results);
+        }
         // A frame with more strong pixels than the stream's lists hold (flag 1) or more components than its
         // record buffers (flag 2) -- an ice ring, the direct beam.  The reference has no such limit (std::map of
         // signals, connected_components.cc:24-32), so neither may the drop-in: the other frames of the batch are

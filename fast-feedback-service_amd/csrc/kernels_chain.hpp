@@ -51,6 +51,11 @@ constexpr int kChainQuads = 4;          // rounds (4 words per lane each) per ba
 constexpr int kChainLdsEntries = 20480; // strong pixels of a frame whose union-find forest fits LDS
 constexpr int kChainPer = kChainLdsEntries / kChainThreads;   // consecutive entries per thread in phases U / P / R
 constexpr int kChainSlots = 832;        // components accumulated in LDS at a time
+// Denser frames of 16-bit pixels (the extended algorithm marks whole spots: 61 k strong pixels in 12 k runs on the bench
+// frames): the forest is built over RUNS -- maximal rows of strong pixels inside one 32-pixel plane word -- instead of pixels.
+constexpr int kChainRunCap = 16384;     // runs of a frame whose forest (4 B) and descriptors (4 B) fit LDS
+constexpr int kChainRunPer = kChainRunCap / kChainThreads;   // consecutive runs per thread in phases U' / P' / R'
+constexpr int kChainRunMaxW = 16383;    // descriptor: y << 19 | x0 << 5 | (len - 1)  (H <= kChainMaxRows < 8192)
 
 // LDS accumulator of one component: sum I, sum (2x+1) I, sum (2y+1) I, peak = I << 32 | ~k
 struct ChainAcc {
@@ -68,6 +73,8 @@ constexpr int kChainStageOff = (kChainMaxTiles + 1) * 4 + (kChainMaxRows + 1) * 
 constexpr int kChainSegOff = kChainStageOff + kChainWaves * 2 * kChainListCap * 4;
 constexpr int kChainDynBytes = kChainSegOff + kChainWaves * kChainSegCap * 2;
 static_assert(kChainStageOff % 8 == 0 && kChainDynBytes <= 160 * 1024 - 256, "LDS plan");
+static_assert(2 * kChainRunCap * 4 <= kChainForestBytes + (kChainDynBytes - kChainStageOff), "LDS plan (runs)");
+static_assert(kChainMaxRows < 8192, "run descriptor");
 
 // Inclusive prefix sum over the 64 lanes in six DPP adds (row_shr 1/2/4/8 inside the rows of 16, then row_bcast:15 and
 // row_bcast:31 carry the row totals on) instead of six ds_bpermute round trips.
@@ -91,6 +98,7 @@ struct ChainArgs {
     int fix_bright;
     uint32_t* fix_done;     // workgroups through with the bright list (the last one zeroes the list's count)
     int stop_after;         // (timing experiments) 1..4: return after phase A / E / U / P
+    int runs_ok;            // frames beyond kChainLdsEntries strong pixels may take the run-based phases (16-bit pixels, W <= kChainRunMaxW)
 };
 
 __device__ __forceinline__ void chain_record(const SegArgs& sa, uint32_t W, uint32_t num_pixels, unsigned long long sum_i,
@@ -130,7 +138,9 @@ __device__ __forceinline__ void chain_record(const SegArgs& sa, uint32_t W, uint
     if (flags & 2u) atomicAdd(&s_sm[4], 1u);
 }
 
-template <typename PixelT>
+// RUNS: the instantiation that also holds the run-based phases for frames beyond kChainLdsEntries strong pixels (launched when
+// the stream's previous batch was that dense; a kernel of its own so that the usual one keeps its register allocation).
+template <typename PixelT, bool RUNS = false>
 __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A) {
     const CclArgs& a = A.c;
     const SegArgs& sa = A.s;
@@ -139,6 +149,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
     uint32_t* s_row = s_toff + (kChainMaxTiles + 1);                     // [H + 1] per-row counts, then offsets
     uint8_t* s_big = reinterpret_cast<uint8_t*>(s_row + (kChainMaxRows + 1));
     __shared__ uint32_t s_wave[kChainWaves];
+    __shared__ uint32_t s_wrun[kChainWaves];   // runs listed by each wave (run-based phases)
     __shared__ uint32_t s_sm[8];
 
     const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -194,11 +205,15 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
             if (frame == 0 && sa.zero_word && !A.fix_bright) *sa.zero_word = 0;
         }
         if (tid < 8) s_sm[tid] = 0;
+        if (tid < kChainWaves) s_wrun[tid] = 0;
         for (int y = tid; y <= a.H; y += kChainThreads) s_row[y] = 0;
     }
     __syncthreads();
     const uint32_t n = min(total, a.cap);
     const bool in_lds = n <= (uint32_t)kChainLdsEntries;
+    // denser: runs instead of pixels where the frame allows it (block-uniform)
+    const bool runs = RUNS && sizeof(PixelT) == 2 && !in_lds && A.runs_ok != 0;
+    uint32_t run_flag = 0;   // 16: more runs than the LDS plan holds (the host runs the batch again through the grid-wide kernels)
     FFS_STOP_AFTER(A, 1);
 
     uint32_t* gk = a.list_k + (uint64_t)frame * a.cap;
@@ -231,6 +246,9 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
             uint32_t* s_w = s_g + kChainListCap;
 
             uint32_t run = s_toff[tb];             // list position of the next strong pixel (wave-uniform)
+            // run-based phases: this wave's run descriptors go, in order, to entries s_toff[tb] .. of the array the pixel path
+            // keeps its parents in (there are never more runs than pixels, so the waves' ranges cannot meet)
+            uint32_t rrun = s_toff[tb];            // scratch position of the next run (wave-uniform)
             int n_list = 0;                        // staged non-zero words (wave-uniform)
             uint32_t last_g = 0xFFFFFFFFu, last_w = 0;  // the word before the staged ones (for the link to the left)
             // places the pixels of `cnt` (<= 64) staged words from `first` on, one word per lane
@@ -244,6 +262,39 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                 const uint32_t inc = wave_inclusive_scan(pc);
                 uint32_t at = run + inc - pc;
                 run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                if constexpr (RUNS) if (runs) {   // block-uniform
+                    // runs inside the word (one that continues from the word before starts anew: phase U' joins them)
+                    const uint32_t starts = w & ~(w << 1);
+                    const uint32_t rc = (uint32_t)__popc(starts);
+                    const uint32_t rinc = wave_inclusive_scan(rc);
+                    uint32_t rat = rrun + rinc - rc;
+                    rrun += (uint32_t)__builtin_amdgcn_readlane((int)rinc, 63);
+                    if (valid) {
+                        const int row = (int)g / dpr;
+                        const int col = (int)g - row * dpr;
+                        const int xb = col * 32;
+                        const int y = yb + row;
+                        atomicAdd(&s_row[y], rc);   // runs per row here
+                        uint32_t st = starts;
+                        while (st) {
+                            const int b = __ffs((int)st) - 1;
+                            st &= st - 1;
+                            const uint32_t rest = w >> b;   // bit 0 = the run's first pixel
+                            const uint32_t len = rest == 0xFFFFFFFFu ? 32u : (uint32_t)__ffs((int)~rest) - 1u;
+                            if (rat < a.cap) gpar[rat] = ((uint32_t)y << 19) | ((uint32_t)(xb + b) << 5) | (len - 1u);
+                            ++rat;
+                        }
+                        while (w) {
+                            const int b = __ffs((int)w) - 1;
+                            w &= w - 1;
+                            if (at < a.cap) gk[at] = (uint32_t)y * W + (uint32_t)(xb + b);
+                            if (a.dense_bytes) sbytes[(uint64_t)y * a.bpitch + (uint32_t)(xb + b)] = 1;
+                            ++at;
+                        }
+                        if (a.clear_bits) words[g] = 0;
+                    }
+                    return;
+                }
                 if (valid) {
                     if (a.clear_bits) words[g] = 0;   // (the streaming kernel needs an all-zero plane)
                     const int row = (int)g / dpr;
@@ -440,6 +491,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
             }
             drain(true);
             }
+            if (lane == 0) s_wrun[wave] = rrun - s_toff[tb];
         }
     }
     __syncthreads();
@@ -647,6 +699,163 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
             }
             __syncthreads();
         }
+    } else if (runs) {
+        // ---- denser frames of 16-bit pixels: the same phases over runs ------------------------------------------------------
+        // s_row holds the list offset of every row's first RUN now.  A run lies inside one 32-pixel plane word = one aligned
+        // 64-byte piece of its image row: phase P' fetches that piece with four 16-byte loads and sums the run in registers,
+        // so the accumulators take one set of atomics per run instead of one per pixel.
+        if constexpr (RUNS && sizeof(PixelT) == 2) {
+        const uint32_t nr = s_row[a.H];
+        uint32_t* s_rd = spar + kChainRunCap;   // descriptors: y << 19 | x0 << 5 | (len - 1)
+        if (nr > (uint32_t)kChainRunCap) {
+            run_flag = 16u;
+        } else {
+            // ---- X': descriptors into LDS in list order (wave after wave), the forest's singletons, the pixel values
+            {
+                const int tpw = (n_tiles + kChainWaves - 1) / kChainWaves;
+                uint32_t base = 0;
+                for (int v = 0; v < kChainWaves; ++v) {
+                    const uint32_t cnt = s_wrun[v], src = s_toff[min(v * tpw, n_tiles)];
+                    for (uint32_t j = tid; j < cnt; j += kChainThreads) {
+                        const uint32_t i = base + j;
+                        if (i < nr) {
+                            s_rd[i] = src + j < a.cap ? gpar[src + j] : 0u;
+                            spar[i] = i;
+                        }
+                    }
+                    base += cnt;
+                }
+                // the intensity list (for the consumers of the pixel lists: nothing below reads it)
+                for (uint32_t i = tid; i < n; i += kChainThreads) gi[i] = pixel_at(gk[i]);
+            }
+            __syncthreads();
+            const uint32_t per = (nr + kChainThreads - 1) / kChainThreads;   // <= kChainRunPer
+            const uint32_t i0 = min((uint32_t)tid * per, nr), i1 = min(i0 + per, nr);
+            auto rx0 = [](uint32_t d) -> uint32_t { return (d >> 5) & 0x3FFFu; };
+            auto rx1 = [](uint32_t d) -> uint32_t { return ((d >> 5) & 0x3FFFu) + (d & 31u); };
+
+            // ---- U': the k + 1 edges between runs that touch (word boundaries; the reference's row-wrap edge), the k + W edges
+            // between runs of consecutive rows that overlap
+            for (uint32_t i = i0; i < i1; ++i) {
+                const uint32_t d = s_rd[i], y = d >> 19, x0 = rx0(d), x1 = rx1(d);
+                if (i > 0) {
+                    const uint32_t dp = s_rd[i - 1], yp = dp >> 19, x1p = rx1(dp);
+                    if ((yp == y && x1p + 1 == x0) || (x0 == 0 && yp + 1 == y && x1p == W - 1)) uf_union(spar, i - 1, i);
+                }
+                if (y + 1 >= H) continue;
+                uint32_t lo = s_row[y + 1], hi = s_row[y + 2];
+                const uint32_t end = hi;
+                while (lo < hi) {   // the first run of the next row that ends at or after x0
+                    const uint32_t mid = lo + ((hi - lo) >> 1);
+                    if (rx1(s_rd[mid]) < x0) lo = mid + 1; else hi = mid;
+                }
+                for (uint32_t j = lo; j < end && rx0(s_rd[j]) <= x1; ++j) uf_union(spar, i, j);
+            }
+            __syncthreads();
+            FFS_STOP_AFTER(A, 3);
+
+            // ---- P': every run's sums (registers, through phase R'); roots, numbered in list order ----------------------
+            uint32_t rd[kChainRunPer], rsi[kChainRunPer], rsj[kChainRunPer], rpk[kChainRunPer], rid[kChainRunPer];
+            const rsrc_t r_img = make_rsrc(img, (uint32_t)a.H * a.pitch);
+            uint32_t mine = 0;
+#pragma unroll
+            for (int q = 0; q < kChainRunPer; ++q) {
+                rd[q] = 0; rsi[q] = 0; rsj[q] = 0; rpk[q] = 0; rid[q] = 0xFFFFu;
+                if (i0 + q < i1) {
+                    const uint32_t d = s_rd[i0 + q];
+                    rd[q] = d;
+                    const uint32_t y = d >> 19, x0 = rx0(d), len = (d & 31u) + 1u, b0 = x0 & 31u;
+                    const uint32_t off = y * a.pitch + (x0 - b0) * 2u;   // the run's 64-byte piece (beyond the frame: zeros, never selected)
+                    uint32_t v[16];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const u32x4 ld = __builtin_amdgcn_raw_buffer_load_b128(r_img, off, (uint32_t)t * 16u, 0);
+                        v[4 * t] = ld[0]; v[4 * t + 1] = ld[1]; v[4 * t + 2] = ld[2]; v[4 * t + 3] = ld[3];
+                    }
+                    const uint32_t sel = (len == 32u ? 0xFFFFFFFFu : ((1u << len) - 1u)) << b0;
+                    uint32_t si = 0, sj = 0, pk = 0;
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) {
+                        const uint32_t I = (j & 1) ? v[j >> 1] >> 16 : v[j >> 1] & 0xFFFFu;
+                        const bool on = (sel >> j) & 1u;
+                        const uint32_t Im = on ? I : 0u;
+                        si += Im;
+                        sj += (uint32_t)j * Im;                                   // < 32 * 32 * 65535
+                        pk = max(pk, on ? (I << 5) | (uint32_t)(31 - j) : 0u);    // highest intensity, ties -> smallest x
+                    }
+                    rsi[q] = si;
+                    rsj[q] = sj - b0 * si;   // sum (x - x0) I
+                    rpk[q] = pk;
+                    const uint32_t root = uf_find(spar, i0 + q);
+                    rid[q] = root;
+                    mine += root == i0 + q ? 1u : 0u;
+                }
+            }
+            __syncthreads();   // every find is done: the forest's root slots now take the component numbers
+            {
+                uint32_t slot = block_exclusive_scan<kChainThreads>(mine, s_wave, before);
+#pragma unroll
+                for (int q = 0; q < kChainRunPer; ++q)
+                    if (i0 + q < i1 && rid[q] == i0 + q) spar[i0 + q] = slot++;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < kChainRunPer; ++q)
+                if (i0 + q < i1) rid[q] = spar[rid[q]];
+            __syncthreads();   // the forest and the descriptors are dead from here on: accumulators + record staging
+            FFS_STOP_AFTER(A, 4);
+
+            // ---- R': kChainSlots components at a time -------------------------------------------------------------------
+            ChainAcc* s_acc = reinterpret_cast<ChainAcc*>(s_big);
+            uint32_t* s_out = reinterpret_cast<uint32_t*>(s_big + kChainSlots * sizeof(ChainAcc));
+            const uint32_t ncomp = min(before, sa.max_comp);
+            for (uint32_t c0 = 0; c0 < ncomp; c0 += kChainSlots) {
+                if (tid < kChainSlots) {
+                    ChainAcc z;
+                    z.sum_i = z.sum_xi = z.sum_yi = z.peak = 0ull;
+                    z.x_min = 0xFFFFFFFFu; z.x_max = 0u; z.y_min = 0xFFFFFFFFu; z.y_max = 0u;
+                    z.num_pixels = 0u; z.pad = 0u;
+                    s_acc[tid] = z;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < kChainRunPer; ++q) {
+                    const uint32_t c = rid[q] - c0;    // (an unused slot's 0xFFFF - c0 is never below kChainSlots)
+                    if (c < (uint32_t)kChainSlots) {
+                        uint32_t d = rd[q];
+                        asm volatile("" : "+v"(d));   // (see phase R: keeps the products inside the loop over c0)
+                        const uint32_t y = d >> 19, x0 = rx0(d), x1 = rx1(d);
+                        const unsigned long long si = rsi[q], sj = rsj[q];
+                        const uint32_t pI = rpk[q] >> 5, px = (x0 & ~31u) + (31u - (rpk[q] & 31u));
+                        ChainAcc* r = &s_acc[c];
+                        atomicMin(&r->x_min, x0); atomicMax(&r->x_max, x1);
+                        atomicMin(&r->y_min, y); atomicMax(&r->y_max, y);
+                        atomicAdd(&r->num_pixels, x1 - x0 + 1u);
+                        atomicAdd(&r->sum_i, si);
+                        atomicAdd(&r->sum_xi, (2ull * x0 + 1ull) * si + 2ull * sj);   // sum (2x + 1) I over the run
+                        atomicAdd(&r->sum_yi, (2ull * y + 1ull) * si);
+                        atomicMax(&r->peak, ((unsigned long long)pI << 32) | (unsigned long long)(0xFFFFFFFFu - (y * W + px)));
+                    }
+                }
+                __syncthreads();
+                const uint32_t here = min((uint32_t)kChainSlots, ncomp - c0);
+                if ((uint32_t)tid < here) {
+                    const ChainAcc r = s_acc[tid];
+                    WireRec2 o;
+                    chain_record(sa, W, r.num_pixels, r.sum_i, r.sum_xi, r.sum_yi, r.x_min, r.x_max, r.y_min, r.y_max,
+                                 0xFFFFFFFFu - (uint32_t)(r.peak & 0xFFFFFFFFull), (uint32_t)(r.peak >> 32), s_sm, o);
+                    *reinterpret_cast<WireRec2*>(&s_out[tid * (sizeof(WireRec2) / 4)]) = o;
+                }
+                __syncthreads();
+                {
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(recs + c0);
+                    const uint32_t ndw = here * (uint32_t)(sizeof(WireRec2) / 4);
+                    for (uint32_t w = tid; w < ndw; w += kChainThreads) dst[w] = s_out[w];
+                }
+                __syncthreads();
+            }
+        }
+        }
     } else {
         // ---- denser frames: the same stages on the global arrays (the bodies of k_union / k_reduce_roots / k_finalize_roots)
         for (uint32_t i = tid; i < n; i += kChainThreads) gi[i] = pixel_at(gk[i]);
@@ -735,7 +944,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
     // ---- counters: device copies for the other consumers of the lists, host copies for ffs_wait() --------------
     __syncthreads();
     if (tid == 0) {
-        uint32_t flags = *a.overflow | bright_flag;   // what the dense stages raised (corrupt chunk; bright-list overflow)
+        uint32_t flags = *a.overflow | bright_flag | run_flag;   // what the dense stages raised (corrupt chunk; bright-list overflow)
         if (total > a.cap) flags |= 1u;
         if (before > sa.max_comp) flags |= 2u;
         a.num_strong[frame] = total;
@@ -750,7 +959,8 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
         A.h_counts[2 * (size_t)A.max_batch + (size_t)frame * 8 + tid] = s_sm[tid];
     }
 }
-template __global__ void k_frame_chain<uint16_t>(const ChainArgs);
-template __global__ void k_frame_chain<uint32_t>(const ChainArgs);
+template __global__ void k_frame_chain<uint16_t, false>(const ChainArgs);
+template __global__ void k_frame_chain<uint16_t, true>(const ChainArgs);
+template __global__ void k_frame_chain<uint32_t, false>(const ChainArgs);
 
 }  // namespace ffsamd

@@ -215,6 +215,8 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     uint32_t col[8], colq[8];
     uint32_t M[4] = {0, 0, 0, 0};  // pair masks of the current mask byte
     uint32_t mprev = 0;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    [[maybe_unused]] f32x2 ext_c1 = {0.0f, 0.0f}, ext_c2 = {0.0f, 0.0f};   // EXT: screen constants of the current window counts, in pairs
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         rinfo[s] = 0;
@@ -251,6 +253,17 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                     M[q] = ((uint32_t)__builtin_amdgcn_sbfe((int)mb, 2 * q, 1) & 0xFFFFu)
                          | ((uint32_t)__builtin_amdgcn_sbfe((int)mb, 2 * q + 1, 1) & 0xFFFF0000u);
                 mprev = mb;
+            }
+            if constexpr (EXT) {
+                // the two constants of the first-pass screen follow the window counts that came with this row (see there):
+                // taken here, where a change of the counts is noticed anyway, not once per row (a root and five more
+                // instructions for values that change at module edges only)
+                const uint32_t mmin = (rinfo[slot] >> 8) & 0xFFu, mmax = (rinfo[slot] >> 16) & 0xFFu;
+                const float mm1 = (float)mmin - 1.0f;
+                const float c1 = (float)mmax * 1.0000019073486328125f;
+                const float c2 = (mm1 + a.kB * __builtin_amdgcn_sqrtf(2.0f * mm1)) * 0.99999952316284179688f;
+                ext_c1 = f32x2{c1, c1};
+                ext_c2 = f32x2{c2, c2};
             }
         }
 #pragma unroll
@@ -295,7 +308,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     // other inside their group's lane (the drain is a latency chain, not a throughput problem).
     // Phase 3: the group's lane collects its result byte.
     auto drain = [&]() {
-        const bool have = lane < qn && !FFS_DBG(a, 2);
+        const bool have = lane < qn && !FFS_DBG(a, 2) && !FFS_DBG(a, 32);   // (bit 32 leaves the queue unwritten: nothing to read back)
         uint32_t todo = 0, row = 0, fe = 0, ge = 0;
         if (have) {
             const uint32_t tag = s_q[30][lane], ln = tag & 63u;
@@ -313,30 +326,43 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
             s_q[12][lane] = mm.x;
             s_q[13][lane] = mm.y;
             s_q[14][lane] = 0u;
+            uint32_t sure = 0;   // EXT: pixels the float32 form already proves "above background"
             if constexpr (EXT) {
                 // every VALID pixel of the group with enough pixels in its window (and a centre not above max_valid,
-                // the device kernels' rule) takes the exact test: the screen already was the dispersion bound
+                // the device kernels' rule) is decided here where float32 can: with t0 = m y, the float32 value af of
+                // a = t0 - x (x + m - 1) is within 2^-22 t0 of the true one (y and the two products rounded once each, x and
+                // x + m - 1 exact below 2^24, the difference once), cf = x kB sqrt(2 (m - 1)) within 2^-19 of the true c
+                // (kB = nsig_b (1 - 2^-20), one ulp each for the root and the two products).  2^-20 t0 and 2^-18 cf are granted:
+                //   af + 2^-20 t0 <  cf               -> certainly not above background
+                //   af - 2^-20 t0 >  cf (1 + 2^-18)   -> certainly above (float64 roundings of the oracle: 2^-50 t0, far inside)
+                // and only the band between the two takes the float64 test of phase 2 (a few pixels per million).
                 const uint32_t valid = ginf >> 24;
                 uint32_t wq = 0;  // window j sums cq[j .. j+6]
 #pragma unroll
                 for (int t = 0; t < 7; ++t) wq += s_q[16 + t][lane];
+                // one count for the whole group almost everywhere: its root is taken once
+                const float kq_group = a.kB * __builtin_amdgcn_sqrtf(2.0f * ((float)gmin - 1.0f));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const uint32_t x = s_q[j][lane];
                     const uint32_t pw = s_q[8 + (j >> 1)][lane];
                     const uint32_t pv = (j & 1) ? pw >> 16 : pw & 0xFFFFu;
                     const uint32_t m = ((j < 4 ? mm.x : mm.y) >> (8 * (j & 3))) & 0xFFu;
-                    // the pixel's own conservative float32 form first (its count this time, not the group's bounds):
-                    // only what it cannot reject takes the float64 test
                     const float mf = (float)m, xf = (float)x, yf = (float)wq;
+                    const float kq = gmin == gmax ? kq_group : a.kB * __builtin_amdgcn_sqrtf(2.0f * (mf - 1.0f));
                     const float t0 = mf * yf;
                     const float af = t0 - xf * (xf + (mf - 1.0f));
-                    const float cf = xf * (a.kB * __builtin_amdgcn_sqrtf(2.0f * (mf - 1.0f)));
-                    const bool maybe = (af + t0 * 9.5367431640625e-07f >= cf) || x >= 65536u;
+                    const float cf = xf * kq;
+                    const float slack = t0 * 9.5367431640625e-07f;
+                    const bool bright = x >= 65536u;   // (the 32-bit sums of p^2 may have wrapped: phase 2 hands it to k_bright_fix)
+                    const bool maybe = (af + slack >= cf) || bright;
+                    const bool yes = !bright && (af - slack > cf * 1.000003814697265625f);
                     const bool ok = ((valid >> j) & 1u) && (int)m >= a.min_count && !(a.max_valid >= 0 && (long long)pv > a.max_valid);
-                    todo |= (ok && maybe) ? (1u << j) : 0u;
+                    todo |= (ok && maybe && !yes) ? (1u << j) : 0u;
+                    sure |= (ok && yes) ? (1u << j) : 0u;
                     if (j < 7) wq = wq - s_q[16 + j][lane] + s_q[23 + j][lane];
                 }
+                s_q[14][lane] = sure;
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -484,16 +510,18 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                     // a pixel can only pass the first pass where d_j >= 0; the lane keeps the largest d_j
                     const uint32_t ys[8] = {y0, y1, y2, y3, y4, y5, y6, y7};
                     // d_j = c1 y_j - x_j (x_j + c2) with c1 = mmax (1 + 2^-19) and c2 = (mmin - 1 + kB sqrt(2 (mmin - 1))) (1 - 2^-21): an upper
-                    // bound of a_j - c_j in float32 whatever the five roundings do (each within 2^-24 of a term no larger than
-                    // c1 y_j or x_j (x_j + c2); the two factors grant 2^-19 and 2^-21 of them) -- seven instructions per pixel
-                    const float mm1 = (float)mmin - 1.0f;
-                    const float c1 = (float)mmax * 1.0000019073486328125f;
-                    const float c2 = (mm1 + a.kB * __builtin_amdgcn_sqrtf(2.0f * mm1)) * 0.99999952316284179688f;
+                    // bound of a_j - c_j in float32 whatever the roundings do (y_j, x_j + c2, the product and the fused difference:
+                    // each within 2^-24 of a term no larger than c1 y_j or x_j (x_j + c2); the two factors grant 2^-19 and 2^-21 of
+                    // them).  Two pixels per instruction: v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32 -- 12 + 16 conversions + 4
+                    // v_max3 per row (the compiler's own packing of the one-pixel form spent 19 v_mov on pairing registers).
                     float dmax = -1.0f;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float xf = (float)Wn[j], yf = (float)ys[j];
-                        dmax = __builtin_fmaxf(dmax, c1 * yf - xf * (xf + c2));
+                    for (int jp = 0; jp < 4; ++jp) {
+                        const f32x2 xf = {(float)Wn[2 * jp], (float)Wn[2 * jp + 1]};
+                        const f32x2 yf = {(float)ys[2 * jp], (float)ys[2 * jp + 1]};
+                        const f32x2 u = xf * (xf + ext_c2);
+                        const f32x2 d = __builtin_elementwise_fma(ext_c1, yf, -u);
+                        dmax = __builtin_fmaxf(dmax, __builtin_fmaxf(d.x, d.y));
                     }
                     const uint32_t xmax = max(max(max(max(Wn[0], Wn[1]), Wn[2]), max(max(Wn[3], Wn[4]), Wn[5])), max(Wn[6], Wn[7]));
                     pass = mmax != 0u && (dmax >= 0.0f || xmax >= 65536u);

@@ -155,6 +155,8 @@ int ffs_ctx_set_params(ffs_ctx *ctx, const ffs_params *p);
  *   "ext_first_pass"   (2) extended algorithm, 16-bit pixels: 2 = streaming kernel, 0 = plain one-pixel-per-lane kernel
  *   "sparse_stage"     (2) one launch per batch, a workgroup per frame: 3 = always, 2 = unless the stream's previous batch
  *                          held a frame with more strong pixels than that workgroup's LDS holds; 1 = four grid-wide kernels
+ *   "chain_runs"       (1) with "sparse_stage" 2: such dense batches of 16-bit frames stay in the one launch, its union-find
+ *                          over runs of strong pixels instead of pixels (up to 16384 runs per frame); 0 = they take the grid-wide kernels
  *   "sched"            (3) 3 = shared dense / sparse / upload HIP streams per context, 0 = one per ffs_stream
  *                          (before the first stream is created)
  *   "direct_records"   (1) records written straight into pinned host memory (before the first stream is created)

@@ -324,3 +324,79 @@ def test_random_shapes_and_densities(ffs, dtype):
         for fr, img in zip(res, frames):
             assert_frame_matches_oracle(fr, img, mask, min_spot_size=mss, max_sep=sep)
         st.close()
+
+
+def _blob_frame(W, H, seed, n_blobs, rmin=3, rmax=7):
+    """Fat spots on a quiet background: many strong pixels in few runs (what the extended algorithm's final mask looks like)."""
+    rng = np.random.default_rng(seed)
+    img = rng.poisson(1.0, (H, W)).astype(np.uint16)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for _ in range(n_blobs):
+        cy, cx, r = rng.integers(0, H), rng.integers(0, W), rng.integers(rmin, rmax + 1)
+        y0, y1, x0, x1 = max(cy - r, 0), min(cy + r + 1, H), max(cx - r, 0), min(cx + r + 1, W)
+        sel = (yy[y0:y1, x0:x1] - cy) ** 2 + (xx[y0:y1, x0:x1] - cx) ** 2 <= r * r
+        img[y0:y1, x0:x1][sel] = rng.integers(200, 4000, sel.sum()).astype(np.uint16)
+    return img
+
+
+@pytest.mark.parametrize("chain_runs", [1, 0])
+def test_run_based_sparse_stage(ffs, chain_runs):
+    """Frames beyond the LDS forest of pixels (20480) whose RUNS fit (16384): from the stream's second dense batch on the one
+    launch builds its forest over runs (k_frame_chain<uint16_t, true>).  Fat spots, spots across 32-pixel word boundaries and
+    frame edges, rows that are one long run (32 word-runs chained), the reference's row-wrap edge between fat runs, equal
+    peak intensities (ties go to the smallest (y, x)), an empty and a sparse frame in the same batch; `chain_runs` 0 (the four
+    grid-wide kernels for such batches) must agree."""
+    W, H = 1000, 700     # (W not a multiple of 32: the last word of a row is cut)
+    a = _blob_frame(W, H, 1, 500)
+    b = _blob_frame(W, H, 2, 420)
+    b[300, :] = 900                       # a whole row: 32 word-runs, joined with everything it touches
+    b[301, 0:40] = 900                    # row wrap: (W-1, 300) -- (0, 301)
+    b[400:440, 31:33] = 700               # a vertical bar across a word boundary
+    b[500, 64:96] = 1234                  # exactly one full word
+    b[502, 63:97] = 1234                  # one pixel more on both sides
+    b[0, 0:5] = 800; b[H - 1, W - 5:W] = 800; b[0, W - 3:W] = 800; b[1, 0:3] = 800   # corners; (W-1, 0) -- (0, 1) wraps
+    c = _blob_frame(W, H, 3, 480)
+    c[c > 150] = 2000                     # every strong pixel the same value: peaks decided by position alone
+    sparse, _ = make_frame(W=W, H=H, seed=33, n_spots=30)
+    empty = np.zeros((H, W), np.uint16)
+    frames = np.stack([a, b, sparse, empty, c])
+    ones = np.ones((H, W), np.uint8)
+    ctx = ffs.Context(W, H, np.uint16, max_batch=5, max_strong_per_frame=90000)
+    ctx.set_tuning(chain_runs=chain_runs)
+    ctx.set_params(want_strong_mask=1, want_strong_list=1, min_spot_size=1, max_peak_centroid_separation=3.0)
+    st = ctx.stream()
+    for rep in range(3):                  # (the first batch cannot know that it is dense; the later ones take the run-based launch)
+        res = st.process(frames, first_frame_id=10 * rep)
+        assert res[0].num_strong_pixels > 20480 and res[1].num_strong_pixels > 20480 and res[4].num_strong_pixels > 20480
+        for fr, img in zip(res, frames):
+            assert_frame_matches_oracle(fr, img, ones, min_spot_size=1, max_sep=3.0)
+    # the reference's default filters, no dense mask asked for, a masked detector
+    mask = (np.random.default_rng(9).random((H, W)) > 0.002).astype(np.uint8)
+    mask[:, 500:504] = 0
+    ctx.set_mask(mask)
+    ctx.set_params(want_strong_mask=0, want_strong_list=1, min_spot_size=3, max_peak_centroid_separation=2.0)
+    for fr, img in zip(st.process(frames), frames):
+        assert_frame_matches_oracle(fr, img, mask)
+
+
+def test_run_based_sparse_stage_overflow_falls_back(ffs):
+    """A dense frame with more runs than the run-based launch holds in LDS (isolated strong pixels: as many runs as pixels)
+    raises its flag; the batch is run again through the grid-wide kernels inside ffs_wait() and the stream keeps to them."""
+    rng = np.random.default_rng(4)
+    W, H = 640, 480
+    noisy = rng.poisson(1.0, (H, W)).astype(np.uint16)
+    noisy[rng.random((H, W)) < 0.09] += 60                      # ~27 k isolated strong pixels
+    fat = _blob_frame(W, H, 5, 520)
+    frames = np.stack([noisy, fat])
+    ones = np.ones((H, W), np.uint8)
+    ctx = ffs.Context(W, H, np.uint16, max_batch=2, max_strong_per_frame=60000)
+    ctx.set_params(want_strong_list=1, min_spot_size=1)
+    st = ctx.stream()
+    for rep in range(3):
+        res = st.process(frames)
+        assert res[0].num_strong_pixels > 20480
+        for fr, img in zip(res, frames):
+            assert_frame_matches_oracle(fr, img, ones, min_spot_size=1)
+    fat_only = np.stack([fat, fat[::-1].copy()])
+    for fr, img in zip(st.process(fat_only), fat_only):
+        assert_frame_matches_oracle(fr, img, ones, min_spot_size=1)
