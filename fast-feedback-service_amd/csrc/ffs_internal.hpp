@@ -71,7 +71,7 @@ struct Tuning {
     int ccl_grid = 32;          // workgroups per frame of the grid-wide sparse kernels
     int rows_ahead = 2;         // rows of loads a wave of the 16-bit streaming kernel keeps in flight (2, 3 or 4)
     int chain_runs = 1;         // sparse_stage 2: frames beyond the LDS forest of pixels stay in the one launch when their RUNS fit
-                                //    (16-bit pixels, rows up to 16383 pixels); 0 = such batches take the four grid-wide kernels
+                                //    (16-bit pixels, rows up to 16383 pixels); 0 = such batches take the four grid-wide kernels; 2 = runs for every frame
 #ifdef FFS_EXPERIMENTS
     struct Exp {
         int k1_debug = 0, chain_skip = 0, chain_stop = 0, dummy_us = 0, dummy_wg = 32, dummy_threads = 1024, dummy_lds = 0;

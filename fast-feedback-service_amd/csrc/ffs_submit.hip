@@ -390,12 +390,12 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
         A.t = ta;
         A.fix_bright = chain_first ? 1 : 0;
         A.fix_done = s->d_tile_counts + tile_counts_bytes(s) / 4 - 2;
-        A.runs_ok = runs_ok ? 1 : 0;
+        A.runs_ok = runs_ok ? (c->tune.chain_runs == 2 ? 2 : 1) : 0;
         {
             // the launch's start event belongs to the context (ffs_internal.hpp); published under the lock the waiting side takes
             std::lock_guard<std::mutex> lock(c->stream_mu);
             const int slot = (int)(c->chain_ev_next.fetch_add(1) % ffs_ctx::kChainEvents);
-            if (c->pixel_bytes == 2 && dense_batch && runs_ok) hipExtLaunchKernelGGL((k_frame_chain<uint16_t, true>), dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
+            if (c->pixel_bytes == 2 && runs_ok && (dense_batch || c->tune.chain_runs == 2)) hipExtLaunchKernelGGL((k_frame_chain<uint16_t, true>), dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
             else if (c->pixel_bytes == 2) hipExtLaunchKernelGGL(k_frame_chain<uint16_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
             else hipExtLaunchKernelGGL(k_frame_chain<uint32_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
             if (aside) c->chain_ev_newest.store(slot);

@@ -98,7 +98,7 @@ struct ChainArgs {
     int fix_bright;
     uint32_t* fix_done;     // workgroups through with the bright list (the last one zeroes the list's count)
     int stop_after;         // (timing experiments) 1..4: return after phase A / E / U / P
-    int runs_ok;            // frames beyond kChainLdsEntries strong pixels may take the run-based phases (16-bit pixels, W <= kChainRunMaxW)
+    int runs_ok;            // 1: frames beyond kChainLdsEntries strong pixels take the run-based phases (16-bit pixels, W <= kChainRunMaxW); 2: every frame
 };
 
 __device__ __forceinline__ void chain_record(const SegArgs& sa, uint32_t W, uint32_t num_pixels, unsigned long long sum_i,
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
     const uint32_t n = min(total, a.cap);
     const bool in_lds = n <= (uint32_t)kChainLdsEntries;
     // denser: runs instead of pixels where the frame allows it (block-uniform)
-    const bool runs = RUNS && sizeof(PixelT) == 2 && !in_lds && A.runs_ok != 0;
+    const bool runs = RUNS && sizeof(PixelT) == 2 && A.runs_ok != 0 && (!in_lds || A.runs_ok == 2);
     uint32_t run_flag = 0;   // 16: more runs than the LDS plan holds (the host runs the batch again through the grid-wide kernels)
     FFS_STOP_AFTER(A, 1);
 
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
     WireRec2* recs = reinterpret_cast<WireRec2*>(sa.recs) + (uint64_t)frame * A.rec_stride;
     uint32_t before = 0;  // components numbered so far (block-uniform)
 
-    if (in_lds) {
+    if (in_lds && !runs) {
         // every thread owns `per` consecutive list entries (<= kChainPer) through phases U, P and R
         const uint32_t per = (n + kChainThreads - 1) / kChainThreads;
         const uint32_t i0 = min((uint32_t)tid * per, n), i1 = min(i0 + per, n);

@@ -156,7 +156,8 @@ int ffs_ctx_set_params(ffs_ctx *ctx, const ffs_params *p);
  *   "sparse_stage"     (2) one launch per batch, a workgroup per frame: 3 = always, 2 = unless the stream's previous batch
  *                          held a frame with more strong pixels than that workgroup's LDS holds; 1 = four grid-wide kernels
  *   "chain_runs"       (1) with "sparse_stage" 2: such dense batches of 16-bit frames stay in the one launch, its union-find
- *                          over runs of strong pixels instead of pixels (up to 16384 runs per frame); 0 = they take the grid-wide kernels
+ *                          over runs of strong pixels instead of pixels (up to 16384 runs per frame); 0 = they take the grid-wide kernels;
+ *                          2 = every frame of 16-bit pixels goes over runs (A/B partner: no faster on sparse frames)
  *   "sched"            (3) 3 = shared dense / sparse / upload HIP streams per context, 0 = one per ffs_stream
  *                          (before the first stream is created)
  *   "direct_records"   (1) records written straight into pinned host memory (before the first stream is created)

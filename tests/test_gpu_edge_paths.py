@@ -339,7 +339,7 @@ def _blob_frame(W, H, seed, n_blobs, rmin=3, rmax=7):
     return img
 
 
-@pytest.mark.parametrize("chain_runs", [1, 0])
+@pytest.mark.parametrize("chain_runs", [1, 0, 2])
 def test_run_based_sparse_stage(ffs, chain_runs):
     """Frames beyond the LDS forest of pixels (20480) whose RUNS fit (16384): from the stream's second dense batch on the one
     launch builds its forest over runs (k_frame_chain<uint16_t, true>).  Fat spots, spots across 32-pixel word boundaries and
