@@ -158,3 +158,11 @@ def test_random_case_alternative_kernels(ffs, seed):
     """The same sweep through the paths that are not the default: bright windows marked in the plane for the exact
     kernel (both pixel widths), the one-pixel-per-lane extended first pass, the four grid-wide sparse kernels."""
     test_random_case(ffs, seed, tuning=dict(threshold_path=1, ext_first_pass=0, sparse_stage=1))
+
+
+@pytest.mark.parametrize("seed", range(1, 240, 4))
+def test_random_case_run_based_sparse_stage(ffs, seed):
+    """The same sweep with every 16-bit frame's connected components built over runs of strong pixels (tuning
+    `chain_runs` = 2: the launch dense frames take by themselves, kernels_chain.hpp): random shapes, masks, algorithms,
+    densities and filters through phases E' / U' / P' / R'."""
+    test_random_case(ffs, seed, tuning=dict(chain_runs=2))
