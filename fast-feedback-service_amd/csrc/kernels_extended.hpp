@@ -247,8 +247,88 @@ __device__ bool ext_final_strong(const ThresholdArgs& a, const uint8_t* img, con
     return global_mask && local_mask;
 }
 
+// X3 for FOUR neighbouring pixels of the signal region at once (16-bit pixels; x0 a multiple of 4, 8 <= x0, x0 + 12 <= pitch_px),
+// by the FOUR lanes of a quad (sub = lane & 3, all four active).  The region is made of fat runs, and the 11 x 11 windows of
+// a run's pixels overlap in 10 of their 11 columns: the quad loads the 11 rows of the 18 columns x0 - 8 .. x0 + 9 once
+// (lane `sub` takes rows sub, sub + 4, sub + 8: four 8-byte loads and a dword per row, all in flight together, where a pixel
+// on its own takes 11 x 6 dwords), each lane keeps the 14 column sums of the background pixels (valid and outside the
+// region) and the four windows' counts over its rows, two DPP quad exchanges add them up, and lane `sub` slides the window to
+// its pixel and takes the float64 test.  Same arithmetic as ext_final_strong (integer sums are order-independent).
+// Columns beyond the image width hold no mask bits, rows outside it are skipped: the clipping of :591-598.
+// Returns whether pixel x0 + sub is strong (callers ask only for pixels of the region).
+__device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    return v;
+}
+__device__ __forceinline__ bool ext_final_strong4(const ThresholdArgs& a, const uint8_t* img, const uint8_t* eplane, int x0, int y, int sub) {
+    const int H = a.H;
+    const int dpr = (int)(a.mpitch >> 2);
+    const int bx = x0 - 8;                         // block column 0; a multiple of 4
+    const int wb = bx >> 5, shb = bx & 31;         // (shb <= 28: the block's 20 bits lie inside two plane words)
+    const bool two = wb + 1 < dpr;
+    uint32_t c[14];                                // background sums of block columns 3 .. 16 = x0 - 5 .. x0 + 8
+#pragma unroll
+    for (int j = 0; j < 14; ++j) c[j] = 0;
+    uint32_t m2[4] = {0, 0, 0, 0};
+    uint32_t centre[2] = {0, 0};                   // the four centre pixels (block columns 8 .. 11 of row y)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int r = sub + 4 * t;                 // 0 .. 11; row 11 does not exist
+        const int yy = y - 5 + r;
+        const bool ok = r < 11 && yy >= 0 && yy < H;
+        const int yc = ok ? yy : y;
+        const uint32_t* mrow = reinterpret_cast<const uint32_t*>(a.maskbits) + (uint64_t)yc * dpr;
+        const uint32_t* erow = reinterpret_cast<const uint32_t*>(eplane) + (uint64_t)yc * dpr;
+        const unsigned long long mw = (unsigned long long)mrow[wb] | (two ? (unsigned long long)mrow[wb + 1] << 32 : 0ull);
+        const unsigned long long ew = (unsigned long long)erow[wb] | (two ? (unsigned long long)erow[wb + 1] << 32 : 0ull);
+        const uint8_t* prow = img + (uint64_t)yc * a.pitch + (uint64_t)bx * 2u;   // 8-byte aligned
+        uint32_t pw[9];                            // block columns 0 .. 17, two per word
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint2 v = *reinterpret_cast<const uint2*>(prow + 8 * q);
+            pw[2 * q] = v.x;
+            pw[2 * q + 1] = v.y;
+        }
+        pw[8] = *reinterpret_cast<const uint32_t*>(prow + 32);
+        // background for the second SAT: valid and not in the signal region (:552-571, :755)
+        const uint32_t inc = ok ? (uint32_t)((mw & ~ew) >> shb) & 0xFFFFFu : 0u;
+#pragma unroll
+        for (int j = 0; j < 14; ++j) {
+            const int k = 3 + j;
+            const uint32_t p = (k & 1) ? pw[k >> 1] >> 16 : pw[k >> 1] & 0xFFFFu;
+            c[j] += ((inc >> k) & 1u) ? p : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m2[i] += (uint32_t)__popc(inc & (0x7FFu << (3 + i)));
+        if (r == 5) { centre[0] = pw[4]; centre[1] = pw[5]; }   // (lane 1, t = 1)
+    }
+#pragma unroll
+    for (int j = 0; j < 14; ++j) c[j] = quad_sum(c[j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m2[i] = quad_sum(m2[i]);
+    centre[0] = quad_sum(centre[0]);               // (three lanes add zeros)
+    centre[1] = quad_sum(centre[1]);
+    uint32_t xs[4];
+    xs[0] = 0;
+#pragma unroll
+    for (int j = 0; j < 11; ++j) xs[0] += c[j];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) xs[i] = xs[i - 1] - c[i - 1] + c[i + 10];
+    const uint32_t x2 = sub == 0 ? xs[0] : sub == 1 ? xs[1] : sub == 2 ? xs[2] : xs[3];
+    const uint32_t m = sub == 0 ? m2[0] : sub == 1 ? m2[1] : sub == 2 ? m2[2] : m2[3];
+    const uint32_t cw = sub < 2 ? centre[0] : centre[1];
+    const uint32_t pc = (sub & 1) ? cw >> 16 : cw & 0xFFFFu;
+    if (a.ext_flavour == 1 && m == 0) return false;                     // thresholding.cu:472
+    if (a.max_valid >= 0 && (long long)pc > a.max_valid) return false;  // thresholding.cu:440-441
+    const double src = (double)pc;
+    const double mean = m >= 2 ? (double)x2 / (double)m : 0.0;          // :640
+    return src > a.threshold && src >= (mean + a.nsig_s * __builtin_sqrt(mean));
+}
+
+// (16-bit pixels: four pixels per quad of lanes, MODE 2 of the tile skeleton; 32-bit pixels: one pixel per lane)
 template <typename PixelT>
-__global__ __launch_bounds__(256) void k_ext_final(const ThresholdArgs a) { exact_tile<PixelT, 256, kExactListCap, 1>(a); }
+__global__ __launch_bounds__(256) void k_ext_final(const ThresholdArgs a) { exact_tile<PixelT, 256, kExactListCap, sizeof(PixelT) == 2 ? 2 : 1>(a); }
 template __global__ void k_ext_final<uint16_t>(const ThresholdArgs);
 template __global__ void k_ext_final<uint32_t>(const ThresholdArgs);
 

@@ -121,10 +121,13 @@ __device__ bool exact_strong(const ThresholdArgs& a, const uint8_t* img, int x, 
 // extended algorithm's final test (kernels_extended.hpp)
 template <typename PixelT>
 __device__ bool ext_final_strong(const ThresholdArgs& a, const uint8_t* img, const uint8_t* eplane, int x, int y);
+__device__ __forceinline__ bool ext_final_strong4(const ThresholdArgs& a, const uint8_t* img, const uint8_t* eplane, int x0, int y, int sub);
 
 // MODE 0: candidates come from (and strong pixels go back to) a.bits, predicate exact_strong.
 // MODE 1: extended algorithm -- candidates are the signal-region plane a.eplane (read-only: other
 //         tiles read it for their 11x11 windows), predicate ext_final_strong, result in a.bits.
+// MODE 2: the same with a list entry per aligned group of FOUR pixels that holds a candidate (16-bit pixels,
+//         ext_final_strong4: the four windows share their loads and column sums).
 template <typename PixelT, int NT, int LISTCAP, int MODE = 0>
 __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
     // The stage is latency-bound (sparse gathers).  Measured dead ends: a smaller LDS footprint
@@ -142,16 +145,18 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
     const uint8_t* img = (const uint8_t*)a.image + (uint64_t)frame * a.frame_stride;
     uint32_t* gwords = reinterpret_cast<uint32_t*>(a.bits + (uint64_t)frame * a.plane_frame_stride
                                                    + (uint64_t)y0 * a.mpitch);
-    const uint8_t* eframe = MODE == 1 ? a.eplane + (uint64_t)frame * a.plane_frame_stride : nullptr;
-    const uint32_t* gin = MODE == 1 ? reinterpret_cast<const uint32_t*>(eframe + (uint64_t)y0 * a.mpitch) : gwords;
+    const uint8_t* eframe = MODE >= 1 ? a.eplane + (uint64_t)frame * a.plane_frame_stride : nullptr;
+    const uint32_t* gin = MODE >= 1 ? reinterpret_cast<const uint32_t*>(eframe + (uint64_t)y0 * a.mpitch) : gwords;
     uint8_t* sbytes = a.strong_bytes + (uint64_t)frame * a.bytes_frame_stride;
 
     if (tid == 0) { s_cnt = 0; s_total = 0; s_strong = 0; }
+    // what a list entry stands for: a candidate pixel, or (MODE 2) the first bit of a group of four that holds one
+    auto entries = [](uint32_t w) -> uint32_t { return MODE == 2 ? (w | (w >> 1) | (w >> 2) | (w >> 3)) & 0x11111111u : w; };
     uint32_t mine = 0;
     for (int g = tid; g < ndw; g += NT) {
         const uint32_t w = gin[g];
         s_words[g] = w;
-        mine += __popc(w);
+        mine += __popc(entries(w));
     }
     __syncthreads();
     if (mine) atomicAdd(&s_total, mine);
@@ -159,7 +164,7 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
     const uint32_t total = s_total;  // block-uniform
     if (total == 0) {
         if (tid == 0) a.tile_counts[(uint64_t)frame * a.n_tiles + tile] = 0;
-        if constexpr (MODE == 1)
+        if constexpr (MODE >= 1)
             for (int g = tid; g < ndw; g += NT) gwords[g] = 0;
         return;
     }
@@ -173,6 +178,26 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
     };
     auto flush = [&]() {
         const uint32_t n = s_cnt;
+        if constexpr (MODE == 2) {
+            // an entry = an aligned group of four pixels, taken by a quad of lanes (whole quads are in or out of the loop)
+            const int sub = tid & 3;
+            for (uint32_t e = (uint32_t)tid >> 2; e < n; e += NT / 4) {
+                const uint32_t idx = s_list[e];
+                const uint32_t g = idx >> 5, bit = idx & 31u;
+                const int row = g / dpr;
+                const int x = (int)((g - row * dpr) * 32u + bit);
+                const int y = y0 + row;
+                const bool want = (s_words[g] >> (bit + (uint32_t)sub)) & 1u;   // (only this lane ever changes this bit)
+                bool strong;
+                if (x >= 8 && x + 12 <= a.pitch_px) strong = ext_final_strong4(a, img, eframe, x, y, sub);   // (quad-uniform branch)
+                else strong = want && ext_final_strong<PixelT>(a, img, eframe, x + sub, y);                   // next to the frame's left or right edge
+                if (want) {
+                    if (strong) sbytes[(uint64_t)y * a.bpitch + x + sub] = 1;
+                    else atomicAnd(&s_words[g], ~(1u << (bit + (uint32_t)sub)));
+                }
+            }
+            return;
+        }
         for (uint32_t e = tid; e < n; e += NT) {
             const uint32_t idx = s_list[e];
             const uint32_t g = idx >> 5, bit = idx & 31u;
@@ -195,7 +220,7 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
         if (mine) {
             uint32_t at = atomicAdd(&s_cnt, mine);
             for (int g = tid; g < ndw; g += NT) {
-                const uint32_t w = s_words[g];
+                const uint32_t w = entries(s_words[g]);
                 append(g, w, at);
                 at += __popc(w);
             }
@@ -206,7 +231,7 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
         // dense tile: 64 words (<= 2048 candidates) at a time
         for (int pos = 0; pos < ndw; pos += LISTCAP / 32) {
             const int g = pos + tid;
-            const uint32_t w = (tid < LISTCAP / 32 && g < ndw) ? s_words[g] : 0u;
+            const uint32_t w = (tid < LISTCAP / 32 && g < ndw) ? entries(s_words[g]) : 0u;
             if (w) append(g, w, atomicAdd(&s_cnt, (uint32_t)__popc(w)));
             __syncthreads();
             flush();
@@ -222,7 +247,7 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
         const uint32_t w = s_words[g];
         gwords[g] = w;
         cnt += __popc(w);
-        if constexpr (MODE == 1) {
+        if constexpr (MODE >= 1) {
             // the extended algorithm's final plane: its occupancy bitmap (one bit per 16-byte segment of a plane row) lets the
             // sparse stage read only the segments that hold something, as after the streaming kernels
             if (w) {
