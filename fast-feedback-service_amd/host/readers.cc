@@ -11,6 +11,9 @@
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "codecs.hpp"
 #include "ffs_synth.h"
@@ -226,6 +229,34 @@ class SHMRead : public Reader {
         const int fd = ::open(image_path(index).c_str(), O_RDONLY);
         if (fd < 0) return {dst.data(), 0};
         size_t got = 0;
+#if defined(__x86_64__)
+        // The destination is the driver's pinned staging area, which the GPU's DMA engine reads next: the chunk goes through
+        // a cache-resident bounce buffer and on with non-temporal stores, so that it lands in DRAM and neither fills this
+        // core's cache with lines the DMA then has to pull out of it nor evicts the bounce buffer (tools/ubench/shm_read.cc
+        // modes 5 / 7: the DMA beside eight such readers keeps 56 GB/s, beside read() into the area itself 40-46).
+        if (stream_copy_ && (reinterpret_cast<uintptr_t>(dst.data()) & 31u) == 0) {
+            constexpr size_t kBounce = 256u << 10;
+            static thread_local std::unique_ptr<uint8_t[]> bounce_store(new uint8_t[kBounce + 64]);
+            uint8_t* bounce = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(bounce_store.get()) + 63) & ~(uintptr_t)63);
+            while (got < dst.size()) {
+                const ssize_t r = ::read(fd, bounce, std::min(kBounce, dst.size() - got));
+                if (r <= 0) break;
+                stream_copy(dst.data() + got, bounce, (size_t)r);
+                got += (size_t)r;
+                if (((size_t)r & 31u) != 0) break;   // (a short read ends the file: the next piece would start unaligned)
+            }
+            _mm_sfence();
+            if (got < dst.size() && (got & 31u) != 0) {   // anything after an odd-sized piece (never for a whole file: EOF follows)
+                for (;;) {
+                    const ssize_t r = ::read(fd, dst.data() + got, dst.size() - got);
+                    if (r <= 0) break;
+                    got += (size_t)r;
+                }
+            }
+            ::close(fd);
+            return {dst.data(), got};
+        }
+#endif
         while (got < dst.size()) {
             const ssize_t r = ::read(fd, dst.data() + got, dst.size() - got);
             if (r <= 0) break;
@@ -234,6 +265,15 @@ class SHMRead : public Reader {
         ::close(fd);
         return {dst.data(), got};
     }
+#if defined(__x86_64__)
+    __attribute__((target("avx2"))) static void stream_copy(uint8_t* d, const uint8_t* s, size_t n) {   // d 32-byte aligned
+        const size_t whole = n & ~(size_t)31;
+        for (size_t o = 0; o < whole; o += 32)
+            _mm256_stream_si256(reinterpret_cast<__m256i*>(d + o), _mm256_load_si256(reinterpret_cast<const __m256i*>(s + o)));
+        if (n != whole) std::memcpy(d + whole, s + whole, n - whole);
+    }
+    const bool stream_copy_ = __builtin_cpu_supports("avx2") && std::getenv("FFS_SHM_PLAIN_READ") == nullptr;
+#endif
     bool reentrant() const override { return true; }  // one file per frame
     ChunkCompression get_raw_chunk_compression() override { return BITSHUFFLE_LZ4; }
     h5read_dtype get_dtype() const override { return dtype_; }

@@ -12,16 +12,20 @@ from ffs_amd import api
 print("GPU 0 NUMA node:", api.device_numa_node(0))
 PY
 $B/ffs_hosttool mkshm synth:eiger16m:32 $T/shm > /dev/null
-cd $T/shm; for i in $(seq 32 999); do cp image_$(printf %06d $((i%32)))_2 image_$(printf %06d $i)_2; done
-sed -i "s/\"nimages\": 32/\"nimages\": 1000/" start_1
+N=${N:-1000}
+cd $T/shm; for i in $(seq 32 $((N-1))); do cp image_$(printf %06d $((i%32)))_2 image_$(printf %06d $i)_2; done
+sed -i "s/\"nimages\": 32/\"nimages\": $N/" start_1
 cd $T
 thr() { grep -E "nr_throttled|throttled_usec" /sys/fs/cgroup/cpu.stat 2>/dev/null | tr '\n' ' '; }
 run() { local t0="$(thr)"; $B/spotfinder $T/shm --threads 8 --batch 4 -v "$@" > $T/out.txt 2> $T/err.txt
-  echo "== 8 x 4 $*: $(grep -E 'images in' $T/out.txt | sed 's/\x1b\[[0-9;]*m//g')"; grep "batches; reading" $T/out.txt | sed -n '1,2p'; grep -E "CPU time|Workers joined|3D finish|3D analysis in all" $T/out.txt; echo "   cpu.stat before: $t0 after: $(thr)"; }
+  echo "== 8 x 4 $* ${FFS_SHM_PLAIN_READ:+(plain read)}: $(grep -E 'images in' $T/out.txt | sed 's/\x1b\[[0-9;]*m//g')"; grep "batches; reading" $T/out.txt | sed -n '1,2p'; grep -E "CPU time|Workers joined|3D finish|3D analysis in all" $T/out.txt; echo "   cpu.stat before: $t0 after: $(thr)"; }
 run
-run
-run
+for k in 1 2 3; do
+  export FFS_SHM_PLAIN_READ=1; run
+  unset FFS_SHM_PLAIN_READ; run
+done
 run --threads 12 --all-threads
+run --threads 16 --all-threads
 ps -eLo pid,tid,pcpu,comm 2>/dev/null | sort -k3 -n -r | sed -n '1,5p'
-$GRAFT_REPO_ROOT/tools/ubench/shm_read $T/shm 1000 | grep -E "registered +(4|8) threads|DMA +(4|8) threads"
+[ -z "$SKIP_UBENCH" ] && $GRAFT_REPO_ROOT/tools/ubench/shm_read $T/shm 1000 | grep -E "registered +(4|8) threads|DMA +(4|8) threads"
 rm -rf $T
