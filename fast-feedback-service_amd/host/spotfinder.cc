@@ -69,12 +69,15 @@ static void usage() {
       "                  [--min-spot-size-3d N] [--max-peak-centroid-separation N] [--start-index N]\n"
       "                  [-t S] [-fd FD] [-a ALGO] [--dmin MIN D] [--dmax MAX D] [-w \xce\xbb] [--detector JSON]\n"
       "                  [-h5] [--output-for-index] [--batch N] [--cpu-decode] [--strict-dtype]\n"
-      "                  [--devices D0,D1,... | --gpus N] [--no-numa-pinning] [--single-buffer] [--all-threads]\n"
+      "                  [--devices D0,D1,... | --gpus N] [--no-numa-pinning] [--single-buffer] [--all-threads] [--read-only]\n"
       "--devices / --gpus: one context and worker pool per GPU, all pulling frames from the one queue\n"
       "              (-n threads are dealt round-robin to the GPUs, at least one each); rotation sweeps send\n"
       "              their strong-pixel lists to the first GPU's 3D stack (RCCL over xGMI, else peer copies)\n"
       "--all-threads: every one of the -n threads feeds the GPU (default: at most eight per GPU when chunks are decoded there)\n"
       "--single-buffer: one batch per worker at a time (default: two, the next is read while the first is on the GPU)\n"
+      "--read-only: (diagnostic) read every chunk into the staging areas and submit nothing\n"
+      "environment, A/B only: FFS_SHM_PLAIN_READ=1 -- /dev/shm chunks by read() straight into the staging area instead of\n"
+      "              through a cache-resident bounce buffer and non-temporal stores\n"
       "--cpu-decode: decompress bitshuffle-LZ4 chunks on the worker thread (the reference's way) instead\n"
       "              of sending them to the GPU as they are\n"
       "FILE: NXmx .nxs/.h5 (needs an HDF5 build), a /dev/shm directory, a ####.cbf template, or\n"
