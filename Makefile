@@ -41,7 +41,7 @@ experiments:
 	$(MAKE) -j5 $(PKG)/libffs_hip_exp.so
 $(PKG)/csrc/obj/%.exp.o: $(PKG)/csrc/%.hip $(HIP_HDRS)
 	@mkdir -p $(PKG)/csrc/obj
-	$(HIPCC) $(HIPFLAGS) -DFFS_EXPERIMENTS -c -o $@ $<
+	$(HIPCC) $(HIPFLAGS) -DFFS_EXPERIMENTS $(EXPFLAGS) -c -o $@ $<
 $(PKG)/libffs_hip_exp.so: $(EXP_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(EXP_OBJS)
 

@@ -401,6 +401,11 @@ int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uint32_t m
         s->d_acc2 = reinterpret_cast<CompAcc2*>(base + o_acc);
         s->d_chunk_roots = reinterpret_cast<uint32_t*>(base + o_roots);
         s->d_recs = reinterpret_cast<ReflOut*>(base + o_recs);
+#ifdef FFS_EXPERIMENTS
+        if (std::getenv("FFS_EXP_PRINT_ADDR"))   // (kernel time follows where the buffers lie: see DESIGN.md section 3.2)
+            std::fprintf(stderr, "ffs addresses: maskbits %p ginfo %p mmap %p | slab %p (%zu MB) bits %p counts %p occ %p bright %p\n", (void*)c->d_maskbits,
+                         (void*)c->d_ginfo, (void*)c->d_mmap, (void*)base, at >> 20, (void*)s->d_bits, (void*)s->d_tile_counts, (void*)s->d_occ, (void*)s->d_bright);
+#endif
     }
     // (the pinned staging area for frames / chunks is allocated on first use: ensure_host_staging)
     STREAM_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), (B * 11 + 1) * 4, hipHostMallocDefault));  // (+ [B] per-frame flags, k_frame_chain)

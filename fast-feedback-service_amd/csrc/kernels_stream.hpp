@@ -39,6 +39,11 @@
 #pragma once
 #include "kernels_threshold.hpp"
 
+// cache policy of the pixel loads of the streaming kernels (raw buffer load `aux`: 0 = default, 2 = non-temporal)
+#ifndef FFS_IMG_LOAD_AUX
+#define FFS_IMG_LOAD_AUX 0
+#endif
+
 namespace ffsamd {
 
 constexpr int kSQWords = 32;         // queue entry: 0-7 window sums, 8-11 centre pixels (two per word), 12-13 window counts,
@@ -236,9 +241,9 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
         const int yin = yb0 - 3 + i;
         const uint32_t prow = (uint32_t)min(max(yin, 0), a.H - 1);
         const uint32_t irow = (uint32_t)min(max(yin, 0), a.H + kInfoExtraRows - 1);
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_img, off_px, prow * a.pitch, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_img, off_px, prow * a.pitch, FFS_IMG_LOAD_AUX);
         ring[slot][0] = v[0]; ring[slot][1] = v[1]; ring[slot][2] = v[2]; ring[slot][3] = v[3];
-        rinfo[slot] = __builtin_amdgcn_raw_buffer_load_b32(r_info, off_info | (yin < 0 ? kOob : 0u), irow * a.gpitch, 0);
+        rinfo[slot] = __builtin_amdgcn_raw_buffer_load_b32(r_info, off_info | (yin < 0 ? kOob : 0u), (FFS_DBG(a, 64) ? 8u : irow) * a.gpitch, 0);   // (bit 64: every row reads table row 8 -- what the table's traffic costs)
     };
 
     // the incoming row's four registers of two pixels each, masked in place
@@ -430,8 +435,8 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
         if (have) {
             const uint32_t cb = s_q[14][lane];
             if (cb) {  // the plane is all zero when the kernel starts (the compaction clears what it consumed)
-                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)cb, r_cb, (uint32_t)((uint64_t)fe * a.plane_frame_stride) + ge, row * a.mpitch, 0);
-                if constexpr (!EXT) {  // (the extended algorithm's final pass counts its own strong pixels)
+                if (!FFS_DBG(a, 256)) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)cb, r_cb, (uint32_t)((uint64_t)fe * a.plane_frame_stride) + ge, row * a.mpitch, 0);
+                if constexpr (!EXT) if (!FFS_DBG(a, 128)) {  // (the extended algorithm's final pass counts its own strong pixels)
                     atomicAdd(a.tile_counts + (uint64_t)(f0 + (int)fe) * a.n_tiles + (row / (uint32_t)kTileRows), (uint32_t)__popc(cb));
                     const uint32_t ob = row * a.occ_spr + (ge >> 4);   // the 16-byte segment of the plane row this byte lies in
                     atomicOr(a.occ + (uint64_t)(f0 + (int)fe) * a.occ_frame_words + (ob >> 5), 1u << (ob & 31u));
@@ -673,7 +678,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
         const int yin = yb0 - 3 + i;
         const uint32_t prow = (uint32_t)min(max(yin, 0), a.H - 1);
         const uint32_t irow = (uint32_t)min(max(yin, 0), a.H + kInfoExtraRows - 1);
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_img, off_px, prow * a.pitch, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_img, off_px, prow * a.pitch, FFS_IMG_LOAD_AUX);
         ring[slot][0] = v[0]; ring[slot][1] = v[1]; ring[slot][2] = v[2]; ring[slot][3] = v[3];
         rinfo[slot] = __builtin_amdgcn_raw_buffer_load_b32(r_info, off_info | (yin < 0 ? kOob : 0u), irow * a.gpitch, 0);
     };

@@ -23,7 +23,9 @@ def main():
     ap.add_argument("--workload", default="eiger16m")
     ap.add_argument("--paths", default="0", help="comma list of tuning threshold_path values to A/B (0 = bright list, 1 = bright plane + exact kernel)")
     ap.add_argument("--exp", default="", help="comma list of FFS_EXP_K1_DEBUG values (experiments build only: FFS_HIP_LIB=.../libffs_hip_exp.so); "
-                                              "1 = no group ever flagged, 2 = drains do nothing, 4 = no exact predicate, 8/16 = dense mask off/on")
+                                              "1 = no group ever flagged, 2 = drains do nothing, 4 = no exact predicate, 8/16 = dense mask off/on, 32 = queue not written, "
+                                              "64 = every row reads one row of the mask table, 128 = no tile-count / occupancy atomics, 256 = no plane byte stores; "
+                                              "a value may be repeated: one context each (kernel time follows where a context's buffers lie)")
     ap.add_argument("--dense", action="store_true", help="ask for the dense byte mask (want_strong_mask)")
     ap.add_argument("--tune", default="", help="A/B over tuning sets, ';'-separated, each 'key=value,key=value' (ffs_ctx_set_tuning), e.g. "
                                                "'rows_ahead=2;rows_ahead=3;rows_ahead=4'")
@@ -49,10 +51,12 @@ def main():
     for i in range(B):
         host[i, :, :W] = frames[i % len(frames)]
     d = torch.from_numpy(host.view(np.uint8).reshape(-1)).cuda()
+    print(f"image buffer at {d.data_ptr():#x}", flush=True)
     alg = float(W) * H * bpp * B
     variants = [("path", int(v)) for v in args.paths.split(",")] if not args.exp else [("exp", int(v)) for v in args.exp.split(",")]
     if args.tune:
         variants = [("tune", t) for t in args.tune.split(";")]
+    variants = [(k, v, i) for i, (k, v) in enumerate(variants)]   # (a value may be given several times: one context each)
     if args.decode:
         from ffs_amd import bslz4
         st = ctx.stream()
@@ -65,7 +69,7 @@ def main():
         del st
     # one context (and stream) per variant: tuning is per context, the experiment switches are read when a context is created
     streams = {}
-    for kind, v in variants:
+    for kind, v, idx in variants:
         if kind == "exp":
             os.environ["FFS_EXP_K1_DEBUG"] = str(v)
         c = make_ctx()
@@ -73,11 +77,11 @@ def main():
             c.set_tuning(threshold_path=v)
         if kind == "tune":
             c.set_tuning(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in v.split(",") if kv})
-        streams[(kind, v)] = (c, c.stream())
+        streams[(kind, v, idx)] = (c, c.stream())
     for rnd in range(args.rounds):          # interleaved A/B rounds in one process
         for key in variants:
             a, b = streams[key][1].bench_threshold(d.data_ptr(), pitch, fstride, B, args.iters)
-            print(f"round {rnd} {key[0]} {key[1]}: dense kernel {a*1e3:.1f} us/launch ({alg/a/1e6:.0f} GB/s algorithmic, "
+            print(f"round {rnd} {key[0]} {key[1]} #{key[2]}: dense kernel {a*1e3:.1f} us/launch ({alg/a/1e6:.0f} GB/s algorithmic, "
                   f"{alg/a/1e6/8000:.3f} of 8 TB/s), rest of the stage {b*1e3:.1f} us/launch, batch {B}", flush=True)
 
 
