@@ -140,9 +140,11 @@ __global__ __launch_bounds__(256) void k_ext_erode(const ThresholdArgs a) {
     if (t >= dpr * n_bands) return;
     const int w = t % dpr, band = t / dpr;
     const int y0 = band * kErodeRows, y1 = min(y0 + kErodeRows, a.H);
-    const uint32_t* dp = reinterpret_cast<const uint32_t*>(a.dplane + (uint64_t)frame * a.plane_frame_stride);
-    const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.maskbits);
-    uint32_t* ep = reinterpret_cast<uint32_t*>(a.eplane + (uint64_t)frame * a.plane_frame_stride);
+    // (__restrict__: the eroded plane is another buffer, so the loads of the next rows may pass the stores of this one --
+    // with the loop unrolled eight times a lane has eight rows of loads in flight instead of one)
+    const uint32_t* __restrict__ dp = reinterpret_cast<const uint32_t*>(a.dplane + (uint64_t)frame * a.plane_frame_stride);
+    const uint32_t* __restrict__ mp = reinterpret_cast<const uint32_t*>(a.maskbits);
+    uint32_t* __restrict__ ep = reinterpret_cast<uint32_t*>(a.eplane + (uint64_t)frame * a.plane_frame_stride);
     // bits of this word column that lie beyond the image width: they never erode anything
     const int x0 = w * 32;
     const uint32_t beyond_c = x0 + 32 > a.W ? (x0 >= a.W ? ~0u : ~((1u << (a.W - x0)) - 1u)) : 0u;
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(256) void k_ext_erode(const ThresholdArgs a) {
     h1 = hrow(y0 - 1, dummy);
     h2 = hrow(y0, c2);
     h3 = hrow(y0 + 1, c3);
+#pragma unroll 8
     for (int y = y0; y < y1; ++y) {
         h4 = hrow(y + 2, c4);
         ep[(uint64_t)y * dpr + w] = c2 & h0 & h1 & h2 & h3 & h4;
