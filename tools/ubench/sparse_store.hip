@@ -50,16 +50,20 @@ int main() {
             }
             if (round) printf("round %d slab %2d at %p: reads only %.1f us, with 576 k byte stores %.1f us (+%.1f)\n", round, i, (void*)slabs[i], ms[0] * 100, ms[1] * 100, (ms[1] - ms[0]) * 100);
         }
-    // the span of the stores: a slow region stays slow down to which size?  (pages of the translation, or the memory behind them)
-    for (int i = 0; i < N; ++i)
-        for (size_t span : {plane_bytes, (size_t)16 << 20, (size_t)2 << 20, (size_t)256 << 10, (size_t)16 << 10}) {
-            float ms;
+    // small allocations: do consecutive 80 MB buffers (what a stream's sparse-write buffers would be on their own) share the state?
+    for (int i = 0; i < N; ++i) hipFree(slabs[i]);
+    std::vector<uint8_t*> small(96);
+    for (auto& p : small) { hipMalloc(&p, (size_t)80 << 20); hipMemset(p, 0, (size_t)80 << 20); }
+    for (size_t i = 0; i < small.size(); ++i) {
+        float ms;
+        for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
             for (int r = 0; r < 10; ++r)
-                hipLaunchKernelGGL(k_stores, dim3(15064), dim3(64), 0, 0, img, img_bytes / 16, slabs[i] + img_bytes, span, sink, 13, 1, 0);
+                hipLaunchKernelGGL(k_stores, dim3(15064), dim3(64), 0, 0, img, img_bytes / 16, small[i], plane_bytes, sink, 13, 1, 0);
             hipEventRecord(e1); hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1);
-            printf("slab %2d, stores within %6zu KB: %.1f us\n", i, span >> 10, ms * 100);
         }
+        printf("small %2zu at %p: %.1f us\n", i, (void*)small[i], ms * 100);
+    }
     return 0;
 }
