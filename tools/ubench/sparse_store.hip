@@ -30,6 +30,13 @@ __global__ __launch_bounds__(64, 4) void k_stores(const uint4* __restrict__ img,
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
+__global__ __launch_bounds__(64) void k_stores_only(uint8_t* plane, size_t plane_bytes, int per_lane) {
+    uint32_t rng = (uint32_t)(blockIdx.x * 2654435761u) ^ (uint32_t)threadIdx.x * 40503u;
+    for (int k = 0; k < per_lane; ++k) {
+        rng = rng * 1664525u + 1013904223u;
+        plane[(size_t)(rng % (uint32_t)plane_bytes)] = (uint8_t)(rng | 1u);
+    }
+}
 int main() {
     const size_t img_bytes = (size_t)32 * 4362 * 8320, plane_bytes = (size_t)32 * 4362 * 528, slab = (size_t)2330 << 20;
     uint4* img; uint32_t* sink;
@@ -63,7 +70,12 @@ int main() {
             hipEventRecord(e1); hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1);
         }
-        printf("small %2zu at %p: %.1f us\n", i, (void*)small[i], ms * 100);
+        float ms2;
+        hipEventRecord(e0);
+        for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(k_stores_only, dim3(1024), dim3(64), 0, 0, small[i], plane_bytes, 9);   // 590 k stores
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms2, e0, e1);
+        printf("small %2zu at %p: %.1f us beside the read, %.1f us stores alone\n", i, (void*)small[i], ms * 100, ms2 * 100);
     }
     return 0;
 }
