@@ -266,6 +266,7 @@ extern "C" int ffs_ctx_set_tuning(ffs_ctx* c, const char* key, long long value) 
     if (k == "threshold_path") { if ((ok = in(0, 1))) t.threshold_path = (int)value; }
     else if (k == "ext_first_pass") { if ((ok = value == 0 || value == 2)) t.ext_first_pass = (int)value; }
     else if (k == "sparse_stage") { if ((ok = in(1, 3))) t.sparse_stage = (int)value; }
+    else if (k == "strong_log") { if ((ok = in(0, 1))) t.strong_log = (int)value; }
     else if (k == "chain_runs") { if ((ok = in(0, 2))) t.chain_runs = (int)value; }
     else if (k == "sched") { if ((ok = (value == 0 || value == 3) && c->n_streams_made == 0)) t.sched = (int)value; }
     else if (k == "chain_first") { if ((ok = in(0, 64))) t.chain_first = (int)value; }
@@ -303,7 +304,7 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     // (d_n_comp, d_summary and d_overflow live inside the d_num_strong allocation)
     if (s->h_pack_tab) (void)hipHostFree(s->h_pack_tab);
     // (the stream's device buffers are one slab; what is allocated on first use is freed by itself)
-    void* dev[] = {s->d_slab, s->d_pack_k, s->d_pack_i, s->d_pack_tab, s->d_comp, s->d_tab, s->d_dplane, s->d_eplane};
+    void* dev[] = {s->d_slab, s->d_pack_k, s->d_pack_i, s->d_pack_tab, s->d_comp, s->d_tab, s->d_dplane, s->d_eplane, s->d_wlog, s->d_wlog_n};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     void* host[] = {s->h_tab, s->h_counts, s->h_recs, s->h_list_k, s->h_list_i, s->h_mask};

@@ -41,6 +41,7 @@ constexpr int kSOwned = 62;
 constexpr int kInfoExtraRows = 3;    // ginfo row y carries the mask bits of row y and the window counts of row y - 3
 
 // Exact-stage tiles: one 256-thread workgroup per 8 rows.
+constexpr int kWlogCap = 256;        // entries of a wave's log (a wave of the bench frames writes ~40)
 constexpr int kTileRows = 8;
 constexpr int kExactListCap = 2048;  // candidate entries staged in LDS per flush
 
@@ -93,6 +94,11 @@ struct ThresholdArgs {
     uint32_t occ_frame_words;  // words per frame = ceil(H * occ_spr / 32)
     uint32_t occ_spr;          // segments per plane row = mpitch / 16
     int dense_mask;            // the streaming kernels zero-fill the byte mask (somebody wants it); else they leave it alone
+    // wave logs (tuning "strong_log", 16-bit standard path): instead of scattering plane bytes, counter and occupancy atomics
+    // and bright-list entries over the stream's buffers, every wave appends one 8-byte entry per group that holds a strong
+    // (or undecided) pixel to its own log -- dense stores; kernels_chain.hpp merges the logs of a frame
+    uint2* wlog;               // [waves][kWlogCap] (row << 16 | group, frame in super row << 16 | undecided << 8 | strong); nullptr: off
+    uint32_t* wlog_n;          // [waves] entries a wave wanted to write (more than kWlogCap: overflow)
     int dbg;                   // timing experiments (-DFFS_EXPERIMENTS builds only; results are wrong when set)
 };
 

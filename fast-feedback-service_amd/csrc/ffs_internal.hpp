@@ -70,6 +70,9 @@ struct Tuning {
     int decode_in_dense_stream = 1;   // the decode kernel runs in the dense kernels' stream (0: in the upload stream)
     int ccl_grid = 32;          // workgroups per frame of the grid-wide sparse kernels
     int rows_ahead = 2;         // rows of loads a wave of the 16-bit streaming kernel keeps in flight (2, 3 or 4)
+    int strong_log = 1;         // 16-bit standard path: the streaming kernel appends its strong groups to per-wave logs and the one-launch sparse
+                                //    stage merges them (kernels_chain.hpp, LOG) instead of scattering plane bytes, counters and occupancy bits;
+                                //    0 = the bit plane (also what dense frames, tall frames and the other algorithms and paths take)
     int chain_runs = 1;         // sparse_stage 2: frames beyond the LDS forest of pixels stay in the one launch when their RUNS fit
                                 //    (16-bit pixels, rows up to 16383 pixels); 0 = such batches take the four grid-wide kernels; 2 = runs for every frame
 #ifdef FFS_EXPERIMENTS
@@ -140,6 +143,10 @@ struct ffs_stream {
     ffs_stream* big = nullptr;               // one-frame stream with room for frames that exceed cap / max_comp
     std::vector<OverflowFrame> ovf;          // such frames of the last batch, re-run on `big`
     int force_path = -1;                     // >= 0: threshold path of the next enqueue (bright-list overflow -> 1)
+    bool log_off = false;                    // the wave logs could not serve a batch of this stream (dense frames, a log overflow): the plane from then on
+    uint2* d_wlog = nullptr;                 // wave logs of the streaming kernel (allocated on first use, sized for the launch geometry)
+    uint32_t* d_wlog_n = nullptr;
+    size_t wlog_waves = 0;
     bool force_grid = false;                 // the next enqueue takes the grid-wide sparse kernels (a frame's runs overflowed the one launch)
     bool runs_overflowed = false;            // ... and dense batches of this stream keep taking them
     uint32_t *d_pack_k = nullptr, *d_pack_i = nullptr;  // a batch's lists packed end to end for another device's 3D stack

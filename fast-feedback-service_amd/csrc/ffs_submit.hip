@@ -16,8 +16,9 @@ bool chain_prepare_device() {   // more than 64 KB of dynamic LDS has to be aske
     const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
     const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
     const hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
+    const hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint16_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
     (void)hipGetLastError();
-    return e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess;
+    return e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && e4 == hipSuccess;
 }
 
 ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t pitch, size_t fstride, uint32_t n_frames) {
@@ -277,6 +278,23 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
         if (dense_batch && !runs_ok) will_chain = false;
     }
     if (s->force_grid) will_chain = false;
+    // Wave logs instead of the plane (tuning "strong_log"): the standard 16-bit path, sparse stage in the one launch, frames
+    // that fit its LDS forest.  The streaming kernel then leaves plane, counters, occupancy bitmap and bright list alone.
+    bool use_log = c->tune.strong_log != 0 && c->pixel_bytes == 2 && list_path && will_chain && !dense_batch && !s->log_off
+                   && s->st2 != s->st && (uint32_t)ta.gpf / (uint32_t)kSOwned + 2u <= 12u && ta.band_rows <= 1024 && L.W <= 65535 && L.H <= 65535;
+    if (use_log) {
+        const dim3 g = stream_grid(ta, n);
+        const size_t waves = (size_t)g.x * g.y;
+        if (waves > s->wlog_waves) {
+            if (s->d_wlog) { (void)hipStreamSynchronize(s->st); (void)hipStreamSynchronize(s->st2); (void)hipFree(s->d_wlog); (void)hipFree(s->d_wlog_n); s->d_wlog = nullptr; s->d_wlog_n = nullptr; }
+            s->wlog_waves = 0;
+            if (hipMalloc(reinterpret_cast<void**>(&s->d_wlog), waves * kWlogCap * sizeof(uint2)) == hipSuccess
+                && hipMalloc(reinterpret_cast<void**>(&s->d_wlog_n), waves * 4) == hipSuccess) s->wlog_waves = waves;
+            else { (void)hipGetLastError(); use_log = false; }
+        }
+    }
+    ThresholdArgs ta_launch = ta;
+    if (use_log) { ta_launch.wlog = s->d_wlog; ta_launch.wlog_n = s->d_wlog_n; }
 #ifdef FFS_EXPERIMENTS
     if (c->tune.exp.chain_skip) will_chain = false;
 #endif
@@ -302,10 +320,11 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
         HIP_TRY(c, hipEventRecord(s->ev[2], s->st));
         if (s->st2 != s->st) HIP_TRY(c, hipStreamWaitEvent(s->st2, s->ev[2], 0));
     } else if (list_path && aside) {
-        // the bright-window fix-up goes to the sparse stream (or into the sparse launch itself: chain_first)
-        launch_stream(s, ta, n, ev_start, s->ev[2]);
+        // the bright-window fix-up goes to the sparse stream (or into the sparse launch itself: chain_first; with wave logs the
+        // sparse launch decides those pixels as it reads the logs)
+        launch_stream(s, ta_launch, n, ev_start, s->ev[2]);
         HIP_TRY(c, hipStreamWaitEvent(s->st2, s->ev[2], 0));
-        if (!chain_first) launch_bright_fix(s, ta, s->st2);
+        if (!chain_first && !use_log) launch_bright_fix(s, ta, s->st2);
     } else {
         launch_stream(s, ta, n, ev_start, nullptr);
         if (list_path) launch_bright_fix(s, ta, s->st);
@@ -387,15 +406,16 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
 #ifdef FFS_EXPERIMENTS
         A.stop_after = c->tune.exp.chain_stop;
 #endif
-        A.t = ta;
-        A.fix_bright = chain_first ? 1 : 0;
+        A.t = ta_launch;
+        A.fix_bright = (chain_first && !use_log) ? 1 : 0;
         A.fix_done = s->d_tile_counts + tile_counts_bytes(s) / 4 - 2;
         A.runs_ok = runs_ok ? (c->tune.chain_runs == 2 ? 2 : 1) : 0;
         {
             // the launch's start event belongs to the context (ffs_internal.hpp); published under the lock the waiting side takes
             std::lock_guard<std::mutex> lock(c->stream_mu);
             const int slot = (int)(c->chain_ev_next.fetch_add(1) % ffs_ctx::kChainEvents);
-            if (c->pixel_bytes == 2 && runs_ok && (dense_batch || c->tune.chain_runs == 2)) hipExtLaunchKernelGGL((k_frame_chain<uint16_t, true>), dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
+            if (use_log) hipExtLaunchKernelGGL((k_frame_chain<uint16_t, false, true>), dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
+            else if (c->pixel_bytes == 2 && runs_ok && (dense_batch || c->tune.chain_runs == 2)) hipExtLaunchKernelGGL((k_frame_chain<uint16_t, true>), dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
             else if (c->pixel_bytes == 2) hipExtLaunchKernelGGL(k_frame_chain<uint16_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
             else hipExtLaunchKernelGGL(k_frame_chain<uint32_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
             if (aside) c->chain_ev_newest.store(slot);

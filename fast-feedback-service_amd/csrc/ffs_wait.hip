@@ -63,6 +63,14 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
             if (rc != FFS_OK) return rc;
             return ffs_wait_impl(s, results, n_results);
         }
+        if (overflow & 32u) {
+            // the wave logs could not serve a frame of the batch (more strong pixels than the one launch's LDS forest holds, or a
+            // wave with more strong groups than its log): the batch again through the plane, and this stream stays with it
+            s->log_off = true;
+            int rc = enqueue_batch(s, s->cur_img, s->cur_pitch, s->cur_fstride, s->n_frames, &s->batch_params);
+            if (rc != FFS_OK) return rc;
+            return ffs_wait_impl(s, results, n_results);
+        }
         if (overflow & 16u) {
             // a dense frame with more runs than the one-launch sparse stage holds in LDS (kernels_chain.hpp): the batch again, its
             // sparse stage as the four grid-wide kernels; the stream's later dense batches go there directly

@@ -88,6 +88,17 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
     return v;
 }
 
+// Inclusive running maximum over the 64 lanes, the same six DPP steps.
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
 struct ChainArgs {
     CclArgs c;
     SegArgs s;
@@ -140,7 +151,10 @@ __device__ __forceinline__ void chain_record(const SegArgs& sa, uint32_t W, uint
 
 // RUNS: the instantiation that also holds the run-based phases for frames beyond kChainLdsEntries strong pixels (launched when
 // the stream's previous batch was that dense; a kernel of its own so that the usual one keeps its register allocation).
-template <typename PixelT, bool RUNS = false>
+// LOG: the instantiation that takes the frame's strong pixels from the streaming kernel's wave logs (ThresholdArgs::wlog,
+// tuning "strong_log") instead of the bit plane: phases B, A and E are replaced by L1 (undecided pixels decided, per-row
+// counts) and, after S, L2 (the list placed in raster order by merging the logs of the strips of every band).
+template <typename PixelT, bool RUNS = false, bool LOG = false>
 __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A) {
     const CclArgs& a = A.c;
     const SegArgs& sa = A.s;
@@ -151,6 +165,9 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
     __shared__ uint32_t s_wave[kChainWaves];
     __shared__ uint32_t s_wrun[kChainWaves];   // runs listed by each wave (run-based phases)
     __shared__ uint32_t s_sm[8];
+    __shared__ uint32_t s_flag;   // flags raised by any thread of the block (LOG)
+    __shared__ uint32_t s_nmaybe;   // LOG: undecided pixels listed
+    __shared__ uint32_t s_lst[kChainWaves][16];   // LOG: per chain wave, where each strip's entries start in the band's row of entries
 
     const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_tiles = a.n_tiles;
@@ -160,7 +177,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
     // ---- B: bright windows (k_bright_fix's work): the listed pixels of THIS frame get their exact 64-bit sums and, if
     // strong, their plane bit, occupancy bit and tile count -- before phase A reads the counts
     uint32_t bright_flag = 0;
-    if (A.fix_bright) {
+    if (!LOG && A.fix_bright) {
         const ThresholdArgs& t = A.t;
         const uint32_t listed = *t.bright_n;
         const uint32_t nb = min(listed, t.bright_cap);
@@ -191,8 +208,8 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
     }
 
     // ---- A: tile offsets ------------------------------------------------------------------------------
-    uint32_t total;
-    {
+    uint32_t total = 0;
+    if constexpr (!LOG) {
         uint32_t* counts = sa.zero_counts + (uint64_t)frame * sa.zero_per_seg;   // (= a.tile_counts, writable)
         const uint32_t mine = tid < n_tiles ? counts[tid] : 0u;                  // (n_tiles <= kChainMaxTiles < kChainThreads)
         const uint32_t at = block_exclusive_scan<kChainThreads>(mine, s_wave, total);
@@ -204,16 +221,17 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
             s_toff[n_tiles] = total;
             if (frame == 0 && sa.zero_word && !A.fix_bright) *sa.zero_word = 0;
         }
-        if (tid < 8) s_sm[tid] = 0;
-        if (tid < kChainWaves) s_wrun[tid] = 0;
-        for (int y = tid; y <= a.H; y += kChainThreads) s_row[y] = 0;
     }
+    if (tid < 8) s_sm[tid] = 0;
+    if (tid == 0) { s_flag = 0; s_nmaybe = 0; }
+    if (tid < kChainWaves) s_wrun[tid] = 0;
+    for (int y = tid; y <= a.H; y += kChainThreads) s_row[y] = 0;
     __syncthreads();
-    const uint32_t n = min(total, a.cap);
-    const bool in_lds = n <= (uint32_t)kChainLdsEntries;
+    uint32_t n = min(total, a.cap);                              // (LOG: known after phase S)
+    bool in_lds = n <= (uint32_t)kChainLdsEntries;
     // denser: runs instead of pixels where the frame allows it (block-uniform)
-    const bool runs = RUNS && sizeof(PixelT) == 2 && A.runs_ok != 0 && (!in_lds || A.runs_ok == 2);
-    uint32_t run_flag = 0;   // 16: more runs than the LDS plan holds (the host runs the batch again through the grid-wide kernels)
+    const bool runs = !LOG && RUNS && sizeof(PixelT) == 2 && A.runs_ok != 0 && (!in_lds || A.runs_ok == 2);
+    uint32_t run_flag = 0;   // 16: more runs than the LDS plan holds; 32: the wave logs cannot serve this frame (the host runs the batch again another way)
     FFS_STOP_AFTER(A, 1);
 
     uint32_t* gk = a.list_k + (uint64_t)frame * a.cap;
@@ -234,7 +252,111 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
     // Nothing in this phase waits for a load it has just issued: the plane words come two batches ahead, and the
     // pixel VALUES are not fetched here at all (phase P loads them, twenty independent loads per thread).  What bounds
     // it is one CU's share of the memory system: the frame's 2.3 MB plane at ~20 GB/s.
-    if (total != 0) {
+    // ---- L1 (LOG): the frame's entries in the wave logs -- undecided pixels decided, per-row counts ------------------------
+    // Frame `frame` = frame fe of super row y; its groups are G0 .. G0 + gpf - 1 of the super row, held by strips ls0 .. ls1
+    // (kSOwned groups each); band b of strip k is wave ((b >> 3) * n_strips + k) * 8 + (b & 7) of super row y.  A log is
+    // sorted by (row, frame, group), the strips of a band partition the groups in order: the raster order of a row is strip
+    // after strip.  Chain wave w takes bands w, w + 16, ...
+    [[maybe_unused]] const ThresholdArgs& T = A.t;
+    [[maybe_unused]] uint32_t l_y = 0, l_fe = 0, l_s0 = 0, l_ns = 0, l_gridx = 0;
+    [[maybe_unused]] auto log_wave = [&](int band, uint32_t k) -> uint32_t {
+        return l_y * l_gridx + (((uint32_t)(band >> 3) * (uint32_t)T.n_strips + (l_s0 + k)) * 8u + (uint32_t)(band & 7));
+    };
+    // The logs of one band, read side by side: lane k fetches strip k's count (one round trip for all strips), a scan lays
+    // the strips' entries end to end, and lane i of a chunk takes entry i of that row of entries -- whichever log it is in.
+    // band_begin() returns the band's entries (all frames of the strips'); band_entry() maps a flat index to (strip, entry).
+    [[maybe_unused]] auto band_begin = [&](int band) -> uint32_t {
+        uint32_t c = 0;
+        if ((uint32_t)lane < l_ns) {
+            c = T.wlog_n[log_wave(band, (uint32_t)lane)];
+            if (c > (uint32_t)kWlogCap) { atomicOr(&s_flag, 32u); c = (uint32_t)kWlogCap; }   // (a wave wanted more than its log holds)
+        }
+        const uint32_t incl = wave_inclusive_scan(c);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 16) s_lst[wave][lane] = incl - c;   // where strip `lane`'s entries start (strips beyond the last: the total)
+        __builtin_amdgcn_wave_barrier();
+        return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    };
+    [[maybe_unused]] auto band_entry = [&](uint32_t f, uint32_t nb, uint32_t& k, uint32_t& e) -> bool {
+        k = 0;
+        for (uint32_t j = 1; j < l_ns; ++j) k += f >= s_lst[wave][j] ? 1u : 0u;   // (wave-uniform loop, LDS broadcast reads)
+        e = f - s_lst[wave][k];
+        return f < nb;
+    };
+    constexpr int kLogChunks = 8;
+    // eight chunks (64 entries each) of the band's row of entries from `sb` on, all loads issued before any is used;
+    // entries past the end read as "frame 0xFFFF" (nobody's)
+    [[maybe_unused]] auto load_chunks = [&](int band, uint32_t sb, uint32_t nb, uint2 (&ent)[kLogChunks]) {
+#pragma unroll
+        for (int c = 0; c < kLogChunks; ++c) {
+            uint32_t k, e;
+            ent[c] = make_uint2(0xFFFFFFFFu, 0xFFFF0000u);
+            if (band_entry(sb + (uint32_t)(c * 64 + lane), nb, k, e)) {
+                // (agent-scope load: past this CU's L1, which the atomics that decide undecided pixels never refresh -- no fence needed,
+                // and a device-wide fence here writes back and invalidates the L2 under the streaming kernel: -4 % on the step)
+                const unsigned long long q = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(T.wlog + (uint64_t)log_wave(band, k) * kWlogCap + e),
+                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ent[c] = make_uint2((uint32_t)q, (uint32_t)(q >> 32));
+            }
+        }
+    };
+    if constexpr (LOG) {
+        l_y = (uint32_t)frame / (uint32_t)T.group_frames;
+        l_fe = (uint32_t)frame - l_y * (uint32_t)T.group_frames;
+        const uint32_t gsep = (uint32_t)T.gpf + 1u, G0 = l_fe * gsep, G1 = G0 + (uint32_t)T.gpf - 1u;
+        l_s0 = G0 / (uint32_t)kSOwned;
+        l_ns = G1 / (uint32_t)kSOwned - l_s0 + 1u;
+        l_gridx = (uint32_t)T.n_strips * (uint32_t)((T.n_bands + 7) / 8 * 8);
+        // Undecided pixels (windows with sum p >= 65536: the cores of bright spots) are listed here and decided below, one per
+        // thread -- decided where they are met, a lane with eight of them kept its whole wave waiting (118 us for this phase).
+        uint32_t* s_maybe = reinterpret_cast<uint32_t*>(s_dyn + kChainStageOff);   // band << 16 | strip << 12 | entry << 3 | bit
+        constexpr uint32_t kMaybeCap = (uint32_t)(kChainWaves * 2 * kChainListCap);   // the staging area: 10 240 words
+        for (int band = wave; band < T.n_bands; band += kChainWaves) {
+            const uint32_t nb = band_begin(band);
+            for (uint32_t sb = 0; sb < nb; sb += 64 * kLogChunks) {   // wave-uniform; eight chunks of loads in flight (usually all there is)
+                uint2 ent[kLogChunks];
+                load_chunks(band, sb, nb, ent);
+#pragma unroll
+                for (int c = 0; c < kLogChunks; ++c) {
+                    const uint2 v = ent[c];
+                    if ((v.y >> 16) != l_fe) continue;   // (entries beyond the band's, and other frames': frame 0xFFFF)
+                    const uint32_t row = v.x >> 16;
+                    uint32_t maybe = (v.y >> 8) & 0xFFu & ~v.y;
+                    if (maybe) {
+                        uint32_t k, e;
+                        (void)band_entry(sb + (uint32_t)(c * 64 + lane), nb, k, e);
+                        const uint32_t at = atomicAdd(&s_nmaybe, (uint32_t)__popc(maybe));
+                        uint32_t q = at;
+                        while (maybe) {
+                            const int b = __ffs((int)maybe) - 1;
+                            maybe &= maybe - 1;
+                            if (q < kMaybeCap) s_maybe[q] = ((uint32_t)band << 16) | (k << 12) | (e << 3) | (uint32_t)b;
+                            ++q;
+                        }
+                    }
+                    const uint32_t pc = (uint32_t)__popc(v.y & 0xFFu);
+                    if (pc) atomicAdd(&s_row[row], pc);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t nm = s_nmaybe;
+            if (nm > kMaybeCap && tid == 0) atomicOr(&s_flag, 32u);
+            for (uint32_t i = tid; i < min(nm, kMaybeCap); i += kChainThreads) {
+                const uint32_t it = s_maybe[i];
+                uint2* ent = T.wlog + (uint64_t)log_wave((int)(it >> 16), (it >> 12) & 15u) * kWlogCap + ((it >> 3) & 0x1FFu);
+                const uint2 v = *ent;
+                const uint32_t row = v.x >> 16, ge = v.x & 0xFFFFu, b = it & 7u;
+                if (exact_strong<PixelT, false>(T, img, (int)(ge * 8u + b), (int)row)) {
+                    atomicOr(&ent->y, 1u << b);   // (phase L2 reads the entry again; the "undecided" bits stay and are ignored)
+                    atomicAdd(&s_row[row], 1u);
+                }
+            }
+        }
+        __syncthreads();   // (also waits for this block's atomics to have been performed)
+    }
+    if (!LOG && total != 0) {
         const int tpw = (n_tiles + kChainWaves - 1) / kChainWaves;
         const int tb = min(wave * tpw, n_tiles), te = min(tb + tpw, n_tiles);
         const int yb = tb * kTileRows, ye = min(te * kTileRows, a.H);
@@ -517,8 +639,106 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                 run += loc[q];
             }
         }
+        if constexpr (LOG) {
+            total = tot;
+            n = min(total, a.cap);
+            in_lds = n <= (uint32_t)kChainLdsEntries;
+        }
     }
     __syncthreads();
+    if constexpr (LOG) {
+        // ---- L2: the list in raster order.  Per band (one chain wave each): pixels per (row, strip) -> where each strip's part
+        // of each row starts -> every entry's pixels placed (a segmented scan over the 64 entries of a chunk of a log).  The
+        // column numbers go straight into LDS (phase X has nothing left to do).  Frames beyond the LDS forest: flag 32.
+        run_flag |= s_flag;
+        if (!in_lds) run_flag |= 32u;
+        if (run_flag == 0 && total != 0) {
+            constexpr int kMaxStrips = 12;
+            uint16_t* s_x = reinterpret_cast<uint16_t*>(s_dyn + kChainStageOff);
+            // per chain wave: cw[row of the band][strip] in the forest area (free until the forest is built)
+            uint32_t* cw = reinterpret_cast<uint32_t*>(s_big) + (size_t)wave * (kChainForestBytes / 4 / kChainWaves);
+            const int cw_rows = (kChainForestBytes / 4 / kChainWaves) / kMaxStrips;   // 106 rows of a band at a time
+            uint8_t* sbytes = a.strong_bytes + (uint64_t)frame * a.bytes_frame_stride;
+            const uint32_t ns = min(l_ns, (uint32_t)kMaxStrips);
+            for (int band = wave; band < T.n_bands; band += kChainWaves) {
+                const int yb0 = band * T.band_rows, yb1 = min(yb0 + T.band_rows, a.H);
+                for (int r0 = yb0; r0 < yb1; r0 += cw_rows) {   // (bands taller than the counters: in pieces)
+                    const int r1 = min(r0 + cw_rows, yb1);
+                    for (int i = lane; i < (r1 - r0) * kMaxStrips; i += 64) cw[i] = 0;
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t nb = band_begin(band);
+                    const bool one = nb <= 64u * kLogChunks;   // (the usual case: the entries stay in registers between the two passes)
+                    uint2 ent[kLogChunks];
+                    for (uint32_t sb = 0; sb < nb; sb += 64 * kLogChunks) {   // pixels per (row, strip)
+                        load_chunks(band, sb, nb, ent);
+#pragma unroll
+                        for (int c = 0; c < kLogChunks; ++c) {
+                            const uint2 v = ent[c];
+                            const int row = (int)(v.x >> 16);
+                            if ((v.y >> 16) != l_fe || row < r0 || row >= r1) continue;
+                            uint32_t k, e;
+                            (void)band_entry(sb + (uint32_t)(c * 64 + lane), nb, k, e);
+                            if (k < ns) atomicAdd(&cw[(row - r0) * kMaxStrips + (int)k], (uint32_t)__popc(v.y & 0xFFu));
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    for (int r = r0 + lane; r < r1; r += 64) {   // counts -> list positions (the row's own offset + the strips before)
+                        uint32_t at = s_row[r];
+                        for (uint32_t k = 0; k < ns; ++k) {
+                            const uint32_t c = cw[(r - r0) * kMaxStrips + (int)k];
+                            cw[(r - r0) * kMaxStrips + (int)k] = at;
+                            at += c;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t sb = 0; sb < nb; sb += 64 * kLogChunks) {
+                        if (!one) load_chunks(band, sb, nb, ent);
+#pragma unroll
+                        for (int c = 0; c < kLogChunks; ++c) {   // 64 consecutive entries of the band's row of entries
+                            if (sb + (uint32_t)(c * 64) >= nb) break;   // wave-uniform
+                            const uint2 v = ent[c];
+                            uint32_t k, e;
+                            const bool have = band_entry(sb + (uint32_t)(c * 64 + lane), nb, k, e);
+                            const int row = (int)(v.x >> 16);
+                            const bool mine = have && (v.y >> 16) == l_fe && row >= r0 && row < r1 && k < ns;
+                            const uint32_t cb = mine ? v.y & 0xFFu : 0u;
+                            const uint32_t pc = (uint32_t)__popc(cb);
+                            const uint32_t incl = wave_inclusive_scan(pc), excl = incl - pc;
+                            // the pixels of MY (strip, row) before me in this chunk: excl minus excl at the first lane of my segment (a
+                            // log is sorted by row and the logs follow each other: a segment is contiguous; lanes that are not mine
+                            // carry keys of their own and no pixels)
+                            const uint32_t key = mine ? (k << 16) | (uint32_t)row : 0x80000000u + (uint32_t)lane;
+                            const uint32_t key_prev = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)key, 0x138, 0xf, 0xf, false);   // wave_shr:1
+                            const bool starts = lane == 0 || key_prev != key;
+                            const uint32_t seg = wave_inclusive_max(starts ? excl : 0u);
+                            if (mine) {
+                                uint32_t at = cw[(row - r0) * kMaxStrips + (int)k] + (excl - seg);
+                                const uint32_t ge = v.x & 0xFFFFu;
+                                uint32_t w = cb;
+                                while (w) {
+                                    const int b = __ffs((int)w) - 1;
+                                    w &= w - 1;
+                                    const uint32_t x = ge * 8u + (uint32_t)b;
+                                    if (at < a.cap) gk[at] = (uint32_t)row * W + x;
+                                    if (at < (uint32_t)kChainLdsEntries) s_x[at] = (uint16_t)x;
+                                    if (a.dense_bytes) sbytes[(uint64_t)row * a.bpitch + x] = 1;
+                                    ++at;
+                                }
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                            // the next chunk may continue the chunk's last segment: move that (row, strip)'s position on
+                            const uint32_t key_next = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)key, 0x130, 0xf, 0xf, false);   // wave_shl:1
+                            if (mine && (lane == 63 || key_next != key)) cw[(row - r0) * kMaxStrips + (int)k] += incl - seg;
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                }
+            }
+        }
+        if (run_flag) n = 0;   // (nothing was placed: the phases below have nothing to do)
+        __syncthreads();
+        FFS_STOP_AFTER(A, 5);
+    }
 
     WireRec2* recs = reinterpret_cast<WireRec2*>(sa.recs) + (uint64_t)frame * A.rec_stride;
     uint32_t before = 0;  // components numbered so far (block-uniform)
@@ -532,11 +752,13 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
         // With the per-row list offsets they ARE the list (k = y W + x), so phases U and P make no global access to it:
         // a dependent access costs ~0.1 us here against ~1 us at the L2.
         uint16_t* s_x = reinterpret_cast<uint16_t*>(s_dyn + kChainStageOff);
-        for (uint32_t i = tid; i < n; i += kChainThreads) {
-            const uint32_t kv = gk[i];
-            s_x[i] = (uint16_t)(kv - (kv / W) * W);
+        if constexpr (!LOG) {   // (phase L2 wrote them as it placed the list)
+            for (uint32_t i = tid; i < n; i += kChainThreads) {
+                const uint32_t kv = gk[i];
+                s_x[i] = (uint16_t)(kv - (kv / W) * W);
+            }
+            __syncthreads();
         }
-        __syncthreads();
         // the row of list entry i0: the last row whose offset is <= i0 (rows without strong pixels share their successor's)
         uint32_t yrow = 0;
         if (i0 < i1) {
@@ -556,6 +778,16 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
             return xj == 0 && xp == W - 1 && r > 0 && s_row[r - 1] < s_row[r];        // first of its row: the row above ends the list before it
         };
 
+        if constexpr (LOG) {
+            // the forest's run links, which the plane's compaction sets as it places a word's pixels: an entry whose left
+            // neighbour is strong points at it (the row-wrap pair is joined in phase U, as there)
+            uint32_t y = yrow;
+            for (uint32_t i = i0; i < i1; ++i) {
+                while (s_row[y + 1] <= i) ++y;
+                spar[i] = (continues(i, y) && s_x[i] != 0) ? i - 1 : i;
+            }
+            __syncthreads();
+        }
         // ---- U: vertical edges + row wrap (k_union<false> with the runs linked by the compaction) ----------------
         {
             uint32_t y = yrow;
@@ -961,6 +1193,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
 }
 template __global__ void k_frame_chain<uint16_t, false>(const ChainArgs);
 template __global__ void k_frame_chain<uint16_t, true>(const ChainArgs);
+template __global__ void k_frame_chain<uint16_t, false, true>(const ChainArgs);
 template __global__ void k_frame_chain<uint32_t, false>(const ChainArgs);
 
 }  // namespace ffsamd

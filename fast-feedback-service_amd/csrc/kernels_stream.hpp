@@ -174,7 +174,11 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
     const int strip = qb % a.n_strips;
     const int band = xcd + 8 * (qb / a.n_strips);
-    if (band >= a.n_bands) return;
+    [[maybe_unused]] const uint32_t wave_id = blockIdx.y * gridDim.x + blockIdx.x;
+    if (band >= a.n_bands) {
+        if constexpr (!EXT) if (a.wlog && lane == 0) a.wlog_n[wave_id] = 0;   // (every wave of the grid has a count)
+        return;
+    }
     const int f0 = blockIdx.y * a.group_frames;                   // first frame of this super row
     const int nf = min(a.group_frames, a.n_frames - f0);
     const int yb0 = band * a.band_rows;
@@ -306,6 +310,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     };
 
     int qn = 0;  // queued lane groups (wave-uniform)
+    [[maybe_unused]] uint32_t nlog = 0;   // entries of this wave's log (wave-uniform)
     // 64 queued groups at a time.  Phase 1, one group per lane: the conservative float32 signal test on its
     // eight pixels (a proven superset, see signal_test8).  Phase 2: the pixels still standing (a few dozen)
     // are dealt one per lane -- each lane's candidates numbered by ballot + mbcnt, bit plane by bit plane --
@@ -420,6 +425,9 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                 } else if (!EXT && a.bright_to_plane) {
                     // sum p^2 may not fit 32 bits: marked as a candidate, k_exact gathers the window and decides
                     atomicOr(&s_q[14][e], 1u << j);
+                } else if (!EXT && a.wlog) {
+                    // ... marked "undecided" in the group's log entry: the sparse launch gathers the window and decides
+                    atomicOr(&s_q[14][e], 0x100u << j);
                 } else {
                     // sum p^2 may not fit 32 bits: k_bright_fix gathers the window and decides (rare)
                     const uint32_t tg = s_q[30][e];
@@ -432,6 +440,17 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
             }
         }
         __builtin_amdgcn_wave_barrier();
+        if constexpr (!EXT) if (a.wlog) {   // (wave-uniform) one dense 8-byte store per group instead of a plane byte and two atomics
+            const uint32_t cbm = have ? s_q[14][lane] : 0u;   // strong | undecided << 8
+            const unsigned long long wm = __builtin_amdgcn_ballot_w64(cbm != 0u);
+            if (cbm != 0u) {
+                const uint32_t at = nlog + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u));
+                if (at < (uint32_t)kWlogCap) a.wlog[(uint64_t)wave_id * kWlogCap + at] = make_uint2((row << 16) | ge, (fe << 16) | cbm);
+            }
+            nlog += (uint32_t)__popcll(wm);   // (queue entries are in (row, lane) order, so the log is sorted by (row, frame, group))
+            qn = 0;
+            return;
+        }
         if (have) {
             const uint32_t cb = s_q[14][lane];
             if (cb) {  // the plane is all zero when the kernel starts (the compaction clears what it consumed)
@@ -578,6 +597,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     }
 rows_done:
     if (qn > 0) drain();
+    if constexpr (!EXT) if (a.wlog && lane == 0) a.wlog_n[wave_id] = nlog;
 }
 // Pixels whose window holds sum p >= 65536 (k_stream_u16 cannot vouch for its 32-bit sum of p^2): exact
 // 64-bit sums gathered from memory, then the same predicate.  A handful per frame at most.

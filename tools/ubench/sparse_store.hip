@@ -16,18 +16,21 @@ __global__ __launch_bounds__(64, 4) void k_stores(const uint4* __restrict__ img,
     uint32_t rng = (uint32_t)(wave * 2654435761u) ^ (uint32_t)lane * 40503u;
     const int every = (int)(per_wave / 64) / (stores_per_wave > 0 ? stores_per_wave : 1);
     int k = 0;
+    uint32_t later[16]; int nl = 0;
     for (size_t i = lane; i < per_wave; i += 64, ++k) {
         const uint4 v = p[i];
         acc += v.x ^ v.y ^ v.z ^ v.w;
         if (with_stores && every > 0 && (k % every) == 0 && lane < 3) {   // a few lanes store, as in a drain
             rng = rng * 1664525u + 1013904223u;
             const size_t at = (size_t)(rng % (uint32_t)plane_bytes);
-            if (flavour == 0) plane[at] = (uint8_t)(acc | 1u);
+            if (flavour == 4) { if (nl < 16) later[nl++] = (uint32_t)at; }
+            else if (flavour == 0) plane[at] = (uint8_t)(acc | 1u);
             else if (flavour == 1) atomicOr(reinterpret_cast<uint32_t*>(plane) + (at >> 2), 1u << (at & 31u));
             else if (flavour == 2) __builtin_nontemporal_store((uint8_t)(acc | 1u), plane + at);
             else reinterpret_cast<uint32_t*>(plane)[at >> 2] = acc | 1u;
         }
     }
+    for (int q = 0; q < nl; ++q) plane[later[q]] = (uint8_t)(acc | 1u);
     if (acc == 0x12345678u) sink[0] = acc;
 }
 __global__ __launch_bounds__(64) void k_stores_only(uint8_t* plane, size_t plane_bytes, int per_lane) {
@@ -57,25 +60,17 @@ int main() {
             }
             if (round) printf("round %d slab %2d at %p: reads only %.1f us, with 576 k byte stores %.1f us (+%.1f)\n", round, i, (void*)slabs[i], ms[0] * 100, ms[1] * 100, (ms[1] - ms[0]) * 100);
         }
-    // small allocations: do consecutive 80 MB buffers (what a stream's sparse-write buffers would be on their own) share the state?
-    for (int i = 0; i < N; ++i) hipFree(slabs[i]);
-    std::vector<uint8_t*> small(96);
-    for (auto& p : small) { hipMalloc(&p, (size_t)80 << 20); hipMemset(p, 0, (size_t)80 << 20); }
-    for (size_t i = 0; i < small.size(); ++i) {
-        float ms;
-        for (int rep = 0; rep < 2; ++rep) {
+    // stores as they come against the same stores held back to the end of the wave (nothing left to wait for behind them)
+    for (int i = 0; i < N; ++i) {
+        float ms[2];
+        for (int v = 0; v < 2; ++v) {
             hipEventRecord(e0);
             for (int r = 0; r < 10; ++r)
-                hipLaunchKernelGGL(k_stores, dim3(15064), dim3(64), 0, 0, img, img_bytes / 16, small[i], plane_bytes, sink, 13, 1, 0);
+                hipLaunchKernelGGL(k_stores, dim3(15064), dim3(64), 0, 0, img, img_bytes / 16, slabs[i] + img_bytes, plane_bytes, sink, 13, 1, v ? 4 : 0);
             hipEventRecord(e1); hipEventSynchronize(e1);
-            hipEventElapsedTime(&ms, e0, e1);
+            hipEventElapsedTime(&ms[v], e0, e1);
         }
-        float ms2;
-        hipEventRecord(e0);
-        for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(k_stores_only, dim3(1024), dim3(64), 0, 0, small[i], plane_bytes, 9);   // 590 k stores
-        hipEventRecord(e1); hipEventSynchronize(e1);
-        hipEventElapsedTime(&ms2, e0, e1);
-        printf("small %2zu at %p: %.1f us beside the read, %.1f us stores alone\n", i, (void*)small[i], ms * 100, ms2 * 100);
+        printf("slab %2d: stores as they come %.1f us, held back to the end of the wave %.1f us\n", i, ms[0] * 100, ms[1] * 100);
     }
     return 0;
 }
