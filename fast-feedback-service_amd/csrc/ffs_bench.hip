@@ -23,7 +23,8 @@ extern "C" int ffs_bench_threshold(ffs_stream* s, const void* device_pixels, siz
         rc = ensure_extended_buffers(s);
         if (rc != FFS_OK) return rc;
     }
-    const ThresholdArgs ta = make_threshold_args(s, device_pixels, pitch, fstride, n_frames);
+    ThresholdArgs ta = make_threshold_args(s, device_pixels, pitch, fstride, n_frames);
+    if (!ext) (void)wave_logs_for(s, ta, n_frames);   // (the kernel as the hot path launches it)
     const Layout& L = c->L;
     std::vector<hipEvent_t> ev(4 * (size_t)iters, nullptr);
     auto cleanup = [&]() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); };

@@ -288,6 +288,7 @@ int ensure_extended_buffers(ffs_stream* s);
 int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride, uint32_t n, const ffs_params* snapshot = nullptr);
 // one launch of the threshold stage's dense kernel on s->st with HIP events on the dispatch itself (either may be null),
 // and of the kernel that follows it (k_bright_fix / k_exact; extended: erosion + final pass) -- what ffs_bench_threshold times
+bool wave_logs_for(ffs_stream* s, ThresholdArgs& a, uint32_t n_frames);
 void bench_launch_dense(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames, hipEvent_t start, hipEvent_t stop);
 void bench_launch_rest(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames);
 // ffs_wait.hip

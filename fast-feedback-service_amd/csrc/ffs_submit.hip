@@ -191,6 +191,40 @@ int ensure_extended_buffers(ffs_stream* s) {
     return FFS_OK;
 }
 
+// Wave logs for this launch (tuning "strong_log"): the 16-bit standard path on a context with sparse streams, a geometry
+// kernels_chain.hpp's merge holds (at most twelve strips per frame).  Allocates the logs for the launch's waves on first use
+// and puts them into `a`; false: the plane.
+bool wave_logs_for(ffs_stream* s, ThresholdArgs& a, uint32_t n_frames) {
+    ffs_ctx* c = s->ctx;
+    const Layout& L = c->L;
+    if (!(c->tune.strong_log != 0 && c->pixel_bytes == 2 && !a.bright_to_plane && !s->log_off && s->st2 != s->st && c->chain_ok
+          && s->batch_params.algorithm != FFS_ALGO_DISPERSION_EXTENDED && c->n_tiles <= kChainMaxTiles && L.H <= kChainMaxRows
+          && (uint32_t)a.gpf / (uint32_t)kSOwned + 2u <= 12u && a.band_rows <= 1024 && L.W <= 65535))
+        return false;
+    const dim3 g = stream_grid(a, n_frames);
+    const size_t waves = (size_t)g.x * g.y;
+    if (waves > s->wlog_waves) {
+        if (s->d_wlog) {
+            (void)hipStreamSynchronize(s->st);
+            (void)hipStreamSynchronize(s->st2);
+            (void)hipFree(s->d_wlog);
+            (void)hipFree(s->d_wlog_n);
+            s->d_wlog = nullptr;
+            s->d_wlog_n = nullptr;
+        }
+        s->wlog_waves = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&s->d_wlog), waves * kWlogCap * sizeof(uint2)) != hipSuccess
+            || hipMalloc(reinterpret_cast<void**>(&s->d_wlog_n), waves * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        s->wlog_waves = waves;
+    }
+    a.wlog = s->d_wlog;
+    a.wlog_n = s->d_wlog_n;
+    return true;
+}
+
 void bench_launch_dense(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames, hipEvent_t start, hipEvent_t stop) {
     if (s->batch_params.algorithm == FFS_ALGO_DISPERSION_EXTENDED) launch_ext_first(s, a, n_frames, start, stop);
     else launch_stream(s, a, n_frames, start, stop);
@@ -198,7 +232,7 @@ void bench_launch_dense(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames
 void bench_launch_rest(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
     if (s->batch_params.algorithm == FFS_ALGO_DISPERSION_EXTENDED) launch_ext_rest(s, a, n_frames);
     else if (a.bright_to_plane) launch_exact(s, a, n_frames, s->st);
-    else launch_bright_fix(s, a, s->st);
+    else if (!a.wlog) launch_bright_fix(s, a, s->st);   // (with wave logs the sparse launch decides the bright windows)
 }
 
 int check_layout(ffs_stream* s, size_t pitch, size_t fstride, uint32_t n_frames) {
@@ -280,21 +314,8 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
     if (s->force_grid) will_chain = false;
     // Wave logs instead of the plane (tuning "strong_log"): the standard 16-bit path, sparse stage in the one launch, frames
     // that fit its LDS forest.  The streaming kernel then leaves plane, counters, occupancy bitmap and bright list alone.
-    bool use_log = c->tune.strong_log != 0 && c->pixel_bytes == 2 && list_path && will_chain && !dense_batch && !s->log_off
-                   && s->st2 != s->st && (uint32_t)ta.gpf / (uint32_t)kSOwned + 2u <= 12u && ta.band_rows <= 1024 && L.W <= 65535 && L.H <= 65535;
-    if (use_log) {
-        const dim3 g = stream_grid(ta, n);
-        const size_t waves = (size_t)g.x * g.y;
-        if (waves > s->wlog_waves) {
-            if (s->d_wlog) { (void)hipStreamSynchronize(s->st); (void)hipStreamSynchronize(s->st2); (void)hipFree(s->d_wlog); (void)hipFree(s->d_wlog_n); s->d_wlog = nullptr; s->d_wlog_n = nullptr; }
-            s->wlog_waves = 0;
-            if (hipMalloc(reinterpret_cast<void**>(&s->d_wlog), waves * kWlogCap * sizeof(uint2)) == hipSuccess
-                && hipMalloc(reinterpret_cast<void**>(&s->d_wlog_n), waves * 4) == hipSuccess) s->wlog_waves = waves;
-            else { (void)hipGetLastError(); use_log = false; }
-        }
-    }
     ThresholdArgs ta_launch = ta;
-    if (use_log) { ta_launch.wlog = s->d_wlog; ta_launch.wlog_n = s->d_wlog_n; }
+    const bool use_log = list_path && will_chain && !dense_batch && wave_logs_for(s, ta_launch, n);
 #ifdef FFS_EXPERIMENTS
     if (c->tune.exp.chain_skip) will_chain = false;
 #endif

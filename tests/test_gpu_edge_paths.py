@@ -400,3 +400,47 @@ def test_run_based_sparse_stage_overflow_falls_back(ffs):
     fat_only = np.stack([fat, fat[::-1].copy()])
     for fr, img in zip(st.process(fat_only), fat_only):
         assert_frame_matches_oracle(fr, img, ones, min_spot_size=1)
+
+
+@pytest.mark.parametrize("strong_log", [1, 0])
+def test_wave_logs_and_bit_plane_agree(ffs, strong_log):
+    """Tuning `strong_log`: the streaming kernel's per-wave logs merged by the sparse launch (1, default) against the bit plane
+    (0).  Frames chosen for the merge: strong pixels in every strip and band, groups that straddle strips, a frame pair
+    that shares a strip (frame width not a multiple of the strip), bright windows (decided by the sparse launch: the cores
+    of saturated spots), the row-wrap pair, rows with hundreds of strong groups (a wave's log overflows: the batch falls back
+    to the plane inside ffs_wait and the stream stays there), an empty frame; then the dense byte mask."""
+    rng = np.random.default_rng(77)
+    W, H, B = 1000, 300, 5
+    frames = []
+    for i in range(B - 1):
+        img = rng.poisson(2.0, (H, W)).astype(np.uint16)
+        for _ in range(150):
+            y, x = rng.integers(0, H - 4), rng.integers(0, W - 4)
+            img[y:y + rng.integers(1, 4), x:x + rng.integers(1, 6)] = rng.integers(200, 3000)
+        for _ in range(12):                                   # saturated cores: windows with sum p >= 65536
+            y, x = rng.integers(0, H - 8), rng.integers(0, W - 8)
+            img[y:y + 6, x:x + 6] = rng.integers(20000, 65535)
+        frames.append(img)
+    frames[1][100, W - 1] = 900; frames[1][101, 0] = 800     # (W-1, y) -- (0, y+1)
+    frames.append(np.zeros((H, W), np.uint16))
+    frames = np.stack(frames)
+    mask = np.ones((H, W), np.uint8)
+    mask[:, 496:500] = 0
+    mask[rng.random((H, W)) < 0.001] = 0
+    ctx = ffs.Context(W, H, np.uint16, max_batch=B)
+    ctx.set_tuning(strong_log=strong_log)
+    ctx.set_mask(mask)
+    ctx.set_params(want_strong_list=1, min_spot_size=1)
+    st = ctx.stream()
+    for rep in range(2):
+        for fr, img in zip(st.process(frames, first_frame_id=rep), frames):
+            assert_frame_matches_oracle(fr, img, mask, min_spot_size=1)
+    ctx.set_params(want_strong_mask=1, want_strong_list=1, min_spot_size=3)
+    for fr, img in zip(st.process(frames[:3]), frames[:3]):
+        assert_frame_matches_oracle(fr, img, mask)
+    # a row of strong groups: more entries than a wave's log holds -> the plane takes over, results unchanged
+    busy = rng.poisson(1.0, (H, W)).astype(np.uint16)
+    busy[20:60, ::5] = 500
+    for rep in range(2):
+        for fr, img in zip(st.process(np.stack([busy, frames[0]])), (busy, frames[0])):
+            assert_frame_matches_oracle(fr, img, mask)

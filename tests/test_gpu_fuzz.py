@@ -166,3 +166,11 @@ def test_random_case_run_based_sparse_stage(ffs, seed):
     `chain_runs` = 2: the launch dense frames take by themselves, kernels_chain.hpp): random shapes, masks, algorithms,
     densities and filters through phases E' / U' / P' / R'."""
     test_random_case(ffs, seed, tuning=dict(chain_runs=2))
+
+
+@pytest.mark.parametrize("seed", range(2, 240, 4))
+def test_random_case_bit_plane_instead_of_wave_logs(ffs, seed):
+    """The same sweep with tuning `strong_log` = 0: the 16-bit streaming kernel scatters plane bytes, counters and occupancy
+    bits and lists bright windows for k_bright_fix, the sparse launch compacts the plane (the default since round 3c is the
+    wave logs, which the sweeps above go through)."""
+    test_random_case(ffs, seed, tuning=dict(strong_log=0))
