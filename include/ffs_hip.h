@@ -155,6 +155,9 @@ int ffs_ctx_set_params(ffs_ctx *ctx, const ffs_params *p);
  *   "ext_first_pass"   (2) extended algorithm, 16-bit pixels: 2 = streaming kernel, 0 = plain one-pixel-per-lane kernel
  *   "sparse_stage"     (2) one launch per batch, a workgroup per frame: 3 = always, 2 = unless the stream's previous batch
  *                          held a frame with more strong pixels than that workgroup's LDS holds; 1 = four grid-wide kernels
+ *   "strong_log"       (1) 16-bit standard path: the streaming kernel appends its strong groups to per-wave logs which the
+ *                          one-launch sparse stage merges (dense stores; the kernel's time no longer depends on where the
+ *                          stream's buffers lie); 0 = plane bytes, counters and an occupancy bitmap as in rounds 1-3b
  *   "chain_runs"       (1) with "sparse_stage" 2: such dense batches of 16-bit frames stay in the one launch, its union-find
  *                          over runs of strong pixels instead of pixels (up to 16384 runs per frame); 0 = they take the grid-wide kernels;
  *                          2 = every frame of 16-bit pixels goes over runs (A/B partner: no faster on sparse frames)
