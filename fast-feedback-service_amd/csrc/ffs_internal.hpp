@@ -143,6 +143,7 @@ struct ffs_stream {
     ffs_stream* big = nullptr;               // one-frame stream with room for frames that exceed cap / max_comp
     std::vector<OverflowFrame> ovf;          // such frames of the last batch, re-run on `big`
     int force_path = -1;                     // >= 0: threshold path of the next enqueue (bright-list overflow -> 1)
+    bool plane_once = false;                 // the next enqueue takes the plane (a batch the logs could not serve is run again)
     bool log_off = false;                    // the wave logs could not serve a batch of this stream (dense frames, a log overflow): the plane from then on
     uint2* d_wlog = nullptr;                 // wave logs of the streaming kernel (allocated on first use, sized for the launch geometry)
     uint32_t* d_wlog_n = nullptr;

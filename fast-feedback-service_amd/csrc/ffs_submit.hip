@@ -197,7 +197,7 @@ int ensure_extended_buffers(ffs_stream* s) {
 bool wave_logs_for(ffs_stream* s, ThresholdArgs& a, uint32_t n_frames) {
     ffs_ctx* c = s->ctx;
     const Layout& L = c->L;
-    if (!(c->tune.strong_log != 0 && c->pixel_bytes == 2 && !a.bright_to_plane && !s->log_off && s->st2 != s->st && c->chain_ok
+    if (!(c->tune.strong_log != 0 && c->pixel_bytes == 2 && !a.bright_to_plane && !s->log_off && !s->plane_once && s->st2 != s->st && c->chain_ok
           && s->batch_params.algorithm != FFS_ALGO_DISPERSION_EXTENDED && c->n_tiles <= kChainMaxTiles && L.H <= kChainMaxRows
           && (uint32_t)a.gpf / (uint32_t)kSOwned + 2u <= 12u && a.band_rows <= 1024 && L.W <= 65535))
         return false;

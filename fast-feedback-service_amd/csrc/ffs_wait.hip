@@ -63,11 +63,15 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
             if (rc != FFS_OK) return rc;
             return ffs_wait_impl(s, results, n_results);
         }
-        if (overflow & 32u) {
-            // the wave logs could not serve a frame of the batch (more strong pixels than the one launch's LDS forest holds, or a
-            // wave with more strong groups than its log): the batch again through the plane, and this stream stays with it
-            s->log_off = true;
+        if (overflow & (32u | 64u)) {
+            // the wave logs could not serve a frame of the batch: the batch again through the plane.  A wave with more strong groups
+            // than its log holds (32): the stream stays with the plane.  A frame with more strong pixels than the one launch's LDS
+            // forest (64): only this batch -- the next one follows what this one held (dense data takes the plane by itself,
+            // and the logs are back when the data is sparse again)
+            if (overflow & 32u) s->log_off = true;
+            s->plane_once = true;
             int rc = enqueue_batch(s, s->cur_img, s->cur_pitch, s->cur_fstride, s->n_frames, &s->batch_params);
+            s->plane_once = false;
             if (rc != FFS_OK) return rc;
             return ffs_wait_impl(s, results, n_results);
         }

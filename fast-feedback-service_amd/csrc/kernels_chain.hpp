@@ -231,7 +231,8 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
     bool in_lds = n <= (uint32_t)kChainLdsEntries;
     // denser: runs instead of pixels where the frame allows it (block-uniform)
     const bool runs = !LOG && RUNS && sizeof(PixelT) == 2 && A.runs_ok != 0 && (!in_lds || A.runs_ok == 2);
-    uint32_t run_flag = 0;   // 16: more runs than the LDS plan holds; 32: the wave logs cannot serve this frame (the host runs the batch again another way)
+    uint32_t run_flag = 0;   // 16: more runs than the LDS plan holds; 32: a wave log (or the list of undecided pixels) overflowed; 64: a frame beyond
+                             // the LDS forest met in the wave logs (the host runs the batch again another way)
     FFS_STOP_AFTER(A, 1);
 
     uint32_t* gk = a.list_k + (uint64_t)frame * a.cap;
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
         // of each row starts -> every entry's pixels placed (a segmented scan over the 64 entries of a chunk of a log).  The
         // column numbers go straight into LDS (phase X has nothing left to do).  Frames beyond the LDS forest: flag 32.
         run_flag |= s_flag;
-        if (!in_lds) run_flag |= 32u;
+        if (!in_lds) run_flag |= 64u;   // (a frame beyond the LDS forest: this batch again through the plane; logs again when the data is sparse again)
         if (run_flag == 0 && total != 0) {
             constexpr int kMaxStrips = 12;
             uint16_t* s_x = reinterpret_cast<uint16_t*>(s_dyn + kChainStageOff);

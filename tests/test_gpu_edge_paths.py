@@ -444,3 +444,20 @@ def test_wave_logs_and_bit_plane_agree(ffs, strong_log):
     for rep in range(2):
         for fr, img in zip(st.process(np.stack([busy, frames[0]])), (busy, frames[0])):
             assert_frame_matches_oracle(fr, img, mask)
+
+
+def test_sparse_and_dense_batches_alternate_on_one_stream(ffs):
+    """Which sparse stage a batch gets follows what the stream's previous batch held: wave logs for sparse data, the plane with
+    the run-based launch for dense data, and a dense batch that arrives on the logs is run again through the plane inside
+    ffs_wait (flag 64) without switching the logs off for good.  Sparse / dense / dense / sparse / sparse / dense."""
+    W, H = 1000, 700
+    sparse = [make_frame(W=W, H=H, seed=300 + i, n_spots=40)[0] for i in range(2)]
+    dense = [_blob_frame(W, H, 40 + i, 500) for i in range(2)]
+    ones = np.ones((H, W), np.uint8)
+    ctx = ffs.Context(W, H, np.uint16, max_batch=2, max_strong_per_frame=90000)
+    ctx.set_params(want_strong_list=1, min_spot_size=2)
+    st = ctx.stream()
+    for k, batch in enumerate([sparse, dense, dense, sparse, sparse, dense, [sparse[0], dense[1]], sparse]):
+        res = st.process(np.stack(batch), first_frame_id=10 * k)
+        for fr, img in zip(res, batch):
+            assert_frame_matches_oracle(fr, img, ones, min_spot_size=2)
