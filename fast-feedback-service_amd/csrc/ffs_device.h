@@ -152,6 +152,8 @@ struct CclArgs {
     uint32_t bpitch;
     uint64_t bytes_frame_stride;
     int dense_bytes;           // write the byte mask at all (only when somebody asked for it)
+    int need_lists;            // the strong-pixel lists (k, intensity) have a reader after the launch (host copy, 3D stack); 0: the launch that
+                               // merges wave logs keeps them to itself (1.15 M scattered 4-byte stores per batch less)
     uint32_t* occ;             // see ThresholdArgs; null or use_occ == 0: the whole plane is read
     uint32_t occ_frame_words, occ_spr;
     int use_occ;

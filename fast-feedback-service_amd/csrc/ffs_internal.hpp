@@ -70,6 +70,8 @@ struct Tuning {
     int decode_in_dense_stream = 1;   // the decode kernel runs in the dense kernels' stream (0: in the upload stream)
     int ccl_grid = 32;          // workgroups per frame of the grid-wide sparse kernels
     int rows_ahead = 2;         // rows of loads a wave of the 16-bit streaming kernel keeps in flight (2, 3 or 4)
+    int device_lists = 2;       // the strong-pixel lists stay on the device after a batch: 1 = always, 0 = only when the host asked for them
+                                //    (want_strong_list), 2 = also while a 3D stack of the process is alive (ffs_stack3d_add_batch reads them)
     int strong_log = 1;         // 16-bit standard path: the streaming kernel appends its strong groups to per-wave logs and the one-launch sparse
                                 //    stage merges them (kernels_chain.hpp, LOG) instead of scattering plane bytes, counters and occupancy bits;
                                 //    0 = the bit plane (also what dense frames, tall frames and the other algorithms and paths take)
@@ -143,6 +145,7 @@ struct ffs_stream {
     ffs_stream* big = nullptr;               // one-frame stream with room for frames that exceed cap / max_comp
     std::vector<OverflowFrame> ovf;          // such frames of the last batch, re-run on `big`
     int force_path = -1;                     // >= 0: threshold path of the next enqueue (bright-list overflow -> 1)
+    bool lists_valid = true;                 // the last batch left its strong-pixel lists on the device
     bool plane_once = false;                 // the next enqueue takes the plane (a batch the logs could not serve is run again)
     bool log_off = false;                    // the wave logs could not serve a batch of this stream (dense frames, a log overflow): the plane from then on
     uint2* d_wlog = nullptr;                 // wave logs of the streaming kernel (allocated on first use, sized for the launch geometry)
@@ -289,6 +292,7 @@ int ensure_extended_buffers(ffs_stream* s);
 int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride, uint32_t n, const ffs_params* snapshot = nullptr);
 // one launch of the threshold stage's dense kernel on s->st with HIP events on the dispatch itself (either may be null),
 // and of the kernel that follows it (k_bright_fix / k_exact; extended: erosion + final pass) -- what ffs_bench_threshold times
+extern std::atomic<int> g_live_stacks;   // 3D stacks alive in the process (ffs_stack3d.hip)
 bool wave_logs_for(ffs_stream* s, ThresholdArgs& a, uint32_t n_frames);
 void bench_launch_dense(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames, hipEvent_t start, hipEvent_t stop);
 void bench_launch_rest(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames);

@@ -101,14 +101,19 @@ static int stack3d_create_impl(ffs_ctx* c, uint64_t max_total, ffs_stack3d** out
     return FFS_OK;
 }
 
+std::atomic<int> g_live_stacks{0};   // while one is alive, batches leave their strong-pixel lists on the device (tuning "device_lists" = 2)
+
 extern "C" int ffs_stack3d_create(ffs_ctx* c, uint64_t max_total, ffs_stack3d** out) {
     if (!c || !out) return FFS_ERR_INVALID;
     *out = nullptr;
-    return stack3d_create_impl(c, max_total, out);
+    const int rc = stack3d_create_impl(c, max_total, out);
+    if (rc == FFS_OK) g_live_stacks.fetch_add(1);
+    return rc;
 }
 
 extern "C" void ffs_stack3d_destroy(ffs_stack3d* st) {
     if (!st) return;
+    g_live_stacks.fetch_sub(1);
     ffs_ctx* c = st->ctx;
     (void)hipSetDevice(c->device);
     {
@@ -509,6 +514,11 @@ static int stack3d_add_batch_impl(ffs_stack3d* st, ffs_stream* s) {
 
 extern "C" int ffs_stack3d_add_batch(ffs_stack3d* st, ffs_stream* s) {
     if (!st || !s) return FFS_ERR_INVALID;
+    if (!s->lists_valid) {   // (the stack was created after the batch was submitted, or tuning "device_lists" is 0)
+        s->ctx->err = "ffs_stack3d_add_batch: this batch did not leave its strong-pixel lists on the device -- create the stack before "
+                      "submitting (tuning \"device_lists\" 2) or set \"device_lists\" to 1";
+        return FFS_ERR_INVALID;
+    }
     return guarded(s->ctx, [&] { return stack3d_add_batch_impl(st, s); });
 }
 

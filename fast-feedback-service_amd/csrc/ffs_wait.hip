@@ -344,6 +344,10 @@ extern "C" int ffs_stream_debug_bitplane(ffs_stream* s, uint32_t frame, int whic
         return FFS_ERR_INVALID;
     }
     HIP_TRY(c, hipSetDevice(c->device));
+    if (which == 0 && s->bits_cleared && !s->dense_valid && !s->lists_valid) {
+        c->err = "ffs_stream_debug_bitplane: the batch kept neither the byte mask nor the strong-pixel list (want_strong_mask / want_strong_list)";
+        return FFS_ERR_INVALID;
+    }
     if (which == 0 && s->bits_cleared && !s->dense_valid) {
         // the compaction consumed (and cleared) the plane and nobody asked for the byte mask: the strong-pixel list has them
         const uint32_t ns = std::min<uint32_t>(s->h_counts[frame], s->cap);

@@ -720,7 +720,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                                     const int b = __ffs((int)w) - 1;
                                     w &= w - 1;
                                     const uint32_t x = ge * 8u + (uint32_t)b;
-                                    if (at < a.cap) gk[at] = (uint32_t)row * W + x;
+                                    if (a.need_lists && at < a.cap) gk[at] = (uint32_t)row * W + x;
                                     if (at < (uint32_t)kChainLdsEntries) s_x[at] = (uint16_t)x;
                                     if (a.dense_bytes) sbytes[(uint64_t)row * a.bpitch + x] = 1;
                                     ++at;
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                 const uint32_t root = uf_find(spar, i0 + q);
                 set_id(q, root);
                 mine += root == i0 + q ? 1u : 0u;
-                gi[i0 + q] = get_i(q);
+                if (!LOG || a.need_lists) gi[i0 + q] = get_i(q);
             }
         }
         __syncthreads();   // every find is done: the forest's root slots now take the component numbers

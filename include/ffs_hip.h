@@ -155,6 +155,9 @@ int ffs_ctx_set_params(ffs_ctx *ctx, const ffs_params *p);
  *   "ext_first_pass"   (2) extended algorithm, 16-bit pixels: 2 = streaming kernel, 0 = plain one-pixel-per-lane kernel
  *   "sparse_stage"     (2) one launch per batch, a workgroup per frame: 3 = always, 2 = unless the stream's previous batch
  *                          held a frame with more strong pixels than that workgroup's LDS holds; 1 = four grid-wide kernels
+ *   "device_lists"     (2) a batch leaves its strong-pixel lists on the device: 1 = always, 0 = only when the host asked for them
+ *                          (want_strong_list), 2 = also while a 3D stack of the process is alive (ffs_stack3d_add_batch reads them:
+ *                          create the stack before submitting).  Without them the sparse launch saves two scattered stores per pixel
  *   "strong_log"       (1) 16-bit standard path: the streaming kernel appends its strong groups to per-wave logs which the
  *                          one-launch sparse stage merges (dense stores; the kernel's time no longer depends on where the
  *                          stream's buffers lie); 0 = plane bytes, counters and an occupancy bitmap as in rounds 1-3b
