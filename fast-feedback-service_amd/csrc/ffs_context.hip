@@ -305,7 +305,7 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     // (d_n_comp, d_summary and d_overflow live inside the d_num_strong allocation)
     if (s->h_pack_tab) (void)hipHostFree(s->h_pack_tab);
     // (the stream's device buffers are one slab; what is allocated on first use is freed by itself)
-    void* dev[] = {s->d_slab, s->d_pack_k, s->d_pack_i, s->d_pack_tab, s->d_comp, s->d_tab, s->d_dplane, s->d_eplane, s->d_wlog, s->d_wlog_n};
+    void* dev[] = {s->d_slab, s->d_pack_k, s->d_pack_i, s->d_pack_tab, s->d_comp, s->d_tab, s->d_dplane, s->d_eplane, s->d_wlog, s->d_wlog_n, s->d_wpix};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     void* host[] = {s->h_tab, s->h_counts, s->h_recs, s->h_list_k, s->h_list_i, s->h_mask};

@@ -99,6 +99,7 @@ struct ThresholdArgs {
     // (or undecided) pixel to its own log -- dense stores; kernels_chain.hpp merges the logs of a frame
     uint2* wlog;               // [waves][kWlogCap] (row << 16 | group, frame in super row << 16 | undecided << 8 | strong); nullptr: off
     uint32_t* wlog_n;          // [waves] entries a wave wanted to write (more than kWlogCap: overflow)
+    uint4* wpix;               // [waves][kWlogCap] the entry's eight (masked) pixels: the sparse launch never gathers from the image
     int dbg;                   // timing experiments (-DFFS_EXPERIMENTS builds only; results are wrong when set)
 };
 

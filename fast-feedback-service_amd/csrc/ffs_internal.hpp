@@ -150,6 +150,7 @@ struct ffs_stream {
     bool log_off = false;                    // the wave logs could not serve a batch of this stream (dense frames, a log overflow): the plane from then on
     uint2* d_wlog = nullptr;                 // wave logs of the streaming kernel (allocated on first use, sized for the launch geometry)
     uint32_t* d_wlog_n = nullptr;
+    uint4* d_wpix = nullptr;
     size_t wlog_waves = 0;
     bool force_grid = false;                 // the next enqueue takes the grid-wide sparse kernels (a frame's runs overflowed the one launch)
     bool runs_overflowed = false;            // ... and dense batches of this stream keep taking them

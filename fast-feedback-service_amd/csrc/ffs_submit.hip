@@ -209,11 +209,14 @@ bool wave_logs_for(ffs_stream* s, ThresholdArgs& a, uint32_t n_frames) {
             (void)hipStreamSynchronize(s->st2);
             (void)hipFree(s->d_wlog);
             (void)hipFree(s->d_wlog_n);
+            (void)hipFree(s->d_wpix);
             s->d_wlog = nullptr;
             s->d_wlog_n = nullptr;
+            s->d_wpix = nullptr;
         }
         s->wlog_waves = 0;
         if (hipMalloc(reinterpret_cast<void**>(&s->d_wlog), waves * kWlogCap * sizeof(uint2)) != hipSuccess
+            || hipMalloc(reinterpret_cast<void**>(&s->d_wpix), waves * kWlogCap * sizeof(uint4)) != hipSuccess
             || hipMalloc(reinterpret_cast<void**>(&s->d_wlog_n), waves * 4) != hipSuccess) {
             (void)hipGetLastError();
             return false;
@@ -222,6 +225,7 @@ bool wave_logs_for(ffs_stream* s, ThresholdArgs& a, uint32_t n_frames) {
     }
     a.wlog = s->d_wlog;
     a.wlog_n = s->d_wlog_n;
+    a.wpix = s->d_wpix;
     return true;
 }
 

@@ -702,6 +702,10 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                             const bool have = band_entry(sb + (uint32_t)(c * 64 + lane), nb, k, e);
                             const int row = (int)(v.x >> 16);
                             const bool mine = have && (v.y >> 16) == l_fe && row >= r0 && row < r1 && k < ns;
+                            // the group's pixels, as the streaming kernel had them (on their way while the scans below run): the
+                            // intensity list is written here, in list order, and phase P never gathers from the image
+                            uint4 px = make_uint4(0u, 0u, 0u, 0u);
+                            if (mine) px = T.wpix[(uint64_t)log_wave(band, k) * kWlogCap + e];
                             const uint32_t cb = mine ? v.y & 0xFFu : 0u;
                             const uint32_t pc = (uint32_t)__popc(cb);
                             const uint32_t incl = wave_inclusive_scan(pc), excl = incl - pc;
@@ -720,6 +724,8 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                                     const int b = __ffs((int)w) - 1;
                                     w &= w - 1;
                                     const uint32_t x = ge * 8u + (uint32_t)b;
+                                    const uint32_t pw = b < 2 ? px.x : b < 4 ? px.y : b < 6 ? px.z : px.w;
+                                    if (at < a.cap) gi[at] = (b & 1) ? pw >> 16 : pw & 0xFFFFu;
                                     if (a.need_lists && at < a.cap) gk[at] = (uint32_t)row * W + x;
                                     if (at < (uint32_t)kChainLdsEntries) s_x[at] = (uint16_t)x;
                                     if (a.dense_bytes) sbytes[(uint64_t)row * a.bpitch + x] = 1;
@@ -846,6 +852,13 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
             }
         }
         const rsrc_t r_img = make_rsrc(img, (uint32_t)a.H * a.pitch);
+        if constexpr (LOG) {
+            // (phase L2 wrote the intensity list from the logs: this thread's entries are consecutive dwords of it)
+            const rsrc_t r_gi = make_rsrc(gi, a.cap * 4u);
+#pragma unroll
+            for (int q = 0; q < kChainPer; ++q)
+                ew[q] = (__builtin_amdgcn_raw_buffer_load_b32(r_gi, i0 + q < i1 ? (i0 + (uint32_t)q) * 4u : kOob, 0, 0) & 0xFFFFu) | 0xFFFF0000u;
+        } else {
 #pragma unroll
         for (int q = 0; q < kChainPer; ++q) {
             const uint32_t y = exy[q] >> 16, x = exy[q] & 0xFFFFu;
@@ -855,6 +868,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
             else v = __builtin_amdgcn_raw_buffer_load_b32(r_img, off, 0, 0);
             ew[q] = v;
         }
+        }
         uint32_t mine = 0;
 #pragma unroll
         for (int q = 0; q < kChainPer; ++q) {
@@ -862,7 +876,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                 const uint32_t root = uf_find(spar, i0 + q);
                 set_id(q, root);
                 mine += root == i0 + q ? 1u : 0u;
-                if (!LOG || a.need_lists) gi[i0 + q] = get_i(q);
+                if constexpr (!LOG) gi[i0 + q] = get_i(q);
             }
         }
         __syncthreads();   // every find is done: the forest's root slots now take the component numbers

@@ -445,7 +445,10 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
             const unsigned long long wm = __builtin_amdgcn_ballot_w64(cbm != 0u);
             if (cbm != 0u) {
                 const uint32_t at = nlog + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u));
-                if (at < (uint32_t)kWlogCap) a.wlog[(uint64_t)wave_id * kWlogCap + at] = make_uint2((row << 16) | ge, (fe << 16) | cbm);
+                if (at < (uint32_t)kWlogCap) {
+                    a.wlog[(uint64_t)wave_id * kWlogCap + at] = make_uint2((row << 16) | ge, (fe << 16) | cbm);
+                    a.wpix[(uint64_t)wave_id * kWlogCap + at] = make_uint4(s_q[8][lane], s_q[9][lane], s_q[10][lane], s_q[11][lane]);   // the group's pixels
+                }
             }
             nlog += (uint32_t)__popcll(wm);   // (queue entries are in (row, lane) order, so the log is sorted by (row, frame, group))
             qn = 0;
