@@ -17,8 +17,9 @@ bool chain_prepare_device() {   // more than 64 KB of dynamic LDS has to be aske
     const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
     const hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
     const hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint16_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
+    const hipError_t e5 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frame_chain<uint32_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainDynBytes);
     (void)hipGetLastError();
-    return e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && e4 == hipSuccess;
+    return e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && e4 == hipSuccess && e5 == hipSuccess;
 }
 
 ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t pitch, size_t fstride, uint32_t n_frames) {
@@ -197,9 +198,9 @@ int ensure_extended_buffers(ffs_stream* s) {
 bool wave_logs_for(ffs_stream* s, ThresholdArgs& a, uint32_t n_frames) {
     ffs_ctx* c = s->ctx;
     const Layout& L = c->L;
-    if (!(c->tune.strong_log != 0 && c->pixel_bytes == 2 && !a.bright_to_plane && !s->log_off && !s->plane_once && s->st2 != s->st && c->chain_ok
+    if (!(c->tune.strong_log != 0 && !a.bright_to_plane && !s->log_off && !s->plane_once && s->st2 != s->st && c->chain_ok
           && s->batch_params.algorithm != FFS_ALGO_DISPERSION_EXTENDED && c->n_tiles <= kChainMaxTiles && L.H <= kChainMaxRows
-          && (uint32_t)a.gpf / (uint32_t)kSOwned + 2u <= 12u && a.band_rows <= 1024 && L.W <= 65535))
+          && (uint32_t)a.gpf / (uint32_t)kSOwned + 2u <= 16u && a.band_rows <= 1024 && L.W <= 65535))
         return false;
     const dim3 g = stream_grid(a, n_frames);
     const size_t waves = (size_t)g.x * g.y;
@@ -441,7 +442,8 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
             // the launch's start event belongs to the context (ffs_internal.hpp); published under the lock the waiting side takes
             std::lock_guard<std::mutex> lock(c->stream_mu);
             const int slot = (int)(c->chain_ev_next.fetch_add(1) % ffs_ctx::kChainEvents);
-            if (use_log) hipExtLaunchKernelGGL((k_frame_chain<uint16_t, false, true>), dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
+            if (use_log && c->pixel_bytes == 2) hipExtLaunchKernelGGL((k_frame_chain<uint16_t, false, true>), dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
+            else if (use_log) hipExtLaunchKernelGGL((k_frame_chain<uint32_t, false, true>), dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
             else if (c->pixel_bytes == 2 && runs_ok && (dense_batch || c->tune.chain_runs == 2)) hipExtLaunchKernelGGL((k_frame_chain<uint16_t, true>), dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
             else if (c->pixel_bytes == 2) hipExtLaunchKernelGGL(k_frame_chain<uint16_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
             else hipExtLaunchKernelGGL(k_frame_chain<uint32_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);

@@ -285,6 +285,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
         return f < nb;
     };
     constexpr int kLogChunks = 8;
+    [[maybe_unused]] constexpr uint32_t kGroupPx = sizeof(PixelT) == 2 ? 8u : 4u;   // pixels of a lane group of the streaming kernels
     // eight chunks (64 entries each) of the band's row of entries from `sb` on, all loads issued before any is used;
     // entries past the end read as "frame 0xFFFF" (nobody's)
     [[maybe_unused]] auto load_chunks = [&](int band, uint32_t sb, uint32_t nb, uint2 (&ent)[kLogChunks]) {
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                 uint2* ent = T.wlog + (uint64_t)log_wave((int)(it >> 16), (it >> 12) & 15u) * kWlogCap + ((it >> 3) & 0x1FFu);
                 const uint2 v = *ent;
                 const uint32_t row = v.x >> 16, ge = v.x & 0xFFFFu, b = it & 7u;
-                if (exact_strong<PixelT, false>(T, img, (int)(ge * 8u + b), (int)row)) {
+                if (exact_strong<PixelT, false>(T, img, (int)(ge * kGroupPx + b), (int)row)) {
                     atomicOr(&ent->y, 1u << b);   // (phase L2 reads the entry again; the "undecided" bits stay and are ignored)
                     atomicAdd(&s_row[row], 1u);
                 }
@@ -654,7 +655,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
         run_flag |= s_flag;
         if (!in_lds) run_flag |= 64u;   // (a frame beyond the LDS forest: this batch again through the plane; logs again when the data is sparse again)
         if (run_flag == 0 && total != 0) {
-            constexpr int kMaxStrips = 12;
+            constexpr int kMaxStrips = 16;
             uint16_t* s_x = reinterpret_cast<uint16_t*>(s_dyn + kChainStageOff);
             // per chain wave: cw[row of the band][strip] in the forest area (free until the forest is built)
             uint32_t* cw = reinterpret_cast<uint32_t*>(s_big) + (size_t)wave * (kChainForestBytes / 4 / kChainWaves);
@@ -723,9 +724,15 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                                 while (w) {
                                     const int b = __ffs((int)w) - 1;
                                     w &= w - 1;
-                                    const uint32_t x = ge * 8u + (uint32_t)b;
-                                    const uint32_t pw = b < 2 ? px.x : b < 4 ? px.y : b < 6 ? px.z : px.w;
-                                    if (at < a.cap) gi[at] = (b & 1) ? pw >> 16 : pw & 0xFFFFu;
+                                    const uint32_t x = ge * kGroupPx + (uint32_t)b;
+                                    uint32_t I;
+                                    if constexpr (sizeof(PixelT) == 2) {
+                                        const uint32_t pw = b < 2 ? px.x : b < 4 ? px.y : b < 6 ? px.z : px.w;
+                                        I = (b & 1) ? pw >> 16 : pw & 0xFFFFu;
+                                    } else {
+                                        I = b == 0 ? px.x : b == 1 ? px.y : b == 2 ? px.z : px.w;
+                                    }
+                                    if (at < a.cap) gi[at] = I;
                                     if (a.need_lists && at < a.cap) gk[at] = (uint32_t)row * W + x;
                                     if (at < (uint32_t)kChainLdsEntries) s_x[at] = (uint16_t)x;
                                     if (a.dense_bytes) sbytes[(uint64_t)row * a.bpitch + x] = 1;
@@ -857,7 +864,8 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
             const rsrc_t r_gi = make_rsrc(gi, a.cap * 4u);
 #pragma unroll
             for (int q = 0; q < kChainPer; ++q)
-                ew[q] = (__builtin_amdgcn_raw_buffer_load_b32(r_gi, i0 + q < i1 ? (i0 + (uint32_t)q) * 4u : kOob, 0, 0) & 0xFFFFu) | 0xFFFF0000u;
+                ew[q] = kPack ? (__builtin_amdgcn_raw_buffer_load_b32(r_gi, i0 + q < i1 ? (i0 + (uint32_t)q) * 4u : kOob, 0, 0) & 0xFFFFu) | 0xFFFF0000u
+                              : __builtin_amdgcn_raw_buffer_load_b32(r_gi, i0 + q < i1 ? (i0 + (uint32_t)q) * 4u : kOob, 0, 0);
         } else {
 #pragma unroll
         for (int q = 0; q < kChainPer; ++q) {
@@ -1209,6 +1217,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
 template __global__ void k_frame_chain<uint16_t, false>(const ChainArgs);
 template __global__ void k_frame_chain<uint16_t, true>(const ChainArgs);
 template __global__ void k_frame_chain<uint16_t, false, true>(const ChainArgs);
+template __global__ void k_frame_chain<uint32_t, false, true>(const ChainArgs);
 template __global__ void k_frame_chain<uint32_t, false>(const ChainArgs);
 
 }  // namespace ffsamd

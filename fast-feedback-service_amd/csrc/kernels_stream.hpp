@@ -646,7 +646,11 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
     const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
     const int strip = qb % a.n_strips;
     const int band = xcd + 8 * (qb / a.n_strips);
-    if (band >= a.n_bands) return;
+    [[maybe_unused]] const uint32_t wave_id = blockIdx.y * gridDim.x + blockIdx.x;
+    if (band >= a.n_bands) {
+        if (a.wlog && lane == 0) a.wlog_n[wave_id] = 0;   // (every wave of the grid has a count)
+        return;
+    }
     const int f0 = blockIdx.y * a.group_frames;
     const int nf = min(a.group_frames, a.n_frames - f0);
     const int yb0 = band * a.band_rows;
@@ -731,6 +735,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
     };
 
     int qn = 0;
+    uint32_t nlog = 0;   // entries of this wave's log (wave-uniform; ThresholdArgs::wlog)
     auto drain = [&]() {
         const bool have = lane < qn && !FFS_DBG(a, 2);
         uint32_t todo = 0, row = 0, fe = 0, ge = 0, info = 0;
@@ -762,6 +767,8 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
         if (__ballot(big) != 0ull) {
             if (big && a.bright_to_plane) {
                 s_q[10][lane] = (info >> 24) & 0xFu;   // every valid pixel of the group is a candidate for k_exact
+            } else if (big && a.wlog) {
+                s_q[10][lane] = ((info >> 24) & 0xFu) << 8;   // ... "undecided" in the group's log entry: the sparse launch gathers and decides
             } else if (big) {
                 for (uint32_t j = 0; j < 4; ++j) {
                     if (!((info >> (24 + j)) & 1u)) continue;   // (byte 3 = mask bits of the centre row)
@@ -799,6 +806,20 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
             }
         }
         __builtin_amdgcn_wave_barrier();
+        if (a.wlog) {   // (wave-uniform) wave logs instead of plane, counters and bitmap: see k_stream_u16
+            const uint32_t cbm = have ? s_q[10][lane] : 0u;   // strong | undecided << 8
+            const unsigned long long wm = __builtin_amdgcn_ballot_w64(cbm != 0u);
+            if (cbm != 0u) {
+                const uint32_t at = nlog + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u));
+                if (at < (uint32_t)kWlogCap) {
+                    a.wlog[(uint64_t)wave_id * kWlogCap + at] = make_uint2((row << 16) | ge, (fe << 16) | cbm);
+                    a.wpix[(uint64_t)wave_id * kWlogCap + at] = make_uint4(s_q[4][lane], s_q[5][lane], s_q[6][lane], s_q[7][lane]);   // the group's four pixels
+                }
+            }
+            nlog += (uint32_t)__popcll(wm);
+            qn = 0;
+            return;
+        }
         if (have) {
             const uint32_t cb = s_q[10][lane];
             if (cb) {  // the plane is all zero when the kernel starts; a lane pair shares a byte, so OR the nibble in
@@ -897,6 +918,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
     }
 rows_done:
     if (qn > 0) drain();
+    if (a.wlog && lane == 0) a.wlog_n[wave_id] = nlog;
 }
 
 template __global__ void k_bright_fix<uint16_t>(const ThresholdArgs);
