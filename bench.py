@@ -714,18 +714,18 @@ def main():
                 s = streams[step % len(streams)]
                 if len(inflight) == len(streams):
                     done = inflight.pop(0)
-                    res = done.wait(copy=False)
-                    gather(res, done)
-                    spots += sum(len(r.boxes) for r in res)
-                    strong_px += sum(r.num_strong_pixels for r in res)
+                    _, nbx, nst = done.wait_counts()      # (every frame's boxes and centroids are in the library's host arrays)
+                    gather(None, done)
+                    spots += nbx
+                    strong_px += nst
                 s.submit_device(ptr, pitch, fstride, B, first_frame_id=(rank * k + step) * B)
                 inflight.append(s)
             elif inflight:
                 done = inflight.pop(0)
-                res = done.wait(copy=False)
-                gather(res, done)
-                spots += sum(len(r.boxes) for r in res)
-                strong_px += sum(r.num_strong_pixels for r in res)
+                _, nbx, nst = done.wait_counts()
+                gather(None, done)
+                spots += nbx
+                strong_px += nst
         flush_gather()                   # every frame's spots are gathered before the clock stops
         return spots
 

@@ -219,6 +219,8 @@ struct ffs_stream {
     size_t cur_pitch = 0, cur_fstride = 0;
     ffs_params batch_params{};
     float timings[5] = {0, 0, 0, 0, 0};
+    bool timings_stale = false;              // the stage times of the last batch are still in its events (ffs_stream_timings reads them out)
+    hipEvent_t timing_last = nullptr;
     // results
     std::vector<ffs_frame_result> results;
     std::vector<ffs_box> boxes;

@@ -190,38 +190,42 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
         HIP_TRY(c, hipEventSynchronize(s->ev[5]));
         last = s->ev[5];
     }
-    s->timings[0] = 0.0f;
-    if (!s->dev_input) (void)hipEventElapsedTime(&s->timings[0], s->ev[0], s->ev[1]);
-    (void)hipEventElapsedTime(&s->timings[1], s->ev[1], s->ev[2]);
-    (void)hipEventElapsedTime(&s->timings[2], s->ev[2], s->ev3_is_ev4 ? s->ev[4] : s->ev[3]);
-    (void)hipEventElapsedTime(&s->timings[3], s->ev3_is_ev4 ? s->ev[4] : s->ev[3], last);
-    (void)hipEventElapsedTime(&s->timings[4], s->dev_input ? s->ev[1] : s->ev[0], last);
+    // (the five stage times are read out of the events by ffs_stream_timings() when somebody asks: five runtime calls per
+    // batch that the last wait of a run pays on the clock)
+    s->timing_last = last;
+    s->timings_stale = true;
 
     // assemble: boxes = components surviving the min-size filter (connected_components.cc:122-135),
     // reflections = components surviving filter_reflections (:207-236); both keep label order.
+    // (written through raw pointers into arrays sized for the worst case: 45 000 records per batch of the bench frames, and the
+    // last wait of a run does this on the clock -- push_back's capacity check per record was a third of it)
     s->results.assign(n, ffs_frame_result{});
-    s->boxes.clear();
-    s->refls.clear();
-    s->boxes.reserve(total_recs);
-    if (p.want_reflections) s->refls.reserve(total_recs);
+    size_t extra = 0;
+    for (const OverflowFrame& o : s->ovf) extra += o.boxes.size();
+    s->boxes.resize(total_recs + extra);
+    if (p.want_reflections) s->refls.resize(total_recs + extra); else s->refls.clear();
     std::vector<size_t> box_at(n), refl_at(n);
+    ffs_box* bo = s->boxes.data();
+    ffs_reflection* ro = s->refls.data();
+    size_t nbx = 0, nrf = 0;
+    const uint32_t min_size = p.min_spot_size;
+    const bool want_refl = p.want_reflections != 0;
     const WireRec2* wrec = reinterpret_cast<const WireRec2*>(s->h_recs);
     for (uint32_t f = 0; f < n; ++f) {
-        box_at[f] = s->boxes.size();
-        refl_at[f] = s->refls.size();
+        box_at[f] = nbx;
+        refl_at[f] = nrf;
         const uint32_t nc = std::min<uint32_t>(h_nc[f], s->max_comp);
         if (s->chain_mode) wrec = reinterpret_cast<const WireRec2*>(s->h_recs) + (size_t)f * s->max_comp;  // k_frame_chain: every frame has its own record area
         if (const OverflowFrame* o = overflow_frame(f)) {  // re-run on the one-frame stream: skip the cut records
             wrec += nc;
-            s->boxes.insert(s->boxes.end(), o->boxes.begin(), o->boxes.end());
-            if (p.want_reflections) s->refls.insert(s->refls.end(), o->refls.begin(), o->refls.end());
+            for (const ffs_box& b : o->boxes) bo[nbx++] = b;
+            if (want_refl) for (const ffs_reflection& r : o->refls) ro[nrf++] = r;
             continue;
         }
         for (uint32_t q = 0; q < nc; ++q, ++wrec) {
             const uint32_t npx = wrec->npx_flags & 0x3FFFFFFFu, flags = wrec->npx_flags >> 30;
-            if (p.min_spot_size == 0 || npx >= p.min_spot_size)
-                s->boxes.push_back(ffs_box{wrec->x_min, wrec->y_min, wrec->x_max, wrec->y_max, (int32_t)npx});
-            if (p.want_reflections && flags == 0) {
+            if (min_size == 0 || npx >= min_size) bo[nbx++] = ffs_box{wrec->x_min, wrec->y_min, wrec->x_max, wrec->y_max, (int32_t)npx};
+            if (want_refl && flags == 0) {
                 ffs_reflection r{};
                 r.x_min = wrec->x_min; r.x_max = wrec->x_max; r.y_min = wrec->y_min; r.y_max = wrec->y_max;
                 r.z_min = 0; r.z_max = 0;
@@ -232,10 +236,12 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
                 r.peak_centroid_distance = wrec->peak_centroid_distance;
                 r.flags = 0;
                 r.sum_intensity = wrec->sum_intensity;
-                s->refls.push_back(r);
+                ro[nrf++] = r;
             }
         }
     }
+    s->boxes.resize(nbx);
+    if (want_refl) s->refls.resize(nrf);
     for (uint32_t f = 0; f < n; ++f) {
         ffs_frame_result& r = s->results[f];
         const uint32_t* sm = h_sm + (size_t)f * 8;
@@ -286,6 +292,17 @@ extern "C" int ffs_stream_batch_arrays(ffs_stream* s, const ffs_box** boxes, uin
 
 extern "C" int ffs_stream_timings(ffs_stream* s, float ms[5]) {
     if (!s || !ms) return FFS_ERR_INVALID;
+    if (s->timings_stale && !s->busy) {   // (the events of the last batch waited for; a new submit re-records them)
+        (void)hipSetDevice(s->ctx->device);
+        s->timings[0] = 0.0f;
+        if (!s->dev_input) (void)hipEventElapsedTime(&s->timings[0], s->ev[0], s->ev[1]);
+        (void)hipEventElapsedTime(&s->timings[1], s->ev[1], s->ev[2]);
+        (void)hipEventElapsedTime(&s->timings[2], s->ev[2], s->ev3_is_ev4 ? s->ev[4] : s->ev[3]);
+        (void)hipEventElapsedTime(&s->timings[3], s->ev3_is_ev4 ? s->ev[4] : s->ev[3], s->timing_last);
+        (void)hipEventElapsedTime(&s->timings[4], s->dev_input ? s->ev[1] : s->ev[0], s->timing_last);
+        (void)hipGetLastError();
+        s->timings_stale = false;
+    }
     std::memcpy(ms, s->timings, sizeof(s->timings));
     return FFS_OK;
 }
