@@ -36,13 +36,13 @@ for rep in range(3):
     infl = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    subs, dones = [], []
     for step in range(K):
         s = streams[step % 4]
         if len(infl) == 4:
-            infl.pop(0).wait(copy=False)
-        s.submit_device(ptr, pitch, fstride, B, step); infl.append(s)
-    t_last_submit = time.perf_counter()
-    marks = []
+            infl.pop(0).wait_counts(); dones.append(time.perf_counter() - t0)
+        s.submit_device(ptr, pitch, fstride, B, step); infl.append(s); subs.append(time.perf_counter() - t0)
     for h in infl:
-        h.wait(copy=False); marks.append(time.perf_counter())
-    print(f"K={K}: last submit at {1e3*(t_last_submit-t0):.3f} ms, the four last waits return at " + ", ".join(f"{1e3*(m-t0):.3f}" for m in marks) + f" ms; per step {1e3*(marks[-1]-t0)/K:.4f} ms")
+        h.wait_counts(); dones.append(time.perf_counter() - t0)
+    print(f"K={K}: per step {1e3*dones[-1]/K:.4f} ms; batches done at (ms): " + " ".join(f"{1e3*d:.2f}" for d in dones))
+    print("      submits at (ms): " + " ".join(f"{1e3*d:.2f}" for d in subs))
