@@ -14,7 +14,7 @@
 // denser frames run the stages on the global arrays), and the accumulators of 832 components at a time do too.
 //
 // Phases (separated by __syncthreads(), which also orders the block's global writes):
-//   B  (only while few batches are in flight, see ffs_api.hip) the bright-window fix-up, k_bright_fix's work, for the
+//   B  (only while few batches are in flight, see ffs_submit.hip) the bright-window fix-up, k_bright_fix's work, for the
 //      listed pixels of this frame; the last workgroup through with the list empties it
 //   A  exclusive scan of the frame's per-tile counts (the streaming kernel's atomics) -> tile offsets in LDS; the
 //      counts are zeroed for the next batch
@@ -32,6 +32,16 @@
 //      per component writes its 40-byte record, the records leave as consecutive dwords
 //   and for denser frames: R' accumulators at the root's list index in global memory, F' records chunk by chunk
 //   (the bodies of k_reduce_roots / k_finalize_roots).
+// Three instantiations (template parameters RUNS, LOG):
+//   plain        the phases above: the streaming kernels' (or the extended algorithm's) bit plane, forest over pixels
+//   RUNS         frames of 16-bit pixels beyond the LDS forest of pixels: phases E' X' U' P' R' over RUNS of strong pixels (a
+//                run = a maximal row of strong pixels inside one 32-pixel plane word: 61 k pixels are 12 k runs on the extended
+//                algorithm's bench frames)
+//   LOG          the standard path (round 3c): no plane at all -- the streaming kernel appends its strong groups, with their
+//                pixels, to per-wave logs (ThresholdArgs::wlog / wpix); phases L1 (per-row counts; undecided bright-window
+//                pixels listed and decided one per thread) and, after S, L2 (the logs of the strips of every band merged into
+//                the raster-order list, column numbers into LDS, intensity list from the logged pixels) replace B, A, E, X and
+//                the image gathers of P
 // Frame f's records start at f * max_comp of the (host) record buffer -- no frame waits for another's count -- and
 // counters and flags go straight into the pinned block ffs_wait() reads: no copy follows the kernel.
 // Results are those of the four-kernel chain bit for bit (same edges, same integer accumulators, same order).

@@ -1,4 +1,4 @@
-// kernels_decode.hpp (included by ffs_api.hip) -- bitshuffle-LZ4 chunk decode on the GPU.
+// kernels_decode.hpp (included by ffs_submit.hip) -- bitshuffle-LZ4 chunk decode on the GPU.
 //
 // What the reference does: every worker thread decompresses its frame on the CPU,
 // bshuf_decompress_lz4(buffer + 12, host_image, W*H, sizeof(pixel_t), 0) (spotfinder.cc:823-842,

@@ -1,4 +1,4 @@
-// kernels_extended.hpp (included by ffs_api.hip) -- the extended dispersion algorithm
+// kernels_extended.hpp (included by ffs_submit.hip) -- the extended dispersion algorithm
 // (`-a dispersion_extended`) for gfx950.
 //
 // What the reference does: DispersionExtendedThreshold::threshold, baseline/spotfinder/baseline.cpp:730-761
