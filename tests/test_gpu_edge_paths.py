@@ -461,3 +461,37 @@ def test_sparse_and_dense_batches_alternate_on_one_stream(ffs):
         res = st.process(np.stack(batch), first_frame_id=10 * k)
         for fr, img in zip(res, batch):
             assert_frame_matches_oracle(fr, img, ones, min_spot_size=2)
+
+
+def test_stack_created_after_the_batch_is_refused(ffs):
+    """Tuning `device_lists` (default 2): a batch leaves its strong-pixel lists on the device while a 3D stack is alive or the
+    host asked for them.  A stack created AFTER the batch was submitted cannot take that batch (an error that says so, not
+    garbage); the next batch is fine, and with `want_strong_list` the lists are always there."""
+    from ffs_amd.api import FfsError
+    W, H = 400, 300
+    frames = np.stack([make_frame(W=W, H=H, seed=500 + i, n_spots=25)[0] for i in range(2)])
+    ctx = ffs.Context(W, H, np.uint16, max_batch=2)
+    st = ctx.stream()
+    st.process(frames, first_frame_id=0)              # no stack alive, no list asked for
+    stack = ffs.Stack3D(ctx)
+    with pytest.raises(FfsError, match="strong-pixel lists"):
+        stack.add_batch(st)
+    st.process(frames, first_frame_id=0)
+    stack.add_batch(st)                                # submitted while the stack was alive
+    refl, n_calc, _, _ = stack.finish()
+    from oracle import oracle as O
+    lists = []
+    for img in frames:
+        strong = O.dispersion(img, np.ones((H, W), np.uint8))
+        k = np.flatnonzero(strong).astype(np.uint64)
+        lists.append((k, img.ravel()[k].astype(np.uint32)))
+    want = O.cc3d(lists, W, H, 3, 2.0)
+    assert n_calc == want.n_calculated
+    del stack
+    ctx2 = ffs.Context(W, H, np.uint16, max_batch=2)
+    ctx2.set_params(want_strong_list=1)
+    st2 = ctx2.stream()
+    st2.process(frames, first_frame_id=0)
+    stack2 = ffs.Stack3D(ctx2)
+    stack2.add_batch(st2)                              # the host asked for the lists: they are on the device
+    assert stack2.finish()[1] == want.n_calculated
