@@ -392,7 +392,9 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
     // (the byte mask: zero-filled by the streaming kernels only when asked for; the exact stages always produce it)
     ca.dense_bytes = ((list_path || (ext && ext_stream_first(ta))) ? ta.dense_mask : 1) ? 1 : 0;
     ca.need_lists = (p.want_strong_list || c->tune.device_lists == 1 || (c->tune.device_lists == 2 && g_live_stacks.load() > 0)) ? 1 : 0;
-    s->lists_valid = !use_log || ca.need_lists != 0;   // (only the launch that merges wave logs can do without them)
+    // (the launch that merges wave logs and the run-based launch of dense frames can do without the lists)
+    const bool runs_launch = will_chain && !use_log && c->pixel_bytes == 2 && runs_ok && (dense_batch || c->tune.chain_runs == 2);
+    s->lists_valid = !(use_log || runs_launch) || ca.need_lists != 0;
     s->dense_valid = ca.dense_bytes != 0;
     ca.occ = s->d_occ;
     ca.occ_frame_words = occ_frame_words(L);

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                         while (w) {
                             const int b = __ffs((int)w) - 1;
                             w &= w - 1;
-                            if (at < a.cap) gk[at] = (uint32_t)y * W + (uint32_t)(xb + b);
+                            if (a.need_lists && at < a.cap) gk[at] = (uint32_t)y * W + (uint32_t)(xb + b);   // (the run-based phases never read the pixel list)
                             if (a.dense_bytes) sbytes[(uint64_t)y * a.bpitch + (uint32_t)(xb + b)] = 1;
                             ++at;
                         }
@@ -991,7 +991,8 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
                     base += cnt;
                 }
                 // the intensity list (for the consumers of the pixel lists: nothing below reads it)
-                for (uint32_t i = tid; i < n; i += kChainThreads) gi[i] = pixel_at(gk[i]);
+                if (a.need_lists)
+                    for (uint32_t i = tid; i < n; i += kChainThreads) gi[i] = pixel_at(gk[i]);
             }
             __syncthreads();
             const uint32_t per = (nr + kChainThreads - 1) / kChainThreads;   // <= kChainRunPer
