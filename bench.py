@@ -300,22 +300,52 @@ def cli_e2e(n_images=1000, threads=None, batch=None, cpu_decode_images=256, keep
         if r.returncode != 0:
             return {"error": "ffs_hosttool mkshm failed: " + (r.stdout + r.stderr)[-300:]}
         # every frame its own file, as a detector writes them (symbolic links to 32 files -- round 2 and 3a -- kept the whole
-        # data set in the page cache's hot end and half of it in L3)
+        # data set in the page cache's hot end and half of it in L3).  tmpfs pages are charged to this job's memory: the long run
+        # is shrunk (or dropped) when the files would not fit what the file system and the memory cgroup have left, and a copier
+        # thread's error ends the leg at once instead of leaving spotfinder waiting for images that never come.
+        chunk = os.path.getsize(os.path.join(shm, "image_000000_2"))
+        room = shutil.disk_usage(work).free
+        for lim in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+            try:
+                v = open(lim).read().strip()
+                if v != "max":
+                    used = 0
+                    for cur in ("/sys/fs/cgroup/memory.current", "/sys/fs/cgroup/memory/memory.usage_in_bytes"):
+                        if os.path.exists(cur):
+                            used = int(open(cur).read().strip())
+                            break
+                    room = min(room, int(v) - used)
+                break
+            except (OSError, ValueError):
+                continue
+        fit = int(room * 0.6 // max(chunk, 1))          # (leave room for the GPU legs that follow: pinned frames, torch)
+        if long_images > n_images and long_images > fit:
+            out["long_run_shrunk"] = f"{long_images} -> {max(fit, 0)} images: {room / 1e9:.1f} GB left in {base or 'tmp'} / the memory cgroup"
+            long_images = fit if fit > n_images else 0
+        if n_images > fit:
+            return dict(out, error=f"{n_images} chunk files of {chunk / 1e6:.1f} MB do not fit the {room / 1e9:.1f} GB left in {base or 'tmp'} / the memory cgroup")
         n_files = max(n_images, long_images)
+        copy_errors = []
 
         def copy_range(lo, hi):
-            for i in range(lo, hi):
-                shutil.copyfile(os.path.join(shm, f"image_{i % 32:06d}_2"), os.path.join(shm, f"image_{i:06d}_2"))
+            try:
+                for i in range(lo, hi):
+                    if copy_errors:
+                        return
+                    shutil.copyfile(os.path.join(shm, f"image_{i % 32:06d}_2"), os.path.join(shm, f"image_{i:06d}_2"))
+            except OSError as e:
+                copy_errors.append(f"{type(e).__name__}: {e}")
         step = (n_files - 32 + 7) // 8
         copiers = [threading.Thread(target=copy_range, args=(32 + k * step, min(32 + (k + 1) * step, n_files))) for k in range(8)]
         for t in copiers:
             t.start()
         for t in copiers:
             t.join()
+        if copy_errors:
+            return dict(out, error="writing the chunk files failed: " + copy_errors[0])
         hdr = open(os.path.join(shm, "start_1")).read()
         open(os.path.join(shm, "start_1"), "w").write(hdr.replace('"nimages": 32', f'"nimages": {max(n_images, long_images)}'))
         out["prepare_s"] = round(time.perf_counter() - t0, 1)
-        chunk = os.path.getsize(os.path.join(shm, "image_000000_2"))
         out["chunk_MB"] = round(chunk / 1e6, 2)
 
         def run(extra, images):
@@ -498,6 +528,17 @@ def bench_single_process(args):
         el, last = region(args.steps)
         times.append(el)
     el2, _ = region(2 * args.steps)
+    # self-check: each context's totals over its last timed region against the committed oracle results for its frames
+    from ffs_amd import fixtures
+    results_checked = True
+    for d in range(n):
+        exp = fixtures.load_expected(args.workload, args.algorithm, d, B)
+        if exp is None:
+            results_checked = None
+            break
+        want = (int(exp["n_boxes"].sum()) * args.steps, int(exp["num_strong_pixels"].sum()) * args.steps)
+        if tuple(int(v) for v in last[d]) != want:
+            results_checked = False
     med = statistics.median(times)
     steady = max(0.0, (el2 - med) / args.steps)
     out = {
@@ -514,9 +555,10 @@ def bench_single_process(args):
         "repetitions": {"n": len(times), "ms_per_step": [round(t / args.steps * 1e3, 4) for t in times], "value_from": "median"},
         "steady_ms_per_step": round(steady * 1e3, 4), "drain_ms": round(max(0.0, med - steady * args.steps) * 1e3, 4),
         "n_contexts_seen": n,
+        "results_checked": results_checked,
     }
     print(json.dumps(out), flush=True)
-    return 0
+    return 0 if results_checked is not False else 6
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -654,6 +696,26 @@ def main():
     ptr = d_frames.data_ptr()
     streams = [ctx.stream() for _ in range(max(1, args.streams))]
 
+    # ---- self-check (the reference's driver has one too, --validate: spotfinder/spotfinder.cc:1012-1053): every batch waited for
+    # inside the timed regions has its per-frame (n_boxes, num_strong_pixels) compared with the committed oracle results for these
+    # frames (tests/golden/bench_workloads.npz, generated by tests/golden/make_golden_bench.py), and after the timing one batch
+    # per stream has every box and reflection compared through their digests.  A mismatch fails the run.
+    from ffs_amd import fixtures
+    expected = fixtures.load_expected(args.workload, args.algorithm, rank, B)
+    check = {"batches": 0, "bad_batches": 0, "first_bad": None}
+
+    def check_counts(st):
+        if expected is None:
+            return
+        raw = st.last_frame_counts
+        check["batches"] += 1
+        if not (np.array_equal(raw["n_boxes"], expected["n_boxes"]) and np.array_equal(raw["num_strong_pixels"], expected["num_strong_pixels"])):
+            check["bad_batches"] += 1
+            if check["first_bad"] is None:
+                f = int(np.flatnonzero((raw["n_boxes"] != expected["n_boxes"]) | (raw["num_strong_pixels"] != expected["num_strong_pixels"]))[0])
+                check["first_bad"] = {"frame_in_batch": f, "got": [int(raw["n_boxes"][f]), int(raw["num_strong_pixels"][f])],
+                                      "want": [int(expected["n_boxes"][f]), int(expected["num_strong_pixels"][f])]}
+
     # ---- N>1: gather of the per-frame spot lists -------------------------------------------------
     # One RCCL collective per `gather_every` batches ("one small collective per batch of
     # frames, not per frame"): every rank contributes a fixed-size block of (frame_id, x, y, z) rows.
@@ -715,6 +777,7 @@ def main():
                 if len(inflight) == len(streams):
                     done = inflight.pop(0)
                     _, nbx, nst = done.wait_counts()      # (every frame's boxes and centroids are in the library's host arrays)
+                    check_counts(done)
                     gather(None, done)
                     spots += nbx
                     strong_px += nst
@@ -723,6 +786,7 @@ def main():
             elif inflight:
                 done = inflight.pop(0)
                 _, nbx, nst = done.wait_counts()
+                check_counts(done)
                 gather(None, done)
                 spots += nbx
                 strong_px += nst
@@ -763,6 +827,20 @@ def main():
     el2, _ = timed(2 * args.steps)
     steady = max(0.0, (el2 - elapsed) / args.steps)
     drain = max(0.0, elapsed - steady * args.steps)
+    digests_ok = None
+    if expected is not None:          # untimed: every box and reflection of one more batch per stream, through their digests
+        digests_ok = True
+        for st in streams:
+            st.submit_device(ptr, pitch, fstride, B, first_frame_id=0)
+        for st in streams:
+            for f, fr in enumerate(st.wait(copy=False)):
+                if fixtures.frame_digest(fr.boxes, fr.reflections) != expected["digest"][f].tobytes():
+                    digests_ok = False
+    results_checked = None if expected is None else bool(check["bad_batches"] == 0 and check["batches"] > 0 and digests_ok)
+    if dist is not None and expected is not None:     # every rank checks its own shard; the line reports all of them
+        t = torch.tensor([0 if results_checked else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        results_checked = bool(int(t.item()) == 0)
     n_ranks_seen = 1
     if use_dist and last_gather[0] is not None:
         torch.cuda.synchronize(dev)
@@ -886,6 +964,13 @@ def main():
             "steady_ms_per_step": round(steady * 1e3, 4),
             "drain_ms": round(drain * 1e3, 4),
             "n_ranks_seen": n_ranks_seen,
+            "results_checked": results_checked,
+            "results_check": ({"batches_compared_in_timed_regions": check["batches"], "bad_batches": check["bad_batches"],
+                               "first_bad": check["first_bad"], "digests_of_boxes_and_reflections_ok": digests_ok,
+                               "against": "tests/golden/bench_workloads.npz (oracle results for this rank's frames: reference standalone.cc "
+                                          "threshold + restated connected components; tests/golden/make_golden_bench.py)"}
+                              if expected is not None else
+                              {"skipped": "no committed oracle results for this workload / rank / batch size"}),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
@@ -937,6 +1022,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if results_checked is False:
+        print(f"bench.py rank {rank}: results differ from the oracle's ({check})", file=sys.stderr)
+        sys.exit(6)
 
 
 if __name__ == "__main__":

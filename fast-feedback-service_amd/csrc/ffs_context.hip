@@ -263,7 +263,7 @@ extern "C" int ffs_ctx_set_tuning(ffs_ctx* c, const char* key, long long value) 
     const std::string k = key;
     auto in = [&](long long lo, long long hi) { return value >= lo && value <= hi; };
     bool ok = true;
-    if (k == "threshold_path") { if ((ok = in(0, 1))) t.threshold_path = (int)value; }
+    if (k == "threshold_path") { if ((ok = in(0, 2))) t.threshold_path = (int)value; }
     else if (k == "ext_first_pass") { if ((ok = value == 0 || value == 2)) t.ext_first_pass = (int)value; }
     else if (k == "sparse_stage") { if ((ok = in(1, 3))) t.sparse_stage = (int)value; }
     else if (k == "device_lists") { if ((ok = in(0, 2))) t.device_lists = (int)value; }

@@ -69,7 +69,8 @@ struct ThresholdArgs {
     uint32_t ib2, is2;         // nsig_b^2, nsig_s^2
     uint32_t thr_floor;        // floor(threshold): for an integer pixel p, p > threshold <=> p > floor(threshold)
     int bright_to_plane;       // streaming kernels: 0 = bright windows go onto bright_list (k_bright_fix decides them);
-                               // 1 = they are marked in the plane as candidates and the exact kernel filters the plane
+                               // 1 = they are marked in the plane as candidates and the exact kernel filters the plane;
+                               // 2 (host side only) = the plane starts as the valid-pixel mask and the exact kernel decides every pixel
     // extended dispersion (kernels_extended.hpp)
     uint8_t* dplane;           // first-pass "not background" bit planes [n][H][mpitch]
     uint8_t* eplane;           // eroded signal-region bit planes [n][H][mpitch]

@@ -54,7 +54,8 @@ struct ThreadError {
 // experiments that break results exist only in -DFFS_EXPERIMENTS builds (`exp`, read from FFS_EXP_* there).
 struct Tuning {
     int threshold_path = 0;     // 0: bright windows -> list -> k_bright_fix; 1: bright windows -> plane -> k_exact (also the
-                                //    fall-back when the list overflows)
+                                //    fall-back when the list overflows); 2: no streaming kernel at all -- EVERY valid pixel is a candidate
+                                //    and k_exact gathers its window (the independent partner of `spotfinder --validate`; ~10 ms per frame)
     int ext_first_pass = 2;     // extended algorithm, 16-bit pixels: 2 = streaming kernel, 0 = k_ext_first
     int sparse_stage = 2;       // one launch per batch, a workgroup per frame (k_frame_chain): 3 = always, 2 = unless the stream's previous
                                 //    batch held a frame beyond its LDS forest; 1 = four grid-wide kernels

@@ -351,6 +351,17 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
         launch_stream(s, ta_launch, n, ev_start, s->ev[2]);
         HIP_TRY(c, hipStreamWaitEvent(s->st2, s->ev[2], 0));
         if (!chain_first && !use_log) launch_bright_fix(s, ta, s->st2);
+    } else if (ta.bright_to_plane == 2) {
+        // the cross-check path of `spotfinder --validate` (tuning "threshold_path" = 2): no streaming kernel, no screen, no LDS
+        // queue -- the plane starts as the valid-pixel mask, so k_exact gathers the window of EVERY valid pixel from memory and
+        // applies the oracle's predicate to 64-bit sums (exact_strong).  Shares nothing with the hot path but that predicate.
+        if (ev_start) HIP_TRY(c, hipEventRecord(ev_start, s->st));
+        HIP_TRY(c, hipMemsetAsync(s->d_sbytes, 0, (size_t)n * L.bytes_frame_stride, s->st));
+        for (uint32_t f = 0; f < n; ++f)
+            HIP_TRY(c, hipMemcpyAsync(s->d_bits + (size_t)f * L.plane_frame_stride, c->d_maskbits, L.plane_frame_stride, hipMemcpyDeviceToDevice, s->st));
+        launch_exact(s, ta, n, s->st);
+        HIP_TRY(c, hipEventRecord(s->ev[2], s->st));
+        if (s->st2 != s->st) HIP_TRY(c, hipStreamWaitEvent(s->st2, s->ev[2], 0));
     } else {
         launch_stream(s, ta, n, ev_start, nullptr);
         if (list_path) launch_bright_fix(s, ta, s->st);
@@ -400,7 +411,7 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
     ca.occ_frame_words = occ_frame_words(L);
     ca.occ_spr = L.mpitch / 16;
     // only the streaming kernels and their fix-up keep the bitmap (path 1: a superset of the final plane, which is fine)
-    ca.use_occ = c->tune.occupancy_bitmap ? 1 : 0;   // (kept by the streaming kernels, their fix-up and the extended algorithm's final pass)
+    ca.use_occ = (c->tune.occupancy_bitmap && ta.bright_to_plane != 2) ? 1 : 0;   // (kept by the streaming kernels, their fix-up and the extended algorithm's final pass)
     s->occ_dirty = !(ca.use_occ && will_chain);      // nobody consumes (and clears) the bits this batch sets
 
     SegArgs sa{};

@@ -59,6 +59,8 @@ struct Args {
     int pipe_fd = -1, device = 0;
     std::vector<int> devices;  // --devices / --gpus: the frame queue is dealt to all of them
     std::string algorithm = "dispersion", detector_json;
+    std::string max_valid = "trusted";   // trusted | none | N
+    uint32_t min_count = 2;
     bool cpu_decode = false, no_numa_pinning = false, single_buffer = false, all_threads = false, read_only = false;
 };
 
@@ -69,7 +71,14 @@ static void usage() {
       "                  [--min-spot-size-3d N] [--max-peak-centroid-separation N] [--start-index N]\n"
       "                  [-t S] [-fd FD] [-a ALGO] [--dmin MIN D] [--dmax MAX D] [-w \xce\xbb] [--detector JSON]\n"
       "                  [-h5] [--output-for-index] [--batch N] [--cpu-decode] [--strict-dtype]\n"
+      "                  [--max-valid trusted|none|N] [--min-count N]\n"
       "                  [--devices D0,D1,... | --gpus N] [--no-numa-pinning] [--single-buffer] [--all-threads] [--read-only]\n"
+      "--max-valid: a centre pixel above this value is never strong (the reference's kernels test it against the\n"
+      "              data set's trusted maximum).  trusted (default) = the frame source's trusted-range maximum when it is\n"
+      "              below the pixel type's maximum, none = no test (the CPU baseline's behaviour), N = this value\n"
+      "--min-count: valid pixels a 7x7 window needs (default 2, the CPU baseline's; the reference's kernels use 3)\n"
+      "--validate:  every image is also decided by an independent path (every valid pixel's window gathered from memory,\n"
+      "              no streaming kernel) and the two strong-pixel masks are compared: Match / Mismatch per image\n"
       "--devices / --gpus: one context and worker pool per GPU, all pulling frames from the one queue\n"
       "              (-n threads are dealt round-robin to the GPUs, at least one each); rotation sweeps send\n"
       "              their strong-pixel lists to the first GPU's 3D stack (RCCL over xGMI, else peer copies)\n"
@@ -159,6 +168,11 @@ static Args parse_args(int argc, char** argv) {
             while (std::getline(ss, tok, ',')) r.devices.push_back((int)u32(tok, s));
         }
         else if (s == "--strict-dtype") r.strict_dtype = true;
+        else if (s == "--max-valid") {
+            r.max_valid = need(i, s);
+            if (r.max_valid != "trusted" && r.max_valid != "none") (void)u32(r.max_valid, s);
+        }
+        else if (s == "--min-count") { r.min_count = u32(need(i, s), s); if (r.min_count < 2) arg_error("--min-count must be at least 2"); }
         else if (s == "--no-numa-pinning") r.no_numa_pinning = true;
         else if (s == "--single-buffer") r.single_buffer = true;
         else if (s == "--read-only") r.read_only = true;   // diagnostic: frames are read into the staging buffers and not submitted
@@ -380,8 +394,15 @@ int main(int argc, char** argv) {
     }
     const uint32_t num_images = args.images_set ? args.images : (uint32_t)reader.get_number_of_images();
     const uint32_t height = (uint32_t)reader.image_shape()[0], width = (uint32_t)reader.image_shape()[1];
+    // The reference hands the frame source's trusted maximum to every launch (spotfinder.cc:482,868,879) and its kernels
+    // refuse centre pixels above it (kernels/thresholding.cu:208-215).  Here: --max-valid trusted (default) does the same
+    // whenever that maximum says something, i.e. lies below the pixel type's own maximum (the reference narrows the int64 to
+    // pixel_t, spotfinder.cu:155,167 -- a cut-off above 65535 on 16-bit data wraps there; here it means "no pixel is above it").
     const int64_t trusted_px_max = reader.get_trusted_range()[1];
-    (void)trusted_px_max;
+    const int64_t type_max = bytes_per_pixel == 2 ? 65535ll : 4294967295ll;
+    int64_t max_valid = -1;   // < 0: no test
+    if (args.max_valid == "trusted") max_valid = (trusted_px_max >= 0 && trusted_px_max < type_max) ? trusted_px_max : -1;
+    else if (args.max_valid != "none") max_valid = std::stoll(args.max_valid);
 
     // ---- detector geometry / wavelength (spotfinder.cc:484-587) -----------------------------------
     DetectorGeometry detector;
@@ -490,10 +511,35 @@ int main(int argc, char** argv) {
     prm.want_reflections = (!rotation && (args.save_h5 || args.output_for_index)) ? 1 : 0;
     prm.want_strong_mask = args.writeout ? 1 : 0;
     prm.algorithm = algorithm;
+    prm.max_valid = max_valid;
+    prm.min_count = (int32_t)args.min_count;
+    if (args.validate) prm.want_strong_mask = 1;   // the masks are what --validate compares (spotfinder.cc:1012-1053)
     for (ffs_ctx* cx : ctxs) FFS_CHECK(cx, ffs_ctx_set_params(cx, &prm));
-    if (args.validate)
-        std::printf("Note: --validate is not linked into this build (the CPU baseline is test infrastructure: "
-                    "run `pytest -m gpu`, which compares every stage with it)\n");
+    if (max_valid >= 0) std::printf("Trusted range: centre pixels above %lld are not spots\n", (long long)max_valid);
+    // --validate (spotfinder.cc:1012-1053 compares every image with the CPU baseline, which is test infrastructure here and
+    // not linked into the product): every batch also goes through a second context per GPU whose threshold stage shares
+    // nothing with the hot path's but the predicate -- no streaming kernel, no screen, no queue: the window of EVERY valid
+    // pixel is gathered from memory (tuning "threshold_path" = 2; the extended algorithm: its plain one-pixel-per-lane first
+    // pass and the grid-wide sparse kernels) -- and the two strong-pixel masks are compared image by image.
+    std::vector<ffs_ctx*> vctxs(n_dev, nullptr);
+    if (args.validate) {
+        for (uint32_t di = 0; di < n_dev; ++di) {
+            if (ffs_ctx_create(devices[di], width, height, (int)bytes_per_pixel, batch, 0, &vctxs[di]) != FFS_OK) {
+                std::printf("Error: %s\n", ffs_last_error(nullptr));
+                return 1;
+            }
+            ffs_ctx* v = vctxs[di];
+            FFS_CHECK(v, ffs_ctx_set_tuning(v, "threshold_path", 2));
+            FFS_CHECK(v, ffs_ctx_set_tuning(v, "ext_first_pass", 0));
+            FFS_CHECK(v, ffs_ctx_set_tuning(v, "sparse_stage", 1));
+            FFS_CHECK(v, ffs_ctx_set_tuning(v, "strong_log", 0));
+            std::vector<uint8_t> m((size_t)width * height);   // the mask as the first context holds it (resolution filter included)
+            FFS_CHECK(ctxs[di], ffs_ctx_get_mask(ctxs[di], m.data()));
+            FFS_CHECK(v, ffs_ctx_set_mask(v, m.data()));
+            FFS_CHECK(v, ffs_ctx_set_params(v, &prm));
+        }
+        std::printf("Validation: every image is also decided by the gather path (every valid pixel's window summed from memory)\n");
+    }
     if (args.save_h5 && !h5_supported()) {
         std::printf("Error: --save-h5 needs an HDF5-enabled build\n");
         return 1;
@@ -561,7 +607,9 @@ int main(int argc, char** argv) {
         std::vector<const void*> chunk_ptr;
         std::vector<size_t> chunk_len;
         bool in_flight = false;
+        ffs_stream* v = nullptr;       // --validate: the same batch on the validation context
     };
+    std::atomic<uint32_t> validate_mismatches{0};
     auto worker = [&](int thread_id) {
         const size_t di = (size_t)thread_id % ctxs.size();
         ffs_ctx* ctx = ctxs[di];  // this worker's GPU (shadows the home context)
@@ -569,9 +617,9 @@ int main(int argc, char** argv) {
         Slot slots[2];
         const int n_slots = args.single_buffer ? 1 : 2;
         const auto t_stream = std::chrono::steady_clock::now();
-        auto close_all = [&]() { for (Slot& q : slots) if (q.s) { ffs_stream_destroy(q.s); q.s = nullptr; } };
+        auto close_all = [&]() { for (Slot& q : slots) { if (q.s) { ffs_stream_destroy(q.s); q.s = nullptr; } if (q.v) { ffs_stream_destroy(q.v); q.v = nullptr; } } };
         for (int k = 0; k < n_slots; ++k) {
-            if (ffs_stream_create(ctx, &slots[k].s) != FFS_OK) {
+            if (ffs_stream_create(ctx, &slots[k].s) != FFS_OK || (args.validate && ffs_stream_create(vctxs[di], &slots[k].v) != FFS_OK)) {
                 std::printf("Error: %s\n", ffs_last_error(ctx));
                 failed = 1;
                 close_all();
@@ -627,6 +675,15 @@ int main(int argc, char** argv) {
             }
             float tm[5] = {0};
             ffs_stream_timings(S.s, tm);
+            const ffs_frame_result* vres = nullptr;
+            if (S.v) {
+                uint32_t nv = 0;
+                if (ffs_wait(S.v, &vres, &nv) != FFS_OK || nv != nres) {
+                    std::printf("Error: validation pass: %s\n", ffs_last_error(vctxs[di]));
+                    failed = 1;
+                    return false;
+                }
+            }
             if (rotation) {
                 // key = image number read (rotation_slices[offset_image_num], :913-918); the stack has its own lock (the
                 // reference's rotation_slices_mutex), held only while the transfer is enqueued
@@ -697,6 +754,16 @@ int main(int argc, char** argv) {
                     pipe->send(j + "}");
                 }
                 std::lock_guard<std::mutex> lock(print_mutex);
+                if (vres) {  // :1012-1053
+                    const ffs_frame_result& v = vres[i];
+                    const bool same = r.strong_mask && v.strong_mask && std::memcmp(r.strong_mask, v.strong_mask, (size_t)width * height) == 0
+                                      && r.num_strong_pixels == v.num_strong_pixels && r.n_boxes == v.n_boxes;
+                    if (same) std::printf("Thread %2d, Image %4u: Compared: \033[32mMatch %u px\033[0m\n", thread_id, image_num, r.num_strong_pixels);
+                    else {
+                        std::printf("Thread %2d, Image %4u: Compared: \033[1;31mMismatch (%u px from kernel)\033[0m\n", thread_id, image_num, r.num_strong_pixels);
+                        validate_mismatches += 1;
+                    }
+                }
                 std::printf("Extracted %u spots\n", r.n_components);  // connected_components.cc:119
                 if (prm.min_spot_size > 0)
                     std::printf("Removed %u spots with size < %u pixels\n", r.n_components - r.n_boxes, prm.min_spot_size);
@@ -825,6 +892,15 @@ int main(int argc, char** argv) {
                 failed = 1;
                 break;
             }
+            if (S.v) {   // the same input through the validation context
+                const int vsub = gpu_decode ? ffs_submit_compressed(S.v, S.chunk_ptr.data(), S.chunk_len.data(), got, first)
+                                            : ffs_submit(S.v, S.host, got, first);
+                if (vsub != FFS_OK) {
+                    std::printf("Error: validation pass: %s\n", ffs_last_error(vctxs[di]));
+                    failed = 1;
+                    break;
+                }
+            }
             S.in_flight = true;
             t_submit += secs(t_sub, now());
             ++n_batches;
@@ -838,7 +914,10 @@ int main(int argc, char** argv) {
         {   // every result is out: the streams' buffers are released after the totals are printed, not on the clock
             // (eight workers' hipFree / hipHostUnregister calls take turns in the runtime: 35-45 ms for 16 streams)
             std::lock_guard<std::mutex> lock(retired_mutex);
-            for (Slot& q : slots) if (q.s) { retired_streams.push_back(q.s); q.s = nullptr; }
+            for (Slot& q : slots) {
+                if (q.s) { retired_streams.push_back(q.s); q.s = nullptr; }
+                if (q.v) { retired_streams.push_back(q.v); q.v = nullptr; }
+            }
         }
         if (args.verbose) {
             std::lock_guard<std::mutex> lock(print_mutex);
@@ -950,11 +1029,14 @@ int main(int argc, char** argv) {
         std::printf("CPU time of the process: %.2f s user + %.2f s system over %.2f s since launch (%.1f cores busy on average)\n", user, sys,
                     since_launch, (user + sys) / since_launch);
     }
+    if (args.validate)
+        std::printf("Validation: %u of %u images differ between the hot path and the gather path\n", validate_mismatches.load(), done);
     const double time_waiting = time_waiting_acc.load();
     if (time_waiting < 10) std::printf("Total time waiting for images to appear: %.0f ms\n", time_waiting * 1000);
     else std::printf("Total time waiting for images to appear: %.2f s\n", time_waiting);
     pipe.reset();
     for (ffs_stream* st : retired_streams) ffs_stream_destroy(st);
     for (ffs_ctx* cx : ctxs) ffs_ctx_destroy(cx);
-    return 0;
+    for (ffs_ctx* cx : vctxs) if (cx) ffs_ctx_destroy(cx);
+    return (args.validate && validate_mismatches.load()) ? 1 : 0;
 }

@@ -392,6 +392,7 @@ class Stream:
         if not n.value:
             return 0, 0, 0
         raw = np.frombuffer((C.c_uint8 * (n.value * C.sizeof(_FrameResult))).from_address(C.addressof(res.contents)), _FRAME_RESULT_DT)
+        self.last_frame_counts = raw     # per-frame view (n_boxes, num_strong_pixels, ...), valid until the next wait on this stream
         return int(n.value), int(raw["n_boxes"].sum()), int(raw["num_strong_pixels"].sum())
 
     def process(self, frames: np.ndarray, first_frame_id: int = 0) -> list[FrameResult]:

@@ -360,3 +360,80 @@ def test_bench_single_process_leg_with_two_contexts_on_one_gpu():
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["n_contexts_seen"] == 2 and d["value"] > 0
     assert d["config"]["spots_per_frame"] > 10 and d["config"]["strong_pixels_per_frame"] > 100
+
+
+def _oracle_counts(frames, mask, max_valid=-1, min_count=2):
+    from oracle import oracle as O
+    p = O.DispParams()
+    O.lib().ffs_oracle_default_disp_params(O.C.byref(p))
+    p.min_count = min_count
+    out = []
+    for img in frames:
+        strong = O.dispersion(img, mask, p)
+        if max_valid >= 0:
+            strong = strong & (img <= max_valid)               # kernels/thresholding.cu:208-215
+        cc = O.cc2d(strong, img, 3)
+        out.append((cc.num_strong_pixels, len(cc.boxes)))
+    return out
+
+
+def test_trusted_range_and_min_count_flags(tmp_path):
+    """The reference driver hands the frame source's trusted maximum to every launch (spotfinder.cc:482,868,879) and its
+    kernels refuse centre pixels above it (kernels/thresholding.cu:208-215); its launch wrapper defaults to min_count 3
+    (spotfinder.cuh:18-20).  Here: `--max-valid trusted` (default) / `none` / `N` and `--min-count N`.  An Eiger-stream
+    directory whose count-rate cut-off (800) lies far below the spots' peaks: counts against the oracle's mask ANDed with
+    `img <= max_valid`, as tests/test_gpu_fuzz.py does for the library."""
+    N = 4
+    shm = tmp_path / "shm"
+    assert subprocess.run([TOOL, "mkshm", "synth:tiny:%d" % N, str(shm)]).returncode == 0
+    hdr = (shm / "start_1").read_text()
+    assert '"countrate_correction_count_cutoff": 65535' in hdr
+    (shm / "start_1").write_text(hdr.replace('"countrate_correction_count_cutoff": 65535', '"countrate_correction_count_cutoff": 800'))
+    frames = tiny_frames(N)
+    assert int((frames > 800).sum()) > 20
+    mask = np.ones((200, 300), np.uint8)
+    cases = [([], dict(max_valid=800)),                                     # default: trusted
+             (["--max-valid", "trusted", "--cpu-decode"], dict(max_valid=800)),
+             (["--max-valid", "none"], dict()),                             # the CPU baseline's behaviour
+             (["--max-valid", "300", "--batch", "3"], dict(max_valid=300)),
+             (["--min-count", "30"], dict(max_valid=800, min_count=30)),    # windows at the frame's edges hold fewer pixels
+             (["--min-count", "3", "--max-valid", "none", "-a", "dispersion"], dict(min_count=3))]
+    seen = set()
+    for argv, want in cases:
+        rc, out, err, lines = run_with_pipe([str(shm), "--threads", "2", *argv], tmp_path)
+        assert rc == 0 and not err, (out, err)
+        got = {json.loads(l)["file-number"]: json.loads(l) for l in lines}
+        exp = _oracle_counts(frames, mask, **want)
+        for i, (ns, nb) in enumerate(exp):
+            assert (got[i]["num_strong_pixels"], got[i]["n_spots_total"]) == (ns, nb), (argv, i)
+        seen.add(tuple(exp))
+        assert ("Trusted range: centre pixels above" in out) == ("max_valid" in want)
+    assert len(seen) >= 4                                                    # the flags changed the answers
+    # a cut-off at or above the pixel type's maximum says nothing: no test (the synthetic source: 65535)
+    rc, out, err, lines = run_with_pipe(["synth:tiny:2"], tmp_path)
+    assert rc == 0 and "Trusted range" not in out
+    r = subprocess.run([SPOTFINDER, "synth:tiny:2", "--min-count", "1"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 1 and "--min-count" in r.stdout
+
+
+@pytest.mark.parametrize("algo", ["dispersion", "dispersion_extended"])
+def test_validate_flag_cross_checks_every_image(tmp_path, algo):
+    """`--validate` (spotfinder.cc:1012-1053: every image against the CPU baseline, "Compared: Match N px" / "Mismatch (N px from
+    kernel)").  The CPU baseline is test infrastructure here; the flag runs every batch through a second context whose threshold
+    stage gathers the window of EVERY valid pixel from memory (no streaming kernel) and compares the strong-pixel masks.
+    The Match counts are the oracle's."""
+    N = 5
+    rc, out, err, lines = run_with_pipe(["synth:tiny:%d" % N, "--threads", "2", "--batch", "2", "--validate", "-a", algo], tmp_path)
+    txt = strip_ansi(out)
+    assert rc == 0 and not err, (out, err)
+    m = dict((int(a), int(b)) for a, b in re.findall(r"Thread\s+\d+, Image\s+(\d+): Compared: Match (\d+) px", txt))
+    assert sorted(m) == list(range(N)) and "Mismatch" not in txt
+    assert f"Validation: 0 of {N} images differ" in txt
+    from oracle import oracle as O
+    frames = tiny_frames(N)
+    mask = np.ones((200, 300), np.uint8)
+    for i, img in enumerate(frames):
+        strong = O.dispersion_extended(img, mask) if algo == "dispersion_extended" else O.dispersion(img, mask)
+        assert m[i] == int(strong.sum())
+    got = {json.loads(l)["file-number"]: json.loads(l) for l in lines}
+    assert sorted(got) == list(range(N))

@@ -339,8 +339,9 @@ def _blob_frame(W, H, seed, n_blobs, rmin=3, rmax=7):
     return img
 
 
+@pytest.mark.parametrize("want_list", [1, 0])
 @pytest.mark.parametrize("chain_runs", [1, 0, 2])
-def test_run_based_sparse_stage(ffs, chain_runs):
+def test_run_based_sparse_stage(ffs, chain_runs, want_list):
     """Frames beyond the LDS forest of pixels (20480) whose RUNS fit (16384): from the stream's second dense batch on the one
     launch builds its forest over runs (k_frame_chain<uint16_t, true>).  Fat spots, spots across 32-pixel word boundaries and
     frame edges, rows that are one long run (32 word-runs chained), the reference's row-wrap edge between fat runs, equal
@@ -363,7 +364,8 @@ def test_run_based_sparse_stage(ffs, chain_runs):
     ones = np.ones((H, W), np.uint8)
     ctx = ffs.Context(W, H, np.uint16, max_batch=5, max_strong_per_frame=90000)
     ctx.set_tuning(chain_runs=chain_runs)
-    ctx.set_params(want_strong_mask=1, want_strong_list=1, min_spot_size=1, max_peak_centroid_separation=3.0)
+    # want_list 0: what the library does by default -- the run-based launch keeps the pixel lists inside LDS (need_lists = 0)
+    ctx.set_params(want_strong_mask=want_list, want_strong_list=want_list, min_spot_size=1, max_peak_centroid_separation=3.0)
     st = ctx.stream()
     for rep in range(3):                  # (the first batch cannot know that it is dense; the later ones take the run-based launch)
         res = st.process(frames, first_frame_id=10 * rep)
@@ -374,12 +376,13 @@ def test_run_based_sparse_stage(ffs, chain_runs):
     mask = (np.random.default_rng(9).random((H, W)) > 0.002).astype(np.uint8)
     mask[:, 500:504] = 0
     ctx.set_mask(mask)
-    ctx.set_params(want_strong_mask=0, want_strong_list=1, min_spot_size=3, max_peak_centroid_separation=2.0)
+    ctx.set_params(want_strong_mask=0, want_strong_list=want_list, min_spot_size=3, max_peak_centroid_separation=2.0)
     for fr, img in zip(st.process(frames), frames):
         assert_frame_matches_oracle(fr, img, mask)
 
 
-def test_run_based_sparse_stage_overflow_falls_back(ffs):
+@pytest.mark.parametrize("want_list", [1, 0])
+def test_run_based_sparse_stage_overflow_falls_back(ffs, want_list):
     """A dense frame with more runs than the run-based launch holds in LDS (isolated strong pixels: as many runs as pixels)
     raises its flag; the batch is run again through the grid-wide kernels inside ffs_wait() and the stream keeps to them."""
     rng = np.random.default_rng(4)
@@ -390,7 +393,7 @@ def test_run_based_sparse_stage_overflow_falls_back(ffs):
     frames = np.stack([noisy, fat])
     ones = np.ones((H, W), np.uint8)
     ctx = ffs.Context(W, H, np.uint16, max_batch=2, max_strong_per_frame=60000)
-    ctx.set_params(want_strong_list=1, min_spot_size=1)
+    ctx.set_params(want_strong_list=want_list, min_spot_size=1)
     st = ctx.stream()
     for rep in range(3):
         res = st.process(frames)
@@ -402,8 +405,9 @@ def test_run_based_sparse_stage_overflow_falls_back(ffs):
         assert_frame_matches_oracle(fr, img, ones, min_spot_size=1)
 
 
+@pytest.mark.parametrize("want_list", [1, 0])
 @pytest.mark.parametrize("strong_log", [1, 0])
-def test_wave_logs_and_bit_plane_agree(ffs, strong_log):
+def test_wave_logs_and_bit_plane_agree(ffs, strong_log, want_list):
     """Tuning `strong_log`: the streaming kernel's per-wave logs merged by the sparse launch (1, default) against the bit plane
     (0).  Frames chosen for the merge: strong pixels in every strip and band, groups that straddle strips, a frame pair
     that shares a strip (frame width not a multiple of the strip), bright windows (decided by the sparse launch: the cores
@@ -430,23 +434,25 @@ def test_wave_logs_and_bit_plane_agree(ffs, strong_log):
     ctx = ffs.Context(W, H, np.uint16, max_batch=B)
     ctx.set_tuning(strong_log=strong_log)
     ctx.set_mask(mask)
-    ctx.set_params(want_strong_list=1, min_spot_size=1)
+    ctx.set_params(want_strong_list=want_list, min_spot_size=1)
     st = ctx.stream()
     for rep in range(2):
         for fr, img in zip(st.process(frames, first_frame_id=rep), frames):
             assert_frame_matches_oracle(fr, img, mask, min_spot_size=1)
-    ctx.set_params(want_strong_mask=1, want_strong_list=1, min_spot_size=3)
+    ctx.set_params(want_strong_mask=1, want_strong_list=want_list, min_spot_size=3)
     for fr, img in zip(st.process(frames[:3]), frames[:3]):
         assert_frame_matches_oracle(fr, img, mask)
     # a row of strong groups: more entries than a wave's log holds -> the plane takes over, results unchanged
     busy = rng.poisson(1.0, (H, W)).astype(np.uint16)
     busy[20:60, ::5] = 500
+    ctx.set_params(want_strong_mask=0, want_strong_list=want_list, min_spot_size=3)
     for rep in range(2):
         for fr, img in zip(st.process(np.stack([busy, frames[0]])), (busy, frames[0])):
             assert_frame_matches_oracle(fr, img, mask)
 
 
-def test_sparse_and_dense_batches_alternate_on_one_stream(ffs):
+@pytest.mark.parametrize("want_list", [1, 0])
+def test_sparse_and_dense_batches_alternate_on_one_stream(ffs, want_list):
     """Which sparse stage a batch gets follows what the stream's previous batch held: wave logs for sparse data, the plane with
     the run-based launch for dense data, and a dense batch that arrives on the logs is run again through the plane inside
     ffs_wait (flag 64) without switching the logs off for good.  Sparse / dense / dense / sparse / sparse / dense."""
@@ -455,7 +461,7 @@ def test_sparse_and_dense_batches_alternate_on_one_stream(ffs):
     dense = [_blob_frame(W, H, 40 + i, 500) for i in range(2)]
     ones = np.ones((H, W), np.uint8)
     ctx = ffs.Context(W, H, np.uint16, max_batch=2, max_strong_per_frame=90000)
-    ctx.set_params(want_strong_list=1, min_spot_size=2)
+    ctx.set_params(want_strong_list=want_list, min_spot_size=2)
     st = ctx.stream()
     for k, batch in enumerate([sparse, dense, dense, sparse, sparse, dense, [sparse[0], dense[1]], sparse]):
         res = st.process(np.stack(batch), first_frame_id=10 * k)
@@ -495,3 +501,40 @@ def test_stack_created_after_the_batch_is_refused(ffs):
     stack2 = ffs.Stack3D(ctx2)
     stack2.add_batch(st2)                              # the host asked for the lists: they are on the device
     assert stack2.finish()[1] == want.n_calculated
+
+
+@pytest.mark.parametrize("kind", ["dense_on_logs", "runs_overflow"])
+def test_stack_takes_a_batch_that_was_run_again(ffs, kind):
+    """`lists_valid` after a re-run inside ffs_wait: a 3D stack is alive (tuning `device_lists` = 2 -> the lists stay on the
+    device), nobody asked for the lists on the host, and the batch is one the first launch cannot serve -- dense frames arriving
+    on the wave logs (flag 64: again through the plane and the run-based launch) or a frame with more runs than the run-based
+    launch holds (flag 16: again through the grid-wide kernels).  ffs_stack3d_add_batch must then read the lists of the
+    SECOND pass: the 3D result is the oracle's for the oracle's own lists."""
+    from oracle import oracle as O
+    from util import assert_reflections_equal
+    rng = np.random.default_rng(17)
+    W, H = 640, 480
+    ones = np.ones((H, W), np.uint8)
+    if kind == "dense_on_logs":
+        frames = np.stack([_blob_frame(W, H, 60, 420), _blob_frame(W, H, 61, 420)])
+    else:
+        noisy = rng.poisson(1.0, (H, W)).astype(np.uint16)
+        noisy[rng.random((H, W)) < 0.09] += 60
+        frames = np.stack([noisy, _blob_frame(W, H, 62, 420)])
+    ctx = ffs.Context(W, H, np.uint16, max_batch=2, max_strong_per_frame=90000)
+    ctx.set_params(min_spot_size=1, min_spot_size_3d=2)       # want_strong_list = 0
+    st = ctx.stream()
+    stack = ffs.Stack3D(ctx)
+    lists = []
+    for rep in range(3):                                       # sparse-path first batch, then the stream knows its data is dense
+        res = st.process(frames, first_frame_id=2 * rep)
+        assert max(r.num_strong_pixels for r in res) > 20480
+        stack.add_batch(st)
+        for fr, img in zip(res, frames):
+            assert_frame_matches_oracle(fr, img, ones, min_spot_size=1)
+            k = np.flatnonzero(O.dispersion(img, ones)).astype(np.uint64)
+            lists.append((k, img.ravel()[k].astype(np.uint32)))
+    refl, n_calc, fs, fp = stack.finish()
+    want = O.cc3d(lists, W, H, 2, 2.0)
+    assert (n_calc, fs, fp) == (want.n_calculated, want.n_filtered_size, want.n_filtered_sep)
+    assert_reflections_equal(refl, want.reflections)

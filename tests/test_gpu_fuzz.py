@@ -54,17 +54,18 @@ def random_case(seed):
 
 
 @pytest.mark.parametrize("seed", range(240))
-def test_random_case(ffs, seed, tuning=None):
+def test_random_case(ffs, seed, tuning=None, want_list=1, want_mask=1, passes=1):
     W, H, dtype, frames, mask, prm, algo, flavour, max_valid, compressed = random_case(seed)
     ctx = ffs.Context(W, H, dtype, max_batch=len(frames))
     if tuning:
         ctx.set_tuning(**tuning)
     ctx.set_mask(mask)
-    ctx.set_params(algorithm=algo, extended_flavour=flavour, max_valid=max_valid, want_strong_mask=1, want_strong_list=1,
-                   want_reflections=1, **prm)
+    ctx.set_params(algorithm=algo, extended_flavour=flavour, max_valid=max_valid, want_strong_mask=want_mask,
+                   want_strong_list=want_list, want_reflections=1, **prm)
     st = ctx.stream()
-    res = (st.process_compressed([bslz4.compress(f) for f in frames], first_frame_id=5) if compressed
-           else st.process(frames, first_frame_id=5))
+    for _ in range(passes):   # (a stream's later batches follow what its earlier ones held: dense data changes the sparse launch)
+        res = (st.process_compressed([bslz4.compress(f) for f in frames], first_frame_id=5) if compressed
+               else st.process(frames, first_frame_id=5))
     p = O.DispParams()
     O.lib().ffs_oracle_default_disp_params(O.C.byref(p))
     p.min_count, p.nsig_b, p.nsig_s, p.threshold = prm["min_count"], prm["nsig_b"], prm["nsig_s"], prm["threshold"]
@@ -174,3 +175,32 @@ def test_random_case_bit_plane_instead_of_wave_logs(ffs, seed):
     bits and lists bright windows for k_bright_fix, the sparse launch compacts the plane (the default since round 3c is the
     wave logs, which the sweeps above go through)."""
     test_random_case(ffs, seed, tuning=dict(strong_log=0))
+
+
+@pytest.mark.parametrize("seed", range(0, 240, 3))
+def test_random_case_without_lists(ffs, seed):
+    """The same sweep as the library runs it by default and as bench.py times it: nobody asks for the strong-pixel lists or the
+    byte mask (`want_strong_list = 0`, `want_strong_mask = 0`), so the sparse launch keeps the lists inside LDS and skips their
+    stores (`need_lists = 0`, kernels_chain.hpp).  Counts, boxes and reflections against the oracle; twice on the same stream."""
+    test_random_case(ffs, seed, want_list=0, want_mask=0, passes=2)
+
+
+@pytest.mark.parametrize("seed", range(1, 240, 6))
+def test_random_case_without_lists_run_based(ffs, seed):
+    """... and through the run-based launch (tuning `chain_runs` = 2), whose list stores are skipped the same way."""
+    test_random_case(ffs, seed, tuning=dict(chain_runs=2), want_list=0, want_mask=0, passes=2)
+
+
+@pytest.mark.parametrize("seed", range(2, 240, 12))
+def test_random_case_without_lists_bit_plane(ffs, seed):
+    """... through the bit plane (tuning `strong_log` = 0) and with the lists forced to stay on the device (`device_lists` = 1)."""
+    test_random_case(ffs, seed, tuning=dict(strong_log=0), want_list=0, want_mask=0, passes=2)
+    test_random_case(ffs, seed, tuning=dict(device_lists=1), want_list=0, want_mask=0)
+
+
+@pytest.mark.parametrize("seed", range(3, 240, 8))
+def test_random_case_gather_path(ffs, seed):
+    """Tuning `threshold_path` = 2, the partner of `spotfinder --validate`: no streaming kernel -- the plane starts as the
+    valid-pixel mask and k_exact gathers the window of every valid pixel.  Must give the oracle's result on its own."""
+    test_random_case(ffs, seed, tuning=dict(threshold_path=2))
+    test_random_case(ffs, seed, tuning=dict(threshold_path=2, sparse_stage=1, strong_log=0), want_list=0, want_mask=1)

@@ -60,3 +60,30 @@ def test_persistent_context_matches_one_shot():
     for _ in range(2):
         ps.run_f64(img.astype(np.float64), mask, dst)
         np.testing.assert_array_equal(dst, O.dispersion(img, mask))
+
+
+@pytest.mark.parametrize("workload,algorithm,frame", [("eiger16m", "dispersion", 0), ("eiger16m", "dispersion", 31),
+                                                      ("eiger16m", "dispersion_extended", 7), ("jungfrau9m", "dispersion", 19)])
+def test_bench_workload_fixture(workload, algorithm, frame):
+    """tests/golden/bench_workloads.npz (what bench.py and tests/test_gpu_bench_config.py hold the HIP path to, generated with
+    the reference's standalone.cc as the threshold): the restatement reproduces a frame's entry -- input hash, counts and
+    the digest of its boxes and reflections -- so the fixture and the generator cannot drift apart unnoticed."""
+    import hashlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from ffs_amd import fixtures, synth
+    exp = fixtures.load_expected(workload, algorithm, 0, 32)
+    assert exp is not None
+    z = np.load(os.path.normpath(fixtures.GOLDEN))
+    p = synth.eiger16m_params(seed=2000) if workload == "eiger16m" else synth.jungfrau9m_params(seed=4000)
+    _, mask = bench.make_inputs(workload, 0, 0)
+    img = synth.frame(p, frame)
+    assert hashlib.sha256(img.tobytes()).digest() == z[fixtures.key(workload, algorithm, 0) + "/input_sha256"][frame].tobytes()
+    strong = O.dispersion_extended(img, mask) if algorithm == "dispersion_extended" else O.dispersion(img, mask)
+    cc = O.cc2d(strong, img, 3)
+    refl = O.cc2d_reflections(cc.k, cc.intensity, img.shape[1], img.shape[0], 3, 2.0)
+    assert (cc.num_strong_pixels, len(cc.boxes), cc.n_unfiltered_boxes, len(refl.reflections)) == (
+        exp["num_strong_pixels"][frame], exp["n_boxes"][frame], exp["n_components"][frame], exp["n_reflections"][frame])
+    assert fixtures.frame_digest(cc.boxes, refl.reflections) == exp["digest"][frame].tobytes()

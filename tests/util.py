@@ -44,8 +44,9 @@ def assert_reflections_equal(got, want, tol=0.0):
             np.testing.assert_allclose(got[f], want[f], rtol=0, atol=tol, err_msg=f)
 
 
-def assert_frame_matches_oracle(fr, img, mask, min_spot_size=3, max_sep=2.0, strong=None):
-    strong, cc, refl = oracle_frame(img, mask, min_spot_size, max_sep, strong)
+def assert_frame_matches_oracle(fr, img, mask, min_spot_size=3, max_sep=2.0, strong=None, precomputed=None):
+    """precomputed: what oracle_frame() returned for this frame (batches that repeat a frame ask the oracle once)."""
+    strong, cc, refl = precomputed if precomputed is not None else oracle_frame(img, mask, min_spot_size, max_sep, strong)
     if fr.strong_mask is not None:
         diff = np.argwhere(fr.strong_mask != strong)
         assert diff.size == 0, f"{len(diff)} strong-mask mismatches, first at (y,x)={diff[:5].tolist()}"

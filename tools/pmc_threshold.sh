@@ -22,9 +22,9 @@ done
 python3 tools/summarize_pmc.py $out/${tag}_pmc_* > $out/${tag}_pmc_threshold_${suffix}_b32.json
 [ -n "$SKIP_TRACE" ] && { cat $out/${tag}_pmc_threshold_${suffix}_b32.json; exit 0; }
 rm -rf $out/${tag}_trace1 $out/${tag}_trace4
-rocprofv3 --kernel-trace --stats -d $out/${tag}_trace1 --output-format csv -- python3 bench.py --steps 20 --warmup 3 --streams 1 --no-cpu-baseline --no-streamed --workload $wl --algorithm $alg > $out/${tag}_trace1.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out/${tag}_trace1 --output-format csv -- python3 bench.py --steps 20 --warmup 3 --streams 1 --no-cpu-baseline --no-streamed --no-cli-e2e --workload $wl --algorithm $alg > $out/${tag}_trace1.log 2>&1
 cp $out/${tag}_trace1/*/*kernel_stats.csv $out/${tag}_kernel_stats_bench_${suffix}_b32_1stream.csv
-rocprofv3 --kernel-trace --stats -d $out/${tag}_trace4 --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-streamed --workload $wl --algorithm $alg > $out/${tag}_trace4.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out/${tag}_trace4 --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-streamed --no-cli-e2e --workload $wl --algorithm $alg > $out/${tag}_trace4.log 2>&1
 cp $out/${tag}_trace4/*/*kernel_stats.csv $out/${tag}_kernel_stats_bench_${suffix}_4streams.csv
 cat $out/${tag}_pmc_threshold_${suffix}_b32.json
 cut -d, -f1-4 $out/${tag}_kernel_stats_bench_${suffix}_b32_1stream.csv | head -12

@@ -46,7 +46,8 @@ for k, seed in enumerate(range(first, first + n)):
         if tuning:
             ctx.set_tuning(**tuning)
         ctx.set_mask(mask)
-        ctx.set_params(algorithm=algo, want_strong_mask=int(rng.random() < 0.5), want_strong_list=1, want_reflections=1, **prm)
+        want_list = int(rng.random() < 0.5)    # 0: the default -- the dense launches keep their pixel lists in LDS (need_lists = 0)
+        ctx.set_params(algorithm=algo, want_strong_mask=int(rng.random() < 0.5) if want_list else 0, want_strong_list=want_list, want_reflections=1, **prm)
         st = ctx.stream()
         p = O.DispParams()
         O.lib().ffs_oracle_default_disp_params(O.C.byref(p))
