@@ -111,7 +111,11 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
                 b->first_id = s->first_id + f;
                 b->dev_input = true;
                 b->ev1_pending = true;
-                int rc = enqueue_batch(b, img, s->cur_pitch, s->cur_fstride, 1, &s->batch_params);
+                // (the frame's strong-pixel list comes back to the host whenever somebody may read it: the caller, or a 3D stack
+                // that is alive -- ffs_stack3d_add_batch takes an overflow frame's list from here, tuning "device_lists")
+                ffs_params bp = s->batch_params;
+                if (c->tune.device_lists == 1 || (c->tune.device_lists == 2 && g_live_stacks.load() > 0)) bp.want_strong_list = 1;
+                int rc = enqueue_batch(b, img, s->cur_pitch, s->cur_fstride, 1, &bp);
                 if (rc != FFS_OK) return rc;
                 HIP_TRY(c, hipEventSynchronize(b->ev[4]));
                 const uint32_t b_ovf = b->chain_mode ? b->h_counts[10 * (size_t)b->max_batch + 1] : b->h_counts[10 * (size_t)b->max_batch];

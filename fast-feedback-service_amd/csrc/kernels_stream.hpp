@@ -198,10 +198,6 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     const rsrc_t r_sb = make_rsrc(a.strong_bytes + (uint64_t)f0 * a.bytes_frame_stride,
                                   (uint32_t)((uint64_t)nf * a.bytes_frame_stride));
     const rsrc_t r_cb = make_rsrc((EXT ? a.dplane : a.bits) + (uint64_t)f0 * a.plane_frame_stride, (uint32_t)((uint64_t)nf * a.plane_frame_stride));
-    // (the drain's read of the window-count table is a bounds-checked buffer load like every other access of this kernel whose address
-    // comes out of the LDS queue: a tag that is not what a push wrote -- round 3's experiment bit 32 left the queue unwritten -- reads
-    // zeros instead of faulting)
-    const rsrc_t r_mm = make_rsrc(a.mmap, (uint32_t)a.H * (uint32_t)a.pitch_px);
     constexpr uint32_t kOob = 0x80000000u;  // offsets with bit 31 set are out of range for every resource (all < 2 GiB)
     const uint32_t off_px = active ? (uint32_t)((uint64_t)fl * a.frame_stride) + (uint32_t)g * 16u : kOob;
     const uint32_t off_info = active ? (uint32_t)g * 4u : kOob;
@@ -336,10 +332,12 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
             const uint32_t ginf = s_q[15][lane];
             const uint32_t gmin = (ginf >> 8) & 0xFFu, gmax = (ginf >> 16) & 0xFFu;
             uint2 mm = make_uint2(gmin * 0x01010101u, gmin * 0x01010101u);
-            if (gmin != gmax) {
-                const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r_mm, ge * 8u, row * (uint32_t)a.pitch_px, 0);
-                mm = make_uint2(t[0], t[1]);
-            }
+            // (row and group clamped into the table: this is the one access of the kernel that is a plain global load at an address
+            // that comes out of the LDS queue -- a tag that is not what a push wrote, as under round 3's experiment bit 32 which left
+            // the queue unwritten, must not become a wild address: DESIGN.md section 10.  A buffer resource for it cost four SGPRs
+            // over the whole kernel, 17 spills instead of 13 and 1-3 % of the step.)
+            if (gmin != gmax)
+                mm = *reinterpret_cast<const uint2*>(a.mmap + (uint64_t)min(row, (uint32_t)a.H - 1u) * a.pitch_px + min(ge * 8u, (uint32_t)a.pitch_px - 8u));
             s_q[12][lane] = mm.x;
             s_q[13][lane] = mm.y;
             s_q[14][lane] = 0u;
@@ -675,7 +673,6 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
     const rsrc_t r_info = make_rsrc(a.ginfo, (uint32_t)(a.H + kInfoExtraRows) * a.gpitch);
     const rsrc_t r_sb = make_rsrc(a.strong_bytes + (uint64_t)f0 * a.bytes_frame_stride,
                                   (uint32_t)((uint64_t)nf * a.bytes_frame_stride));
-    const rsrc_t r_mm = make_rsrc(a.mmap, (uint32_t)a.H * (uint32_t)a.pitch_px);   // bounds-checked, see k_stream_u16
     constexpr uint32_t kOob = 0x80000000u;
     const uint32_t off_px = active ? (uint32_t)((uint64_t)fl * a.frame_stride) + (uint32_t)g * 16u : kOob;
     const uint32_t off_info = active ? (uint32_t)g * 4u : kOob;
@@ -756,7 +753,8 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
             fe = (uint32_t)Ge / (uint32_t)gsep;
             ge = (uint32_t)Ge - fe * (uint32_t)gsep;
             info = s_q[8][lane];
-            const uint32_t mm = __builtin_amdgcn_raw_buffer_load_b32(r_mm, ge * 4u, row * (uint32_t)a.pitch_px, 0);
+            const uint32_t mm = *reinterpret_cast<const uint32_t*>(a.mmap + (uint64_t)min(row, (uint32_t)a.H - 1u) * a.pitch_px
+                                                                   + min(ge * 4u, (uint32_t)a.pitch_px - 4u));   // (clamped: see k_stream_u16)
             s_q[9][lane] = mm;
             s_q[10][lane] = 0u;
             if (!big) {

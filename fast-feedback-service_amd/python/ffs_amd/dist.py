@@ -100,6 +100,49 @@ def all_gather_fixed(t, group=None):
     return torch.cat(out, 0)
 
 
+def gather_rows_to_root(rows, n: int, tag: int = 0, root: int = 0, group=None, recv_buf=None):
+    """The gather `north_star` words ("a simple RCCL-over-xGMI gather of the per-frame spot lists"): one tiny
+    all_gather of every rank's row count, then EXACTLY the written rows travel, point to point, to `root` -- no padding, and
+    nothing lands on ranks that do not read it.  `rows`: (cap, 4) float32 tensor whose first `n` rows are valid (device
+    tensor under "nccl" = RCCL: the sends and receives go out as one group; CPU tensor under "gloo").  `tag` travels with the
+    count (bench.py: rank + 1).  Returns (gathered, counts, requests): on `root` `gathered` is the (sum of counts, 4) tensor
+    of all ranks' rows in rank order (a view of `recv_buf` when given, which must hold them), None elsewhere; `counts` is the
+    (world, 2) int64 array of (rows, tag) per rank; wait on `requests` before reading `gathered` / reusing `rows`."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    me = torch.tensor([int(n), int(tag)], dtype=torch.int64, device=rows.device)
+    counts = all_gather_fixed(me, group).cpu().numpy().reshape(world, 2)
+    ops, gathered = [], None
+    if rank == root:
+        total = int(counts[:, 0].sum())
+        if recv_buf is None:
+            recv_buf = torch.empty((max(total, 1), 4), dtype=rows.dtype, device=rows.device)
+        if recv_buf.shape[0] < total:
+            raise SpotGatherTruncated(f"{total} rows gathered, room for {recv_buf.shape[0]}")
+        off = 0
+        for r in range(world):
+            c = int(counts[r, 0])
+            if r == rank:
+                if c:
+                    recv_buf[off:off + c].copy_(rows[:c])
+            elif c:
+                ops.append(dist.P2POp(dist.irecv, recv_buf[off:off + c], r, group))
+            off += c
+        gathered = recv_buf[:total]
+    elif n:
+        ops.append(dist.P2POp(dist.isend, rows[:int(n)], root, group))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    return gathered, counts, reqs
+
+
+def rows_by_frame(rows: np.ndarray) -> dict:
+    """{frame_id: (n, 3) float32 centres} from gathered (frame_id bits, x, y, z) rows, in frame order."""
+    rows = np.ascontiguousarray(rows, np.float32).reshape(-1, 4)
+    ids = rows[:, 0].view(np.uint32)
+    return {int(fid): rows[ids == fid, 1:4].copy() for fid in np.unique(ids)}
+
+
 def gather_strong_lists(slices: dict, device=None, group=None) -> dict:
     """Variable-length gather of {frame_id: (k uint32, intensity uint32)} to every rank:
     all_gather of counts, then one padded all_gather of the payload."""

@@ -57,3 +57,13 @@ def test_a_failing_rank_takes_the_run_down_with_its_code():
     assert p.returncode == 7 and p.stdout.strip() == ""
     assert "failed" in p.stderr
     assert time.time() - t0 < 60
+
+
+def test_three_ranks_gather_rows_with_an_empty_rank_and_the_padded_partner():
+    # --gather rows (default): counts + send/recv to rank 0, rank 1 has no rows; --gather padded: the all_gather of blocks
+    for extra in ([], ["--gather", "padded"]):
+        p = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--dry-run", *extra], env=_env(FFS_BENCH_ASSUME_GPUS="3"),
+                           capture_output=True, text=True, timeout=240)
+        assert p.returncode == 0, p.stderr[-2000:]
+        d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+        assert d["n_gpus"] == 3 and d["n_ranks_seen"] == 3, d     # (the empty rank is seen too: its tag travels with its count)

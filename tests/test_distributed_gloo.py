@@ -133,3 +133,61 @@ def test_spot_rows_keep_large_frame_ids_and_flag_truncation():
     assert list(got) == ids
     with pytest.raises(D.SpotGatherTruncated):
         D.unpack_spots(D.pack_spots(results, 8), 1, 8)
+
+
+def _rows_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ffs_amd import dist as D
+        cap = 40
+        counts = [7, 0, 19]                      # unequal, and rank 1 has nothing
+        rows = np.zeros((cap, 4), np.float32)
+        n = counts[rank]
+        ids = np.repeat(np.arange(rank * 100, rank * 100 + 4), 5)[:n] + (1 << 24)      # ids past 2^24: bit patterns, not values
+        rows[:n, 0] = D._ids_as_float_lanes(ids)
+        rows[:n, 1] = np.arange(n) + 0.25 * rank
+        rows[:n, 2] = rank
+        rows[:n, 3] = 0.5
+        for rep in range(2):                     # twice: the receive buffer is reused
+            recv = torch.full((sum(counts) + 3, 4), -1.0) if rank == 0 else None
+            got, cts, reqs = D.gather_rows_to_root(torch.from_numpy(rows), n, tag=rank + 1, root=0, recv_buf=recv)
+            for r in reqs:
+                r.wait()
+            assert cts[:, 0].tolist() == counts and cts[:, 1].tolist() == [1, 2, 3]
+            assert (got is None) == (rank != 0)
+        if rank == 0:
+            q.put(got.numpy().copy())
+        # a receive buffer that is too small is an error on the root, not a silent cut -- raised after the counts have
+        # been exchanged (so no rank is left waiting in a collective): here every rank sends nothing
+        if rank == 0:
+            with pytest.raises(D.SpotGatherTruncated):
+                D.gather_rows_to_root(torch.from_numpy(rows), 5, root=0, recv_buf=torch.empty((2, 4)))
+        else:
+            D.gather_rows_to_root(torch.from_numpy(rows), 0, root=0)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_three_rank_row_gather_with_unequal_counts_and_an_empty_rank():
+    """north_star's gather: all_gather of the ranks' row counts, then exactly the written rows point to point to
+    rank 0 (`ffs_amd.dist.gather_rows_to_root`, what bench.py --gpus N runs over RCCL by default)."""
+    from ffs_amd import dist as D
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_rows_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got.shape == (26, 4)
+    by_frame = D.rows_by_frame(got)
+    assert list(by_frame) == [(1 << 24) + 0, (1 << 24) + 1, (1 << 24) + 200, (1 << 24) + 201, (1 << 24) + 202, (1 << 24) + 203]
+    assert [len(v) for v in by_frame.values()] == [5, 2, 5, 5, 5, 4]
+    np.testing.assert_array_equal(got[:7, 1], np.arange(7, dtype=np.float32))            # rank 0's rows first, in order
+    np.testing.assert_array_equal(got[7:, 1], np.arange(19, dtype=np.float32) + 0.5)     # then rank 2's
+    assert (got[7:, 2] == 2).all()

@@ -58,6 +58,18 @@ def test_one_rank_nccl_gather_of_hip_spots(ffs):
                 continue
             want = np.stack([refl["com_x"], refl["com_y"], refl["com_z"]], 1)
             np.testing.assert_array_equal(spots[first_id + i], want)      # HIP -> RCCL -> here == oracle
+        # the default of bench.py --gpus N: counts, then exactly the written rows to rank 0 (gather_rows_to_root; with one rank the
+        # root's own rows are copied on the device -- the count exchange is the RCCL call that runs here)
+        rows_dev = host[:n].to(dev, non_blocking=True) if n else torch.empty((1, 4), dtype=torch.float32, device=dev)
+        recv = torch.empty((n + 2, 4), dtype=torch.float32, device=dev)
+        got, counts, reqs = D.gather_rows_to_root(rows_dev, n, tag=1, root=0, recv_buf=recv)
+        for q in reqs:
+            q.wait()
+        assert counts.tolist() == [[n, 1]] and got.shape == (n, 4)
+        by_frame = D.rows_by_frame(got.cpu().numpy())
+        assert list(by_frame) == list(spots)
+        for fid in spots:
+            np.testing.assert_array_equal(by_frame[fid], spots[fid])
         # too small a block is reported, not dropped silently
         with pytest.raises(ffs.FfsError):
             st.pack_spot_centres(np.empty((9, 4), np.float32), 8)

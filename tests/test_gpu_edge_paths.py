@@ -516,11 +516,11 @@ def test_stack_takes_a_batch_that_was_run_again(ffs, kind):
     W, H = 640, 480
     ones = np.ones((H, W), np.uint8)
     if kind == "dense_on_logs":
-        frames = np.stack([_blob_frame(W, H, 60, 420), _blob_frame(W, H, 61, 420)])
+        frames = np.stack([_blob_frame(W, H, 60, 520), _blob_frame(W, H, 61, 520)])
     else:
         noisy = rng.poisson(1.0, (H, W)).astype(np.uint16)
         noisy[rng.random((H, W)) < 0.09] += 60
-        frames = np.stack([noisy, _blob_frame(W, H, 62, 420)])
+        frames = np.stack([noisy, _blob_frame(W, H, 62, 520)])
     ctx = ffs.Context(W, H, np.uint16, max_batch=2, max_strong_per_frame=90000)
     ctx.set_params(min_spot_size=1, min_spot_size_3d=2)       # want_strong_list = 0
     st = ctx.stream()

@@ -4,7 +4,7 @@
 tag=${1:-check}; shift
 out=gpurun_out/$tag
 mkdir -p $out
-python -m pytest tests -m gpu -q -x > $out/gputests.log 2>&1; rc=$?; tail -4 $out/gputests.log
+python -m pytest tests -m gpu -q ${PYTEST_X--x} > $out/gputests.log 2>&1; rc=$?; tail -4 $out/gputests.log
 [ $rc -ne 0 ] && exit $rc
 python bench.py "$@" > $out/bench.json 2> $out/bench.err; rc=$?; cat $out/bench.json; tail -2 $out/bench.err
 exit $rc

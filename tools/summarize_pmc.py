@@ -42,6 +42,14 @@ def main():
         out["_commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
       except Exception:
         pass
+    # what the profiled kernels were compiled from: bench.py compares these hashes with the files it finds and says so when a
+    # kernel source changed after the counters were taken (the GPU box has no .git to ask)
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = {}
+    for f in sorted(glob.glob(os.path.join(root, "fast-feedback-service_amd", "csrc", "kernels_*.hpp")) + [os.path.join(root, "fast-feedback-service_amd", "csrc", "ffs_device.h")]):
+        src[os.path.basename(f)] = hashlib.sha256(open(f, "rb").read()).hexdigest()[:16]
+    out["_sources_sha256_16"] = src
     json.dump(out, sys.stdout, indent=1, sort_keys=True)
     print()
 
