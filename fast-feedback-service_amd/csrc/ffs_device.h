@@ -38,6 +38,10 @@ struct Layout {
 // One wave64 marches down a column strip; a lane holds 16 bytes of a pixel row (8 pixels of 16 bits, 4 of 32).
 // Lanes 0 and 63 are halo (their windows are incomplete), lanes 1..62 own output.
 constexpr int kSOwned = 62;
+// first row of band b for a (split, rows, rows2) geometry -- see ThresholdArgs::band_split
+__host__ __device__ inline int band_first_row(int band, int band_rows, int band_rows2, int band_split) {
+    return band < band_split ? band * band_rows : band_split * band_rows + (band - band_split) * band_rows2;
+}
 constexpr int kInfoExtraRows = 3;    // ginfo row y carries the mask bits of row y and the window counts of row y - 3
 
 // Exact-stage tiles: one 256-thread workgroup per 8 rows.
@@ -57,6 +61,10 @@ struct ThresholdArgs {
     uint32_t mpitch, bpitch;
     uint64_t plane_frame_stride, bytes_frame_stride;
     int n_strips, band_rows, n_bands, n_tiles;
+    // Bands of two heights (tuning "band_taper"): bands 0 .. band_split - 1 are band_rows tall, the rest band_rows2.  The block map
+    // hands out bands in ascending order, so with band_rows2 < band_rows the LAST waves of a launch are the short ones and the
+    // launch's tail (the slots of the machine that idle while the last round of waves finishes) shrinks.  band_split = n_bands: uniform.
+    int band_rows2, band_split;
     // parameters
     float kS;                  // nsig_s^2 (1 - 2^-16): conservative signal pre-filter
     float kB;                  // nsig_b (1 - 2^-20): conservative dispersion pre-filter

@@ -70,6 +70,10 @@ struct Tuning {
     int direct_records = 1;     // records and counters are written straight into pinned host memory
     int decode_in_dense_stream = 1;   // the decode kernel runs in the dense kernels' stream (0: in the upload stream)
     int ccl_grid = 32;          // workgroups per frame of the grid-wide sparse kernels
+    int ext_rest_aside = 0;     // extended algorithm: 1 = erosion + final pass in the batch's sparse stream, beside the next batch's first pass; 0 = in the
+                                //    dense stream (measured round 4: no gain -- a CU full of first-pass waves has neither LDS nor registers left for the
+                                //    final pass's workgroups, so the kernels take turns either way: profiles/r04b_ext_streams_ab.txt)
+    int band_taper = 0;         // streaming kernels: the last two bands per XCD are this many per cent as tall as the others (0 = uniform bands)
     int rows_ahead = 2;         // rows of loads a wave of the 16-bit streaming kernel keeps in flight (2, 3 or 4)
     int device_lists = 2;       // the strong-pixel lists stay on the device after a batch: 1 = always, 0 = only when the host asked for them
                                 //    (want_strong_list), 2 = also while a 3D stack of the process is alive (ffs_stack3d_add_batch reads them)
@@ -173,6 +177,12 @@ struct ffs_stream {
     uint8_t* d_bits = nullptr;
     uint8_t* d_sbytes = nullptr;
     uint8_t *d_dplane = nullptr, *d_eplane = nullptr;  // extended algorithm only (allocated on first use)
+    // The first-pass plane must be all zero when the streaming kernel starts (it writes non-zero bytes only).  Two planes take
+    // turns: the one the previous batch used is cleared in the sparse stream behind this batch's sparse launch -- done before
+    // this batch's last event, i.e. before the stream's next submit -- instead of by a fill in the dense stream ahead of every
+    // first pass; the last batch's plane stays readable (ffs_stream_debug_bitplane, --writeout).
+    uint8_t* d_dplane2 = nullptr;
+    bool dplane2_clean = false;                        // the plane the NEXT batch takes is zero
     uint8_t* d_comp = nullptr;                         // compressed chunks (allocated on first use)
     uint2 *d_tab = nullptr, *h_tab = nullptr;          // per-block (offset, length) tables
     uint32_t dec_blocks = 0, dec_last = 0, dec_tail = 0, dec_block_elems = 0;

@@ -101,6 +101,27 @@ ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t pitch, 
         if (nb >= 8) nb = nb / 8 * 8;
         a.band_rows = (int)std::min<long long>(1024, (L.H + nb - 1) / nb);
         a.n_bands = (L.H + a.band_rows - 1) / a.band_rows;
+        a.band_rows2 = a.band_rows;
+        a.band_split = a.n_bands;
+        // Tapered bands (tuning "band_taper" = t per cent, 0 = off): the last two bands of every XCD are t % as tall as the others.
+        // The waves of a launch all take about the same time and there are 3-4 times as many of them as the machine has slots, so
+        // the last round leaves slots idle; handed out last and short, the final waves fill that tail with less work each.
+        const int taper = c->tune.band_taper;
+        if (taper > 0 && taper < 100 && nb >= 32 && nb % 8 == 0 && a.n_bands == (int)nb) {
+            const int K = (int)nb / 8;                       // bands per XCD
+            const int K2 = 2, K1 = K - K2;
+            // 8 (K1 h1 + K2 h2) >= H with h2 = taper h1 / 100
+            const double h1f = (double)L.H / (8.0 * (K1 + K2 * taper / 100.0));
+            int h1 = std::min(1024, (int)std::ceil(h1f));
+            int h2 = (int)std::ceil((L.H / 8.0 - (double)K1 * h1) / K2);
+            while (h2 < 24) { --h1; h2 = (int)std::ceil((L.H / 8.0 - (double)K1 * h1) / K2); }
+            if (h1 >= h2 && h2 >= 24 && 8 * (K1 * h1 + K2 * h2) >= L.H && 8 * K1 * h1 < L.H) {
+                a.band_rows = h1;
+                a.band_rows2 = h2;
+                a.band_split = 8 * K1;
+                a.n_bands = a.band_split + (L.H - a.band_split * h1 + h2 - 1) / h2;
+            }
+        }
     }
     a.dplane = s->d_dplane;
     a.eplane = s->d_eplane;
@@ -154,37 +175,40 @@ static void launch_exact(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frame
 // when the bright-window list of a batch overflowed).
 static bool ext_stream_first(const ThresholdArgs& a) { return a.ext_variant >= 2; }
 
-static void launch_ext_first(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames, hipEvent_t start, hipEvent_t stop) {
+static void launch_ext_first(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames, hipEvent_t start, hipEvent_t stop, bool fix_here = true,
+                             bool plane_clean = false, bool counts_clean = false) {
     if (ext_stream_first(a)) {
         // the kernel writes the non-zero bytes of the first-pass plane; the bright-list count sits behind the tile counts
-        (void)hipMemsetAsync(a.dplane, 0, (size_t)n_frames * a.plane_frame_stride, s->st);
-        (void)hipMemsetAsync(a.tile_counts, 0, tile_counts_bytes(s), s->st);
+        // (both are usually clean already: the plane was cleared behind the previous batch's sparse launch, which also zeroed the counts)
+        if (!plane_clean) (void)hipMemsetAsync(a.dplane, 0, (size_t)n_frames * a.plane_frame_stride, s->st);
+        if (!counts_clean) (void)hipMemsetAsync(a.tile_counts, 0, tile_counts_bytes(s), s->st);
         if (a.dense_mask) hipExtLaunchKernelGGL((k_stream_u16<2, true, true>), stream_grid(a, n_frames), dim3(64), 0, s->st, start, stop, 0, a);
         else hipExtLaunchKernelGGL((k_stream_u16<2, true, false>), stream_grid(a, n_frames), dim3(64), 0, s->st, start, stop, 0, a);
-        hipLaunchKernelGGL((k_bright_fix<uint16_t, true>), dim3(32), dim3(256), 0, s->st, a);
+        if (fix_here) hipLaunchKernelGGL((k_bright_fix<uint16_t, true>), dim3(32), dim3(256), 0, s->st, a);
         return;
     }
     dim3 g1((unsigned)(a.ext_strips * a.ext_bands), n_frames);
     if (s->ctx->pixel_bytes == 2) hipExtLaunchKernelGGL(k_ext_first<uint16_t>, g1, dim3(64), 0, s->st, start, stop, 0, a);
     else hipExtLaunchKernelGGL(k_ext_first<uint32_t>, g1, dim3(64), 0, s->st, start, stop, 0, a);
 }
-static void launch_ext_rest(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
+static void launch_ext_rest(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames, hipStream_t st) {
     const bool u16 = s->ctx->pixel_bytes == 2;
     // The byte mask: the streaming kernel zero-filled it if somebody wants it (k_ext_final sets 1s in it either way; without a
     // taker they land in a buffer nobody reads); after k_ext_first it is always produced, so zero it here.
-    if (!ext_stream_first(a)) (void)hipMemsetAsync(a.strong_bytes, 0, (size_t)n_frames * a.bytes_frame_stride, s->st);
+    if (!ext_stream_first(a)) (void)hipMemsetAsync(a.strong_bytes, 0, (size_t)n_frames * a.bytes_frame_stride, st);
     const unsigned erode_lanes = (a.mpitch / 4) * (unsigned)((a.H + kErodeRows - 1) / kErodeRows);
-    hipLaunchKernelGGL(k_ext_erode, dim3((erode_lanes + 255) / 256, n_frames), dim3(256), 0, s->st, a);
+    hipLaunchKernelGGL(k_ext_erode, dim3((erode_lanes + 255) / 256, n_frames), dim3(256), 0, st, a);
     dim3 g3((unsigned)a.n_tiles, n_frames);
-    if (u16) hipLaunchKernelGGL(k_ext_final<uint16_t>, g3, dim3(256), 0, s->st, a);
-    else hipLaunchKernelGGL(k_ext_final<uint32_t>, g3, dim3(256), 0, s->st, a);
+    if (u16) hipLaunchKernelGGL(k_ext_final<uint16_t>, g3, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_ext_final<uint32_t>, g3, dim3(256), 0, st, a);
 }
 
 int ensure_extended_buffers(ffs_stream* s) {
     if (s->d_dplane) return FFS_OK;
     ffs_ctx* c = s->ctx;
     const size_t bytes = (size_t)s->max_batch * c->L.plane_frame_stride;
-    if (dmalloc(&s->d_dplane, bytes) != hipSuccess || dmalloc(&s->d_eplane, bytes) != hipSuccess) {
+    s->dplane2_clean = false;
+    if (dmalloc(&s->d_dplane, bytes) != hipSuccess || dmalloc(&s->d_dplane2, bytes) != hipSuccess || dmalloc(&s->d_eplane, bytes) != hipSuccess) {
         (void)hipGetLastError();
         c->err = "hipMalloc(extended dispersion planes) failed";
         return FFS_ERR_NOMEM;
@@ -235,7 +259,7 @@ void bench_launch_dense(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames
     else launch_stream(s, a, n_frames, start, stop);
 }
 void bench_launch_rest(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
-    if (s->batch_params.algorithm == FFS_ALGO_DISPERSION_EXTENDED) launch_ext_rest(s, a, n_frames);
+    if (s->batch_params.algorithm == FFS_ALGO_DISPERSION_EXTENDED) launch_ext_rest(s, a, n_frames, s->st);
     else if (a.bright_to_plane) launch_exact(s, a, n_frames, s->st);
     else if (!a.wlog) launch_bright_fix(s, a, s->st);   // (with wave logs the sparse launch decides the bright windows)
 }
@@ -279,10 +303,15 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
 
     (void)hipGetLastError();  // drop any stale error state: the check below is for OUR launches
     if (s->st_up != s->st && !s->dev_input) HIP_TRY(c, hipStreamWaitEvent(s->st, s->ev[1], 0));   // the frames are in place (upload / decode stream)
+    bool ext_plane_clean = false;
     if (ext) {
         const int rc = ensure_extended_buffers(s);
         if (rc != FFS_OK) return rc;
+        std::swap(s->d_dplane, s->d_dplane2);   // this batch's plane: the one cleared behind the previous batch (d_dplane2 keeps that batch's)
+        ext_plane_clean = s->dplane2_clean;
+        s->dplane2_clean = false;
     }
+    const bool counts_were_clean = !s->counts_dirty;
     const ThresholdArgs ta = make_threshold_args(s, d_img, pitch, fstride, n);
     // "streamed": the plane the sparse stage reads was produced by a streaming kernel into a zeroed plane (and is zeroed
     // again by the compaction); path 0 also keeps the occupancy bitmap in step with it
@@ -340,9 +369,23 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
     }
     hipEvent_t ev_start = nullptr;
     if (s->ev1_pending) { ev_start = s->ev[1]; s->ev1_pending = false; }
-    if (ext) {
-        launch_ext_first(s, ta, n, ev_start, nullptr);
-        launch_ext_rest(s, ta, n);
+    if (ext && s->st2 != s->st && c->tune.ext_rest_aside) {
+        // The dense stream carries the first pass alone; erosion and the final pass -- a latency-bound gather over the signal
+        // region that keeps the vector units half busy -- go to the batch's sparse stream, ahead of its sparse launch, and run
+        // BESIDE the next batch's first pass (an issue-bound stream of the whole frame) instead of between two of them.
+        if (ext_stream_first(ta)) {   // (the first pass's stop event rides on its dispatch; the bright-window fix-up goes aside too)
+            launch_ext_first(s, ta, n, ev_start, s->ev[2], false, ext_plane_clean, counts_were_clean);
+            HIP_TRY(c, hipStreamWaitEvent(s->st2, s->ev[2], 0));
+            hipLaunchKernelGGL((k_bright_fix<uint16_t, true>), dim3(32), dim3(256), 0, s->st2, ta);
+        } else {
+            launch_ext_first(s, ta, n, ev_start, nullptr);
+            HIP_TRY(c, hipEventRecord(s->ev[2], s->st));
+            HIP_TRY(c, hipStreamWaitEvent(s->st2, s->ev[2], 0));
+        }
+        launch_ext_rest(s, ta, n, s->st2);
+    } else if (ext) {
+        launch_ext_first(s, ta, n, ev_start, nullptr, true, ext_plane_clean, counts_were_clean);
+        launch_ext_rest(s, ta, n, s->st);
         HIP_TRY(c, hipEventRecord(s->ev[2], s->st));
         if (s->st2 != s->st) HIP_TRY(c, hipStreamWaitEvent(s->st2, s->ev[2], 0));
     } else if (list_path && aside) {
@@ -463,6 +506,11 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
             if (aside) c->chain_ev_newest.store(slot);
         }
         HIP_TRY(c, hipGetLastError());
+        if (ext && ext_stream_first(ta) && s->st2 != s->st) {
+            // the plane the previous batch used (nobody reads it any more) is cleared here, beside the dense kernels, for the next batch
+            HIP_TRY(c, hipMemsetAsync(s->d_dplane2, 0, (size_t)s->max_batch * L.plane_frame_stride, s->st2));
+            s->dplane2_clean = true;
+        }
         HIP_TRY(c, hipEventRecord(s->ev[4], s->st2));
         s->ev3_is_ev4 = true;
         s->spec_recs_copied = (uint64_t)s->max_batch * s->max_comp;

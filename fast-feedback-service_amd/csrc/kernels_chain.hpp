@@ -673,7 +673,8 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
             uint8_t* sbytes = a.strong_bytes + (uint64_t)frame * a.bytes_frame_stride;
             const uint32_t ns = min(l_ns, (uint32_t)kMaxStrips);
             for (int band = wave; band < T.n_bands; band += kChainWaves) {
-                const int yb0 = band * T.band_rows, yb1 = min(yb0 + T.band_rows, a.H);
+                const int yb0 = band_first_row(band, T.band_rows, T.band_rows2, T.band_split);
+                const int yb1 = min(band_first_row(band + 1, T.band_rows, T.band_rows2, T.band_split), (int)a.H);
                 for (int r0 = yb0; r0 < yb1; r0 += cw_rows) {   // (bands taller than the counters: in pieces)
                     const int r1 = min(r0 + cw_rows, yb1);
                     for (int i = lane; i < (r1 - r0) * kMaxStrips; i += 64) cw[i] = 0;

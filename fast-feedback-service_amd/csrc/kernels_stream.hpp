@@ -181,8 +181,8 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     }
     const int f0 = blockIdx.y * a.group_frames;                   // first frame of this super row
     const int nf = min(a.group_frames, a.n_frames - f0);
-    const int yb0 = band * a.band_rows;
-    const int yb1 = min(yb0 + a.band_rows, a.H);
+    const int yb0 = band_first_row(band, a.band_rows, a.band_rows2, a.band_split);
+    const int yb1 = min(band_first_row(band + 1, a.band_rows, a.band_rows2, a.band_split), a.H);
 
     // lane -> (frame, group) in the super row; group a.gpf of every frame is the empty separator
     const int gsep = a.gpf + 1;
@@ -352,9 +352,6 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                 //   af - 2^-20 t0 >  cf (1 + 2^-18)   -> certainly above (float64 roundings of the oracle: 2^-50 t0, far inside)
                 // and only the band between the two takes the float64 test of phase 2 (a few pixels per million).
                 const uint32_t valid = ginf >> 24;
-                uint32_t wq = 0;  // window j sums cq[j .. j+6]
-#pragma unroll
-                for (int t = 0; t < 7; ++t) wq += s_q[16 + t][lane];
                 // one count for the whole group almost everywhere: its root is taken once
                 const float kq_group = a.kB * __builtin_amdgcn_sqrtf(2.0f * ((float)gmin - 1.0f));
 #pragma unroll
@@ -363,7 +360,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                     const uint32_t pw = s_q[8 + (j >> 1)][lane];
                     const uint32_t pv = (j & 1) ? pw >> 16 : pw & 0xFFFFu;
                     const uint32_t m = ((j < 4 ? mm.x : mm.y) >> (8 * (j & 3))) & 0xFFu;
-                    const float mf = (float)m, xf = (float)x, yf = (float)wq;
+                    const float mf = (float)m, xf = (float)x, yf = (float)s_q[16 + j][lane];   // (the window's sum of p^2, as pushed)
                     const float kq = gmin == gmax ? kq_group : a.kB * __builtin_amdgcn_sqrtf(2.0f * (mf - 1.0f));
                     const float t0 = mf * yf;
                     const float af = t0 - xf * (xf + (mf - 1.0f));
@@ -375,7 +372,6 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                     const bool ok = ((valid >> j) & 1u) && (int)m >= a.min_count && !(a.max_valid >= 0 && (long long)pv > a.max_valid);
                     todo |= (ok && maybe && !yes) ? (1u << j) : 0u;
                     sure |= (ok && yes) ? (1u << j) : 0u;
-                    if (j < 7) wq = wq - s_q[16 + j][lane] + s_q[23 + j][lane];
                 }
                 s_q[14][lane] = sure;
             } else {
@@ -414,8 +410,12 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                 if (x < 65536u) {
                     // sum p^2 mod 2^32 is the true sum while x < 65536 (y <= 65535 x < 2^32); window j = cq[j .. j+6]
                     uint32_t y = 0;
+                    if constexpr (EXT) {
+                        y = s_q[16 + j][e];
+                    } else {
 #pragma unroll
-                    for (uint32_t t = 0; t < 7; ++t) y += s_q[16 + j + t][e];
+                        for (uint32_t t = 0; t < 7; ++t) y += s_q[16 + j + t][e];
+                    }
                     bool certain;
                     bool strong;
                     if constexpr (EXT) {
@@ -526,6 +526,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                 const uint32_t xmin = min(min(min(min(Wn[0], Wn[1]), Wn[2]), min(min(Wn[3], Wn[4]), Wn[5])), min(Wn[6], Wn[7]));
                 const uint32_t mmin = (info >> 8) & 0xFFu, mmax = (info >> 16) & 0xFFu;
                 bool pass;
+                [[maybe_unused]] uint32_t ys[8];   // EXT: the eight windows' sums of p^2 (the queue takes them as they are)
                 if constexpr (EXT) {
                     // For every valid pixel j of the group:  a_j = m_j y_j - x_j^2 - x_j (m_j - 1) <= mmax y_j - x_j (x_j + mmin - 1)  and
                     // c_j = nsig_b x_j sqrt(2 (m_j - 1)) >= nsig_b x_j sqrt(2 (mmin - 1)).  The eight windows of sum p^2 slide over
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                     // per pixel (a bound per GROUP pairs the largest sum p^2 with the smallest sum p and lets most of the
                     // background through): d_j = [mmax y_j - x_j (x_j + mmin - 1)] (1 + 2^-20) - kB x_j sqrt(2 (mmin - 1)),
                     // a pixel can only pass the first pass where d_j >= 0; the lane keeps the largest d_j
-                    const uint32_t ys[8] = {y0, y1, y2, y3, y4, y5, y6, y7};
+                    ys[0] = y0; ys[1] = y1; ys[2] = y2; ys[3] = y3; ys[4] = y4; ys[5] = y5; ys[6] = y6; ys[7] = y7;
                     // d_j = c1 y_j - x_j (x_j + c2) with c1 = mmax (1 + 2^-19) and c2 = (mmin - 1 + kB sqrt(2 (mmin - 1))) (1 - 2^-21): an upper
                     // bound of a_j - c_j in float32 whatever the roundings do (y_j, x_j + c2, the product and the fused difference:
                     // each within 2^-24 of a term no larger than c1 y_j or x_j (x_j + c2); the two factors grant 2^-19 and 2^-21 of
@@ -580,6 +581,23 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                 if (fm) {  // wave-uniform
                     const int nfl = __popcll(fm);
                     if (qn + nfl > kQCap) drain();
+                    if constexpr (EXT) {
+                        // the first pass's screen has the eight windows' sums of p^2 in hand: they go into the queue as they are
+                        // (words 16-23) -- no neighbour exchange, six words less, and the drain does not slide windows again
+                        if (flag && !FFS_DBG(a, 32)) {
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                            const int e = qn + (int)rank;   // < kQCap: after a drain qn = 0 and nfl <= 62
+#pragma unroll
+                            for (int w = 0; w < 8; ++w) {
+                                s_q[w][e] = Wn[w];
+                                s_q[16 + w][e] = ys[w];
+                            }
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) s_q[8 + w][e] = ring[sc][w];
+                            s_q[15][e] = info;
+                            s_q[30][e] = ((uint32_t)yout << 6) | (uint32_t)lane;
+                        }
+                    } else {
                     // the group's 14 column sums of p^2 (own 8 + 3 from each neighbour lane)
                     const uint32_t QL5 = from_left(colq[5]), QL6 = from_left(colq[6]), QL7 = from_left(colq[7]);
                     const uint32_t QR0 = from_right(colq[0]), QR1 = from_right(colq[1]), QR2 = from_right(colq[2]);
@@ -597,6 +615,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                         s_q[16][e] = QL5; s_q[17][e] = QL6; s_q[18][e] = QL7;
                         s_q[27][e] = QR0; s_q[28][e] = QR1; s_q[29][e] = QR2;
                         s_q[30][e] = ((uint32_t)yout << 6) | (uint32_t)lane;
+                    }
                     }
                     qn += nfl;
                 }
@@ -658,8 +677,8 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
     }
     const int f0 = blockIdx.y * a.group_frames;
     const int nf = min(a.group_frames, a.n_frames - f0);
-    const int yb0 = band * a.band_rows;
-    const int yb1 = min(yb0 + a.band_rows, a.H);
+    const int yb0 = band_first_row(band, a.band_rows, a.band_rows2, a.band_split);
+    const int yb1 = min(band_first_row(band + 1, a.band_rows, a.band_rows2, a.band_split), a.H);
 
     const int gsep = a.gpf + 1;   // a.gpf = groups of four pixels per frame row
     const int G = strip * kSOwned + lane - 1;

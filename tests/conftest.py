@@ -4,6 +4,11 @@ import sys
 
 import pytest
 
+try:   # torch brings its own copy of the HIP runtime: it has to be in the process BEFORE libffs_hip.so pulls in /opt/rocm's (two
+    import torch  # noqa: F401  runtimes in one process cannot both have the GPU; bench.py imports torch first for the same reason)
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "fast-feedback-service_amd")
 sys.path.insert(0, os.path.join(PKG, "python"))

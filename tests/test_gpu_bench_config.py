@@ -14,6 +14,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before libffs_hip.so is loaded: torch brings its own copy of the HIP runtime, and two runtimes in one
+#                            process cannot both have the GPU -- bench.py imports torch first for the same reason)
 
 from util import assert_frame_matches_oracle, oracle_frame
 
