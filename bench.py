@@ -400,6 +400,7 @@ def cli_e2e(n_images=1000, threads=None, batch=None, cpu_decode_images=256, keep
                 except ValueError:
                     pass
             return {"frames_per_s": float(m.group(3)), "images": int(m.group(1)), "binary_s": float(m.group(2)),
+                    "chunks_read_GBps": round(int(m.group(1)) * chunk / 1e9 / max(float(m.group(2)), 1e-9), 1),
                     "wall_s": round(wall, 2), "json_lines": ok, "stderr_bytes": len(p.stderr)}
 
         run([], 32)          # untimed warm-up of the binary (first GPU context of the process tree, page cache of the libraries)
@@ -414,6 +415,10 @@ def cli_e2e(n_images=1000, threads=None, batch=None, cpu_decode_images=256, keep
         if long_images > n_images:   # the fixed set-up and drain (tens of ms) against a run of the length of a real data set
             out["long_run_first_pass"] = run([], long_images)
             out["long_run"] = run([], long_images)
+        # two contexts on this one GPU, each with its own readers (2 x 8), batches dealt alternately: what the HOST side of a
+        # multi-GPU node has to sustain per pair of GPUs -- the frame source, the page cache and the memory system are shared by
+        # all GPUs of a host, PCIe is not (here both contexts share one link, so the frame rate stays at one GPU's)
+        out["two_contexts_one_gpu"] = run(["--devices", "0,0"], max(n_images, long_images))
         out["note"] = ("frames/s = the binary's own last line (timer from just before its workers start to after the last result, "
                        "stream set-up and pinned staging included); at most 8 of the threads feed the GPU when it decodes the chunks; "
                        "PCIe floor for 7.5 MB chunks at the 55 GB/s measured on this pool: ~7.3 k frames/s; every frame is a file of its own "

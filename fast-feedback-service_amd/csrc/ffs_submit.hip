@@ -227,11 +227,18 @@ bool wave_logs_for(ffs_stream* s, ThresholdArgs& a, uint32_t n_frames) {
           && (uint32_t)a.gpf / (uint32_t)kSOwned + 2u <= 16u && a.band_rows <= 1024 && L.W <= 65535))
         return false;
     const dim3 g = stream_grid(a, n_frames);
-    const size_t waves = (size_t)g.x * g.y;
+    size_t waves = (size_t)g.x * g.y;
     if (waves > s->wlog_waves) {
+        // Sized ONCE, for the largest launch any batch of this stream can make (1 .. max_batch frames), so that a batch of another
+        // size never re-allocates: hipFree synchronises the whole device, i.e. every other worker's batches in flight.  (A stream is
+        // idle here -- submit refuses a busy one, and a re-run inside ffs_wait comes after the batch's last event -- so nothing of
+        // its own has to be waited for if it does happen: a tuning change between batches.)
+        for (uint32_t nf = 1; nf <= s->max_batch; ++nf) {
+            const ThresholdArgs t = make_threshold_args(s, a.image, a.pitch, a.frame_stride, nf);
+            const dim3 gg = stream_grid(t, nf);
+            waves = std::max(waves, (size_t)gg.x * gg.y);
+        }
         if (s->d_wlog) {
-            (void)hipStreamSynchronize(s->st);
-            (void)hipStreamSynchronize(s->st2);
             (void)hipFree(s->d_wlog);
             (void)hipFree(s->d_wlog_n);
             (void)hipFree(s->d_wpix);
@@ -706,7 +713,24 @@ static int stage_chunks(ffs_stream* s, const void* const* chunks, const size_t* 
         }
         s->d_comp_bytes = want;
     }
-    HIP_TRY(c, hipMemcpyAsync(s->d_comp + lo, s->h_img + lo, hi - lo, hipMemcpyHostToDevice, s->st_up));
+    if (in_place) {
+        // chunks placed by the caller (a driver's fixed slots leave gaps between them): only the bytes of the chunks cross PCIe --
+        // ranges closer than 512 KB travel as one copy (the gap costs what a copy of its own would), each copy costs ~10 us of the caller's time
+        std::vector<std::pair<size_t, size_t>> r(n);
+        for (uint32_t f = 0; f < n; ++f) r[f] = {base[f] & ~(size_t)15, base[f] + chunk_bytes[f]};
+        std::sort(r.begin(), r.end());
+        size_t a = r[0].first, b = r[0].second;
+        for (uint32_t f = 1; f <= n; ++f) {
+            if (f < n && r[f].first <= b + 524288) { b = std::max(b, r[f].second); continue; }
+            HIP_TRY(c, hipMemcpyAsync(s->d_comp + a, s->h_img + a, b - a, hipMemcpyHostToDevice, s->st_up));
+            if (f < n) { a = r[f].first; b = r[f].second; }
+        }
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(s->d_comp + lo, s->h_img + lo, hi - lo, hipMemcpyHostToDevice, s->st_up));
+    }
+    // "this batch's chunks are on the device", recorded HERE: the upload stream is shared by the context's streams, and an event
+    // recorded later (by the helper thread, after the block index) would also wait for every other batch's chunks queued meanwhile
+    HIP_TRY(c, hipEventRecord(s->ev[6], s->st_up));
     return FFS_OK;
 }
 
@@ -715,7 +739,7 @@ static int stage_chunks(ffs_stream* s, const void* const* chunks, const size_t* 
 // the frames' chains are walked side by side so that their cache misses overlap -- and enqueues the
 // table copy.  Errors go to `err`, not to the context (another thread may own that string).
 static int index_blocks(ffs_stream* s, const std::vector<size_t>& base, const std::vector<size_t>& chunk_bytes,
-                        std::string& err) {
+                        std::string& err, hipStream_t tab_stream) {
     ffs_ctx* c = s->ctx;
     const uint32_t n = (uint32_t)base.size();
     const size_t es = c->pixel_bytes;
@@ -754,7 +778,8 @@ static int index_blocks(ffs_stream* s, const std::vector<size_t>& base, const st
         err = "ffs_submit_compressed: block lengths run past the end of a chunk";
         return FFS_ERR_INVALID;
     }
-    const hipError_t e = hipMemcpyAsync(s->d_tab, s->h_tab, (size_t)n * stride * sizeof(uint2), hipMemcpyHostToDevice, s->st_up);
+    // (the table goes up in the stream the decode kernel runs in: half a megabyte that must not queue behind other batches' chunks)
+    const hipError_t e = hipMemcpyAsync(s->d_tab, s->h_tab, (size_t)n * stride * sizeof(uint2), hipMemcpyHostToDevice, tab_stream);
     if (e != hipSuccess) {
         err = std::string("hipMemcpyAsync(block table): ") + hipGetErrorString(e);
         return FFS_ERR_DEVICE;
@@ -816,16 +841,13 @@ static int ffs_submit_compressed_impl(ffs_stream* s, const void* const* chunks, 
             s->job_err = "hipSetDevice failed on the stream's helper thread";
             return;
         }
-        int r = index_blocks(s, base, sizes, s->job_err);
+        // the decode kernel runs with the dense kernels (in their order), behind the copies of its input
+        hipStream_t dst = c->tune.decode_in_dense_stream ? s->st : s->st_up;
+        int r = index_blocks(s, base, sizes, s->job_err, dst);
         if (r == FFS_OK) {
             (void)hipGetLastError();
-            // the decode kernel runs with the dense kernels (in their order), behind the copies of its input
             hipError_t e = hipSuccess;
-            hipStream_t dst = c->tune.decode_in_dense_stream ? s->st : s->st_up;
-            if (dst != s->st_up) {
-                e = hipEventRecord(s->ev[6], s->st_up);
-                if (e == hipSuccess) e = hipStreamWaitEvent(dst, s->ev[6], 0);
-            }
+            if (dst != s->st_up) e = hipStreamWaitEvent(dst, s->ev[6], 0);
             launch_decode(s, n_frames, dst);
             if (e == hipSuccess) e = hipGetLastError();
             if (e == hipSuccess) e = hipEventRecord(s->ev[1], dst);
@@ -857,7 +879,7 @@ extern "C" int ffs_decode_only(ffs_stream* s, const void* const* chunks, const s
     int rc = stage_chunks(s, chunks, chunk_bytes, n_frames, base);
     if (rc == FFS_OK) {
         std::string err;
-        rc = index_blocks(s, base, std::vector<size_t>(chunk_bytes, chunk_bytes + n_frames), err);
+        rc = index_blocks(s, base, std::vector<size_t>(chunk_bytes, chunk_bytes + n_frames), err, s->st_up);
         if (rc != FFS_OK) c->err = err;
     }
     if (rc != FFS_OK) {

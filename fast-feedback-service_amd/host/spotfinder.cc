@@ -16,6 +16,7 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <condition_variable>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -53,9 +54,9 @@ struct Args {
     std::string file;
     bool sample = false, validate = false, writeout = false, save_h5 = false, output_for_index = false;
     bool verbose = false, strict_dtype = false;
-    uint32_t threads = 1, images = 0, min_spot_size = 3, min_spot_size_3d = 3, start_index = 0, batch = 0;
+    uint32_t threads = 1, images = 0, min_spot_size = 3, min_spot_size_3d = 3, start_index = 0, batch = 0, assemblies = 0;
     bool images_set = false, wavelength_set = false, detector_set = false;
-    float max_sep = 2.0f, timeout = 30.0f, dmin = -1.f, dmax = -1.f, wavelength = 0.f;
+    float max_sep = 2.0f, timeout = 30.0f, dmin = -1.f, dmax = -1.f, wavelength = 0.f, slot_margin = 2.0f;
     int pipe_fd = -1, device = 0;
     std::vector<int> devices;  // --devices / --gpus: the frame queue is dealt to all of them
     std::string algorithm = "dispersion", detector_json;
@@ -82,8 +83,9 @@ static void usage() {
       "--devices / --gpus: one context and worker pool per GPU, all pulling frames from the one queue\n"
       "              (-n threads are dealt round-robin to the GPUs, at least one each); rotation sweeps send\n"
       "              their strong-pixel lists to the first GPU's 3D stack (RCCL over xGMI, else peer copies)\n"
-      "--all-threads: every one of the -n threads feeds the GPU (default: at most eight per GPU when chunks are decoded there)\n"
-      "--single-buffer: one batch per worker at a time (default: two, the next is read while the first is on the GPU)\n"
+      "--all-threads: every one of the -n threads reads (default: at most eight per GPU when chunks are decoded there)\n"
+      "--batch N:   frames per GPU batch (default 16 chunks / 4 decoded frames); a batch is filled by all readers of its GPU\n"
+      "--single-buffer: one batch per GPU at a time (default: four of chunks / three of decoded frames, filled while the others are on the GPU)\n"
       "--read-only: (diagnostic) read every chunk into the staging areas and submit nothing\n"
       "environment, A/B only: FFS_SHM_PLAIN_READ=1 -- /dev/shm chunks by read() straight into the staging area instead of\n"
       "              through a cache-resident bounce buffer and non-temporal stores\n"
@@ -160,6 +162,8 @@ static Args parse_args(int argc, char** argv) {
         else if (s == "-h5" || s == "--save-h5") r.save_h5 = true;
         else if (s == "--output-for-index") r.output_for_index = true;
         else if (s == "--batch") r.batch = u32(need(i, s), s);
+        else if (s == "--assemblies") r.assemblies = u32(need(i, s), s);   // batches in flight per GPU (tuning; default below)
+        else if (s == "--slot-margin") r.slot_margin = f32(need(i, s), s);  // per cent of head room per chunk slot (tuning)
         else if (s == "--gpus") { const uint32_t n = u32(need(i, s), s); r.devices.clear(); for (uint32_t d = 0; d < n; ++d) r.devices.push_back((int)d); }
         else if (s == "--devices") {
             r.devices.clear();
@@ -447,9 +451,17 @@ int main(int argc, char** argv) {
     std::signal(SIGINT, stop_processing);
 
     // ---- device context -------------------------------------------------------------------------------
-    const uint32_t batch = args.batch ? args.batch : std::max<uint32_t>(1, std::min<uint32_t>(4, num_images / std::max(1u, args.threads)));
+    // bitshuffle-LZ4 chunks go to the GPU as they are (read straight into the pinned staging area) unless the pixels are
+    // needed on the host (--writeout) or --cpu-decode asks for the reference's way
+    const bool gpu_decode = reader.get_raw_chunk_compression() == Reader::BITSHUFFLE_LZ4 && !args.cpu_decode && !args.writeout;
+    // frames per GPU batch: chunks -- 16 (120 MB of staging per batch for Eiger-16M: the threshold kernels are tuned for 16-32
+    // frames and PCIe, not the GPU, is the limit); decoded frames are five times larger: 4.  Never more than half the data set per GPU.
+    const uint32_t n_dev_arg = (uint32_t)std::max<size_t>(1, args.devices.size());
+    const uint32_t batch = args.batch ? args.batch
+                                      : std::max<uint32_t>(1, std::min<uint32_t>(gpu_decode ? 16u : 4u, num_images / (2 * n_dev_arg)));
     std::printf("Image:       %4u x %4u = %u px\n", width, height, width * height);
-    std::printf("GPU batches: %u frames per submit, %s per worker\n", batch, args.single_buffer ? "one batch in flight" : "two batches in flight");
+    std::printf("GPU batches: %u frames per submit, filled by all readers of a GPU; %s\n", batch,
+                args.single_buffer ? "one batch in flight" : (gpu_decode ? "four batches in flight per GPU" : "three batches in flight per GPU"));
     std::printf("Running with %u CPU threads\n", args.threads);
 
     // One context per GPU (the reference has one device, -d: src/ffs/cuda_arg_parser.cc:30-61).  With
@@ -597,349 +609,474 @@ int main(int argc, char** argv) {
                             node_known[di] ? ", workers pinned to its CPUs" : " (workers not pinned)");
     }
 
-    // Every worker owns TWO streams and fills one while the other's batch is on the GPU: reading a batch of chunks from the
-    // frame source and the device work of the batch before it overlap inside the worker, not only across workers (the
-    // reference: one frame per thread, read, copy, kernel and host post-processing in sequence, spotfinder.cc:751-1008).
-    struct Slot {
+    // ---- batches assembled from several readers (round 4) ---------------------------------------------------------------
+    // The reference gives every worker thread one frame at a time: read, decompress, copy, kernel, copy back, connected
+    // components, in sequence (spotfinder.cc:751-1008).  Rounds 2-3 gave every worker batches of its own -- four frames, an
+    // eighth of what the kernels are tuned for, and sixteen small submissions in flight.  Now a GPU batch is an ASSEMBLY that all
+    // the GPU's reader threads fill together: global batch b holds images b B .. b B + B - 1, goes to GPU b mod n_dev, and sits
+    // in assembly (b / n_dev) mod K of that GPU (an ffs_stream with its pinned staging area cut into B slots).  A reader takes
+    // the next slot number from the GPU's counter, reads that image's chunk into its slot, and whoever fills a batch's last
+    // slot submits it.  One collector thread per GPU waits for the batches in order, hands out their results (in frame order)
+    // and frees the assembly for batch b + K n_dev.  Readers never wait for the GPU unless all K assemblies are in flight.
+    struct Assembly {
         ffs_stream* s = nullptr;
-        uint8_t* host = nullptr;       // the stream's pinned staging area (allocated on first use)
-        size_t host_bytes = 0;
+        ffs_stream* v = nullptr;       // --validate: the same batch on the validation context
+        uint8_t* host = nullptr;       // the stream's pinned staging area (allocated when the assembly is first claimed)
+        size_t host_bytes = 0, slot_bytes = 0;
+        size_t over_at = 0, over_used = 0;   // overflow area behind the slots
+        std::unique_ptr<std::mutex> over_mu = std::make_unique<std::mutex>();
         std::vector<const void*> chunk_ptr;
         std::vector<size_t> chunk_len;
-        bool in_flight = false;
-        ffs_stream* v = nullptr;       // --validate: the same batch on the validation context
+        std::vector<std::vector<uint8_t>> spill;   // chunks that did not fit their slot (their whole batch then goes up from here)
+        // state, under the GPU's mutex
+        int64_t batch = -1;            // the global batch this assembly holds, -1: free
+        uint64_t next_q = 0;           // the GPU-local batch number it serves next (claims happen in order)
+        uint32_t n = 0, filled = 0;
+        bool ready = false;            // staging area in place: slots may be filled
+        bool submitted = false, skipped = false;
+        int submitted_by = 0;
     };
+    struct Gpu {
+        ffs_ctx* ctx = nullptr;
+        ffs_ctx* vctx = nullptr;
+        uint32_t index = 0;
+        std::vector<Assembly> as;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::atomic<uint64_t> next_slot{0};
+    };
+    const size_t frame_bytes = (size_t)width * height * bytes_per_pixel;
+    const uint32_t K = args.single_buffer ? 1u : args.assemblies ? std::min(args.assemblies, 32u) : (gpu_decode ? 4u : 3u);
+    const uint64_t total_batches = ((uint64_t)num_images + batch - 1) / batch;
+    std::vector<std::unique_ptr<Gpu>> gpus;
+    for (uint32_t di = 0; di < n_dev; ++di) {
+        auto g = std::make_unique<Gpu>();
+        g->ctx = ctxs[di];
+        g->vctx = args.validate ? vctxs[di] : nullptr;
+        g->index = di;
+        g->as.resize(K);
+        for (uint32_t k = 0; k < K; ++k) {
+            Assembly& A = g->as[k];
+            A.next_q = k;
+            A.chunk_ptr.resize(batch);
+            A.chunk_len.resize(batch);
+            A.spill.resize(batch);
+        }
+        gpus.push_back(std::move(g));
+    }
+    std::atomic<size_t> chunk_estimate{0};   // staging bytes per compressed chunk, from the first chunk anybody reads
     std::atomic<uint32_t> validate_mismatches{0};
-    auto worker = [&](int thread_id) {
-        const size_t di = (size_t)thread_id % ctxs.size();
-        ffs_ctx* ctx = ctxs[di];  // this worker's GPU (shadows the home context)
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    auto wake_all = [&]() { for (auto& g : gpus) { std::lock_guard<std::mutex> lock(g->mu); g->cv.notify_all(); } };
+    auto fail = [&](const char* what, ffs_ctx* cx) {
+        std::printf("Error: %s%s\n", what, cx ? ffs_last_error(cx) : "");
+        failed = 1;
+        wake_all();
+    };
+
+    // ---- the collector of one GPU: results of its batches, in order (the reference's post-processing of an image, :901-1087) ----
+    auto collector = [&](uint32_t di) {
+        Gpu& G = *gpus[di];
+        ffs_ctx* ctx = G.ctx;
         if (node_known[di]) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &node_cpus[di]);
-        Slot slots[2];
-        const int n_slots = args.single_buffer ? 1 : 2;
-        const auto t_stream = std::chrono::steady_clock::now();
-        auto close_all = [&]() { for (Slot& q : slots) { if (q.s) { ffs_stream_destroy(q.s); q.s = nullptr; } if (q.v) { ffs_stream_destroy(q.v); q.v = nullptr; } } };
-        for (int k = 0; k < n_slots; ++k) {
-            if (ffs_stream_create(ctx, &slots[k].s) != FFS_OK || (args.validate && ffs_stream_create(vctxs[di], &slots[k].v) != FFS_OK)) {
-                std::printf("Error: %s\n", ffs_last_error(ctx));
-                failed = 1;
-                close_all();
-                return;
+        double t_wait = 0, t_emit = 0;
+        uint32_t n_batches = 0;
+        for (uint64_t q = 0;; ++q) {
+            const uint64_t b = q * n_dev + di;
+            if (b >= total_batches) break;
+            Assembly& A = G.as[q % K];
+            {
+                std::unique_lock<std::mutex> lock(G.mu);
+                G.cv.wait(lock, [&] { return (A.batch == (int64_t)b && A.submitted) || g_stop.load() || failed.load(); });
+                if (!(A.batch == (int64_t)b && A.submitted)) break;   // interrupted / timed out / failed: what is not submitted is dropped
             }
-            slots[k].chunk_ptr.resize(batch);
-            slots[k].chunk_len.resize(batch);
+            const uint32_t thread_id = (uint32_t)A.submitted_by;
+            if (!A.skipped) {
+                const ffs_frame_result* res = nullptr;
+                uint32_t nres = 0;
+                const auto t_w0 = now();
+                const int wrc = ffs_wait(A.s, &res, &nres);
+                t_wait += secs(t_w0, now());
+                const auto t_e0 = now();
+                if (wrc != FFS_OK) { fail("", ctx); break; }
+                float tm[5] = {0};
+                ffs_stream_timings(A.s, tm);
+                const ffs_frame_result* vres = nullptr;
+                if (A.v) {
+                    uint32_t nv = 0;
+                    if (ffs_wait(A.v, &vres, &nv) != FFS_OK || nv != nres) { fail("validation pass: ", G.vctx); break; }
+                }
+                if (rotation) {
+                    // key = image number read (rotation_slices[offset_image_num], :913-918); the stack has its own lock (the
+                    // reference's rotation_slices_mutex), held only while the transfer is enqueued
+                    if (ffs_stack3d_add_batch(stack, A.s) != FFS_OK) { fail("", ctx); break; }
+                }
+                for (uint32_t i = 0; i < nres; ++i) {
+                    const ffs_frame_result& r = res[i];
+                    const uint32_t image_num = (uint32_t)r.frame_id;
+                    if (args.writeout && r.strong_mask) {  // :937-994
+                        const uint8_t* px = A.host + (size_t)i * frame_bytes;
+                        std::vector<uint8_t> img((size_t)width * height * 3);
+                        for (size_t k = 0; k < (size_t)width * height; ++k) {
+                            const float v = bytes_per_pixel == 2 ? (float)reinterpret_cast<const uint16_t*>(px)[k]
+                                                                 : (float)reinterpret_cast<const uint32_t*>(px)[k];
+                            const uint8_t g = (uint8_t)std::max(0.0f, 255.99f - v * 10);
+                            img[3 * k] = img[3 * k + 1] = img[3 * k + 2] = g;
+                        }
+                        auto put = [&](long x, long y) {
+                            if (x >= 0 && y >= 0 && x < (long)width && y < (long)height) {
+                                const size_t k = (size_t)y * width + x;
+                                img[3 * k] = 0; img[3 * k + 1] = 0; img[3 * k + 2] = 255;
+                            }
+                        };
+                        for (uint32_t bi = 0; bi < r.n_boxes; ++bi) {
+                            const ffs_box& bx = r.boxes[bi];
+                            for (int e = 5; e <= 7; ++e) {
+                                for (long x = (long)bx.l - e; x <= (long)bx.r + e; ++x) { put(x, (long)bx.t - e); put(x, (long)bx.b + e); }
+                                for (long y = (long)bx.t - e; y <= (long)bx.b + e; ++y) { put((long)bx.l - e, y); put((long)bx.r + e, y); }
+                            }
+                        }
+                        char name[64];
+                        std::snprintf(name, sizeof name, "pixels_%05u.txt", image_num);
+                        std::ofstream out(name);
+                        for (uint32_t y = 0, k = 0; y < height; ++y)
+                            for (uint32_t x = 0; x < width; ++x, ++k)
+                                if (r.strong_mask[k]) {
+                                    img[3 * k] = 255; img[3 * k + 1] = 0; img[3 * k + 2] = 0;
+                                    char line[32];
+                                    std::snprintf(line, sizeof line, "%4u, %4u\n", x, y);
+                                    out << line;
+                                }
+                        std::snprintf(name, sizeof name, "image_%05u.png", image_num);
+                        write_png_rgb(name, img.data(), width, height);
+                    }
+                    if (args.save_h5 && !rotation) {  // :919-933
+                        std::vector<float> coms;
+                        for (uint32_t qq = 0; qq < r.n_reflections; ++qq) {
+                            coms.push_back(r.reflections[qq].com_x);
+                            coms.push_back(r.reflections[qq].com_y);
+                            coms.push_back(r.reflections[qq].com_z);
+                        }
+                        std::lock_guard<std::mutex> lock(reflection_centers_2d_mutex);
+                        reflection_centers_2d[image_num + args.start_index] = std::move(coms);
+                    }
+                    if (pipe) {  // keys in alphabetical order, as nlohmann dumps them (:997-1008)
+                        std::string j = "{\"file\":" + json_escape(file) + ",\"file-number\":" + std::to_string(image_num)
+                                        + ",\"n_spots_total\":" + std::to_string(r.n_boxes)
+                                        + ",\"num_strong_pixels\":" + std::to_string(r.num_strong_pixels);
+                        if (args.output_for_index) {
+                            j += ",\"spot_centers\":[";
+                            for (uint32_t qq = 0; qq < r.n_reflections; ++qq) {
+                                if (qq) j += ",";
+                                j += json_number(r.reflections[qq].com_x) + "," + json_number(r.reflections[qq].com_y) + ","
+                                     + json_number(r.reflections[qq].com_z);
+                            }
+                            j += "]";
+                        }
+                        pipe->send(j + "}");
+                    }
+                    std::lock_guard<std::mutex> lock(print_mutex);
+                    if (vres) {  // :1012-1053
+                        const ffs_frame_result& v = vres[i];
+                        const bool same = r.strong_mask && v.strong_mask && std::memcmp(r.strong_mask, v.strong_mask, (size_t)width * height) == 0
+                                          && r.num_strong_pixels == v.num_strong_pixels && r.n_boxes == v.n_boxes;
+                        if (same) std::printf("Thread %2u, Image %4u: Compared: \033[32mMatch %u px\033[0m\n", thread_id, image_num, r.num_strong_pixels);
+                        else {
+                            std::printf("Thread %2u, Image %4u: Compared: \033[1;31mMismatch (%u px from kernel)\033[0m\n", thread_id, image_num, r.num_strong_pixels);
+                            validate_mismatches += 1;
+                        }
+                    }
+                    std::printf("Extracted %u spots\n", r.n_components);  // connected_components.cc:119
+                    if (prm.min_spot_size > 0)
+                        std::printf("Removed %u spots with size < %u pixels\n", r.n_components - r.n_boxes, prm.min_spot_size);
+                    if (prm.want_reflections && r.n_filtered_sep > 0)
+                        std::printf("Filtered %u spots with peak-centroid distance > %s\n", r.n_filtered_sep, fmt_num(prm.max_peak_centroid_separation).c_str());
+                    if (args.threads == 1) {  // :1056-1076 (timings are per batch here)
+                        std::printf("Thread %2u finished image %4u\n       Copy: %5.1f ms\n     Kernel: %5.1f ms\n  Post Copy: %5.1f ms\n"
+                                    "       Post: %5.1f ms\n             \xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\n"
+                                    "     Total:  %5.1f ms (%.1f GBps)\n    %u strong pixels\n    %u filtered reflections (%u pixels)\n",
+                                    thread_id, image_num, tm[0] / nres, tm[1] / nres, tm[3] / nres, tm[2] / nres, tm[4] / nres,
+                                    (double)frame_bytes * nres / (tm[4] * 1e-3) / 1e9, r.num_strong_pixels, r.n_boxes,
+                                    r.num_strong_pixels_filtered);
+                    } else {  // :1078-1085
+                        std::printf("Thread %2u finished image %4u with %5u strong pixels, %4u filtered reflections (%u pixels)\n",
+                                    thread_id, image_num, r.num_strong_pixels, r.n_boxes, r.num_strong_pixels_filtered);
+                    }
+                    completed += 1;
+                }
+                t_emit += secs(t_e0, now());
+            } else {
+                completed += A.n;   // --read-only: nothing was submitted
+            }
+            ++n_batches;
+            {
+                std::lock_guard<std::mutex> lock(G.mu);
+                A.batch = -1;
+                A.next_q += K;
+                A.submitted = false;
+                G.cv.notify_all();
+            }
         }
         if (args.verbose) {
             std::lock_guard<std::mutex> lock(print_mutex);
-            std::printf("Thread %2d: streams ready after %.0f ms (%.0f ms since the start)\n", thread_id,
-                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_stream).count(),
-                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - all_start).count());
+            std::printf("GPU %d collector: %u batches; waiting for the GPU %.0f ms, results out %.0f ms, done %.0f ms after the start\n",
+                        devices[di], n_batches, t_wait * 1e3, t_emit * 1e3, secs(all_start, now()) * 1e3);
         }
-        const size_t frame_bytes = (size_t)width * height * bytes_per_pixel;
-        std::vector<uint8_t> raw(frame_bytes * (bytes_per_pixel == 2 ? 2 : 1) + 4096);
-        // bitshuffle-LZ4 chunks go to the GPU as they are (read straight into the pinned staging buffer)
-        // unless the pixels are needed on the host (--writeout) or --cpu-decode asks for the reference's way
-        const bool gpu_decode = reader.get_raw_chunk_compression() == Reader::BITSHUFFLE_LZ4 && !args.cpu_decode
-                                && !args.writeout;
-        // The pinned staging area is what a worker's set-up costs (~170 ms per GB, serialised over all threads by the runtime):
-        // decoded frames need `batch` frames of it; chunks that the GPU decodes need `batch` CHUNKS, sized once the first one
-        // has been seen (+ 25 %), and a batch that does not fit is cut short -- the area then grows for the next one.
-        size_t chunk_estimate = 0;
-        auto take_host = [&](Slot& S, size_t want) {
-            void* v = nullptr;
-            if (ffs_stream_reserve_host(S.s, want) != FFS_OK || ffs_stream_host_buffer(S.s, &v, &S.host_bytes) != FFS_OK) {
-                std::printf("Error: %s\n", ffs_last_error(ctx));
-                failed = 1;
-                return false;
-            }
-            S.host = static_cast<uint8_t*>(v);
-            return true;
-        };
+    };
 
-        double t_wait = 0, t_emit = 0;
-        // wait for a slot's batch and hand out its results (the reference's post-processing of one image, :901-1087)
-        auto collect = [&](Slot& S) -> bool {
-            if (!S.in_flight) return true;
-            S.in_flight = false;
-            const ffs_frame_result* res = nullptr;
-            uint32_t nres = 0;
-            const auto t_w0 = std::chrono::steady_clock::now();
-            const int wrc = ffs_wait(S.s, &res, &nres);
-            t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w0).count();
-            const auto t_e0 = std::chrono::steady_clock::now();
-            struct EmitTimer { double& acc; std::chrono::steady_clock::time_point t0;
-                               ~EmitTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } emit_timer{t_emit, t_e0};
-            if (wrc != FFS_OK) {
-                std::printf("Error: %s\n", ffs_last_error(ctx));
-                failed = 1;
-                return false;
-            }
-            float tm[5] = {0};
-            ffs_stream_timings(S.s, tm);
-            const ffs_frame_result* vres = nullptr;
-            if (S.v) {
-                uint32_t nv = 0;
-                if (ffs_wait(S.v, &vres, &nv) != FFS_OK || nv != nres) {
-                    std::printf("Error: validation pass: %s\n", ffs_last_error(vctxs[di]));
-                    failed = 1;
-                    return false;
-                }
-            }
-            if (rotation) {
-                // key = image number read (rotation_slices[offset_image_num], :913-918); the stack has its own lock (the
-                // reference's rotation_slices_mutex), held only while the transfer is enqueued
-                if (ffs_stack3d_add_batch(stack, S.s) != FFS_OK) { std::printf("Error: %s\n", ffs_last_error(ctx)); failed = 1; return false; }
-            }
-            for (uint32_t i = 0; i < nres; ++i) {
-                const ffs_frame_result& r = res[i];
-                const uint32_t image_num = (uint32_t)r.frame_id;
-                if (args.writeout && r.strong_mask) {  // :937-994
-                    const uint8_t* px = S.host + (size_t)i * frame_bytes;
-                    std::vector<uint8_t> img((size_t)width * height * 3);
-                    for (size_t k = 0; k < (size_t)width * height; ++k) {
-                        const float v = bytes_per_pixel == 2 ? (float)reinterpret_cast<const uint16_t*>(px)[k]
-                                                             : (float)reinterpret_cast<const uint32_t*>(px)[k];
-                        const uint8_t g = (uint8_t)std::max(0.0f, 255.99f - v * 10);
-                        img[3 * k] = img[3 * k + 1] = img[3 * k + 2] = g;
-                    }
-                    auto put = [&](long x, long y) {
-                        if (x >= 0 && y >= 0 && x < (long)width && y < (long)height) {
-                            const size_t k = (size_t)y * width + x;
-                            img[3 * k] = 0; img[3 * k + 1] = 0; img[3 * k + 2] = 255;
-                        }
-                    };
-                    for (uint32_t bi = 0; bi < r.n_boxes; ++bi) {
-                        const ffs_box& b = r.boxes[bi];
-                        for (int e = 5; e <= 7; ++e) {
-                            for (long x = (long)b.l - e; x <= (long)b.r + e; ++x) { put(x, (long)b.t - e); put(x, (long)b.b + e); }
-                            for (long y = (long)b.t - e; y <= (long)b.b + e; ++y) { put((long)b.l - e, y); put((long)b.r + e, y); }
-                        }
-                    }
-                    char name[64];
-                    std::snprintf(name, sizeof name, "pixels_%05u.txt", image_num);
-                    std::ofstream out(name);
-                    for (uint32_t y = 0, k = 0; y < height; ++y)
-                        for (uint32_t x = 0; x < width; ++x, ++k)
-                            if (r.strong_mask[k]) {
-                                img[3 * k] = 255; img[3 * k + 1] = 0; img[3 * k + 2] = 0;
-                                char line[32];
-                                std::snprintf(line, sizeof line, "%4u, %4u\n", x, y);
-                                out << line;
-                            }
-                    std::snprintf(name, sizeof name, "image_%05u.png", image_num);
-                    write_png_rgb(name, img.data(), width, height);
-                }
-                if (args.save_h5 && !rotation) {  // :919-933
-                    std::vector<float> coms;
-                    for (uint32_t q = 0; q < r.n_reflections; ++q) {
-                        coms.push_back(r.reflections[q].com_x);
-                        coms.push_back(r.reflections[q].com_y);
-                        coms.push_back(r.reflections[q].com_z);
-                    }
-                    std::lock_guard<std::mutex> lock(reflection_centers_2d_mutex);
-                    reflection_centers_2d[image_num + args.start_index] = std::move(coms);
-                }
-                if (pipe) {  // keys in alphabetical order, as nlohmann dumps them (:997-1008)
-                    std::string j = "{\"file\":" + json_escape(file) + ",\"file-number\":" + std::to_string(image_num)
-                                    + ",\"n_spots_total\":" + std::to_string(r.n_boxes)
-                                    + ",\"num_strong_pixels\":" + std::to_string(r.num_strong_pixels);
-                    if (args.output_for_index) {
-                        j += ",\"spot_centers\":[";
-                        for (uint32_t q = 0; q < r.n_reflections; ++q) {
-                            if (q) j += ",";
-                            j += json_number(r.reflections[q].com_x) + "," + json_number(r.reflections[q].com_y) + ","
-                                 + json_number(r.reflections[q].com_z);
-                        }
-                        j += "]";
-                    }
-                    pipe->send(j + "}");
-                }
-                std::lock_guard<std::mutex> lock(print_mutex);
-                if (vres) {  // :1012-1053
-                    const ffs_frame_result& v = vres[i];
-                    const bool same = r.strong_mask && v.strong_mask && std::memcmp(r.strong_mask, v.strong_mask, (size_t)width * height) == 0
-                                      && r.num_strong_pixels == v.num_strong_pixels && r.n_boxes == v.n_boxes;
-                    if (same) std::printf("Thread %2d, Image %4u: Compared: \033[32mMatch %u px\033[0m\n", thread_id, image_num, r.num_strong_pixels);
-                    else {
-                        std::printf("Thread %2d, Image %4u: Compared: \033[1;31mMismatch (%u px from kernel)\033[0m\n", thread_id, image_num, r.num_strong_pixels);
-                        validate_mismatches += 1;
-                    }
-                }
-                std::printf("Extracted %u spots\n", r.n_components);  // connected_components.cc:119
-                if (prm.min_spot_size > 0)
-                    std::printf("Removed %u spots with size < %u pixels\n", r.n_components - r.n_boxes, prm.min_spot_size);
-                if (prm.want_reflections && r.n_filtered_sep > 0)
-                    std::printf("Filtered %u spots with peak-centroid distance > %s\n", r.n_filtered_sep, fmt_num(prm.max_peak_centroid_separation).c_str());
-                if (args.threads == 1) {  // :1056-1076 (timings are per batch here)
-                    std::printf("Thread %2d finished image %4u\n       Copy: %5.1f ms\n     Kernel: %5.1f ms\n  Post Copy: %5.1f ms\n"
-                                "       Post: %5.1f ms\n             \xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\n"
-                                "     Total:  %5.1f ms (%.1f GBps)\n    %u strong pixels\n    %u filtered reflections (%u pixels)\n",
-                                thread_id, image_num, tm[0] / nres, tm[1] / nres, tm[3] / nres, tm[2] / nres, tm[4] / nres,
-                                (double)frame_bytes * nres / (tm[4] * 1e-3) / 1e9, r.num_strong_pixels, r.n_boxes,
-                                r.num_strong_pixels_filtered);
-                } else {  // :1078-1085
-                    std::printf("Thread %2d finished image %4u with %5u strong pixels, %4u filtered reflections (%u pixels)\n",
-                                thread_id, image_num, r.num_strong_pixels, r.n_boxes, r.num_strong_pixels_filtered);
-                }
-                completed += 1;
-            }
-            return true;
+    // ---- a reader: chunks from the frame source into the slots of its GPU's assemblies ----------------------------------------
+    auto reader_thread = [&](int thread_id) {
+        const uint32_t di = (uint32_t)thread_id % n_dev;
+        Gpu& G = *gpus[di];
+        ffs_ctx* ctx = G.ctx;
+        if (node_known[di]) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &node_cpus[di]);
+        // scratch: a chunk whose size nobody knows yet; chunks the CPU decodes.  NOT value-initialised: a vector of this size
+        // zero-fills 72 MB (10 ms of page faults on the clock, for a chunk of 7 MB)
+        const size_t raw_bytes = frame_bytes * (bytes_per_pixel == 2 ? 2 : 1) + 4096;
+        std::unique_ptr<uint8_t[]> raw;
+        auto scratch = [&]() -> std::span<uint8_t> {
+            if (!raw) raw.reset(new uint8_t[raw_bytes]);
+            return {raw.get(), raw_bytes};
         };
-
-        auto last_received = std::chrono::steady_clock::now();
-        uint32_t run_first = 0, run_n = 0, run_done = 0;   // the run of frame numbers this worker took, and how far it is through it
-        int cur = 0;
-        double t_read = 0, t_submit = 0, t_chunk = 0;   // (-v: where this worker's time went; t_chunk = inside get_raw_chunk)
-        uint32_t n_batches = 0;
-        auto now = [] { return std::chrono::steady_clock::now(); };
-        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        double t_read = 0, t_chunk = 0, t_submit = 0, t_blocked = 0;
+        uint32_t n_read = 0, n_submitted = 0;
+        auto last_received = now();
         while (!g_stop.load() && !failed.load()) {
-            if (run_done >= run_n) {
-                run_first = next_image.fetch_add(batch);  // a run of frames instead of one (:752)
-                if (run_first >= num_images) break;
-                run_n = std::min(batch, num_images - run_first);
-                run_done = 0;
-            }
-            Slot& S = slots[cur];
-            if (!collect(S)) break;   // (only with --single-buffer: otherwise the slot was collected after the other's submit)
-            if (!gpu_decode && !S.host && !take_host(S, (size_t)batch * frame_bytes)) break;
-            const uint32_t first = run_first + run_done;
-            const uint32_t n = run_n - run_done;
-            uint32_t got = 0;
-            size_t cursor = 0;  // gpu_decode: fill position in the pinned buffer
-            bool cut_short = false;
+            const uint64_t j = G.next_slot.fetch_add(1);
+            const uint64_t q = j / batch, b = q * n_dev + di;
+            const uint32_t k = (uint32_t)(j % batch);
+            if (b >= total_batches) break;
+            const uint32_t first = (uint32_t)(b * batch);
+            const uint32_t n_in_batch = std::min<uint32_t>(batch, num_images - first);
+            if (k >= n_in_batch) continue;   // (the last batch is short)
+            const uint32_t image_num = first + k;
+            const uint32_t offset_image_num = image_num + args.start_index;  // :756
+            Assembly& A = G.as[q % K];
+
+            // the first chunk anybody reads sizes the staging areas (chunks that the GPU decodes: B slots of that size + 25 %)
+            std::span<uint8_t> chunk;
+            bool have_chunk = false;
+            auto read_into = [&](std::span<uint8_t> dst) -> bool {   // false: stopped
+                // readers are not thread-safe in general (:763-765); those that say they are skip the lock
+                std::unique_lock<std::mutex> lock(reader_mutex, std::defer_lock);
+                if (!reader.reentrant()) lock.lock();
+                const auto w0 = now();
+                while (!reader.is_image_available(offset_image_num) && !g_stop.load()) {
+                    if (secs(last_received, now()) > args.timeout) {  // :776-787
+                        std::printf("Timeout waiting for image %u\n", offset_image_num);
+                        g_stop.store(true);
+                        wake_all();
+                        break;
+                    }
+                    std::this_thread::sleep_for(100ms);
+                }
+                if (g_stop.load()) return false;
+                last_received = now();
+                time_waiting_acc.fetch_add(secs(w0, last_received));
+                for (;;) {  // zero-length reads on /dev/shm: retry (:805-821)
+                    const auto c0 = now();
+                    chunk = reader.get_raw_chunk(offset_image_num, dst);
+                    t_chunk += secs(c0, now());
+                    if (chunk.size() != 0) break;
+                    std::printf("\033[1mRace Condition?!?? Got buffer size 0 for image %u. Sleeping.\033[0m\n", image_num);
+                    std::this_thread::sleep_for(100ms);
+                    if (g_stop.load() || failed.load()) return false;
+                }
+                return true;
+            };
             const auto t_fill = now();
-            for (; got < n && !g_stop.load() && !cut_short; ++got) {
-                const uint32_t image_num = first + got;
-                const uint32_t offset_image_num = image_num + args.start_index;  // :756
-                std::span<uint8_t> chunk;
-                {
-                    // readers are not thread-safe in general (:763-765); those that say they are skip the lock
-                    std::unique_lock<std::mutex> lock(reader_mutex, std::defer_lock);
-                    if (!reader.reentrant()) lock.lock();
-                    const auto w0 = std::chrono::steady_clock::now();
-                    while (!reader.is_image_available(offset_image_num) && !g_stop.load()) {
-                        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - last_received).count();
-                        if (waited > args.timeout) {  // :776-787
-                            std::printf("Timeout waiting for image %u\n", offset_image_num);
-                            g_stop.store(true);
-                            break;
+            if (gpu_decode && chunk_estimate.load() == 0) {
+                if (!read_into(scratch())) break;
+                have_chunk = true;
+                size_t expect = 0;
+                chunk_estimate.compare_exchange_strong(expect, ((chunk.size() + (size_t)(chunk.size() * (double)args.slot_margin / 100.0) + 16384) + 63) & ~(size_t)63);
+            }
+
+            // this batch's assembly: claimed by the first of its readers to get here (in order: batch q - K must have been collected)
+            {
+                const auto t_b0 = now();
+                std::unique_lock<std::mutex> lock(G.mu);
+                G.cv.wait(lock, [&] { return A.batch == (int64_t)b || (A.batch == -1 && A.next_q == q) || g_stop.load() || failed.load(); });
+                if (g_stop.load() || failed.load()) break;
+                if (A.batch == -1) {
+                    A.batch = (int64_t)b;
+                    A.n = n_in_batch;
+                    A.filled = 0;
+                    A.submitted = false;
+                    A.skipped = false;
+                    if (!A.s) {   // first use: the stream(s) and the pinned staging area, outside the lock
+                        A.ready = false;
+                        lock.unlock();
+                        const auto t_c0 = now();
+                        bool ok = ffs_stream_create(ctx, &A.s) == FFS_OK && (!G.vctx || ffs_stream_create(G.vctx, &A.v) == FFS_OK);
+                        const auto t_c1 = now();
+                        // chunks: B tight slots (the first chunk's size + 2 %: what lies in consecutive slots crosses PCIe as ONE copy --
+                        // a copy per chunk cost 5 % of the frame rate) and behind them an overflow area for the chunks that do not fit theirs
+                        A.slot_bytes = gpu_decode ? chunk_estimate.load() : frame_bytes;
+                        A.over_at = (size_t)batch * A.slot_bytes;
+                        const size_t over = gpu_decode ? std::max((size_t)batch * A.slot_bytes / 4, std::min(3 * A.slot_bytes, frame_bytes + 4096)) : 0;
+                        void* v = nullptr;
+                        ok = ok && ffs_stream_reserve_host(A.s, A.over_at + over) == FFS_OK
+                             && ffs_stream_host_buffer(A.s, &v, &A.host_bytes) == FFS_OK;
+                        A.host = static_cast<uint8_t*>(v);
+                        lock.lock();
+                        if (!ok) { lock.unlock(); fail("", ctx); break; }
+                        A.ready = true;
+                        G.cv.notify_all();
+                        if (args.verbose) {
+                            std::lock_guard<std::mutex> pl(print_mutex);
+                            std::printf("Thread %2d: assembly %llu of GPU %d ready (stream %.1f ms, %.0f MB of staging %.1f ms) %.0f ms after the start\n", thread_id,
+                                        (unsigned long long)(q % K), devices[di], secs(t_c0, t_c1) * 1e3, A.host_bytes / 1e6, secs(t_c1, now()) * 1e3,
+                                        secs(all_start, now()) * 1e3);
                         }
-                        std::this_thread::sleep_for(100ms);
                     }
-                    if (g_stop.load()) break;
-                    last_received = std::chrono::steady_clock::now();
-                    time_waiting_acc.fetch_add(std::chrono::duration<double>(last_received - w0).count());
-                    for (;;) {  // zero-length reads on /dev/shm: retry (:805-821)
-                        if (gpu_decode && S.host) {
-                            const auto c0 = now();
-                            chunk = reader.get_raw_chunk(offset_image_num, {S.host + cursor, S.host_bytes - cursor});
-                            t_chunk += secs(c0, now());
-                            if (chunk.size() != 0 && chunk.size() >= S.host_bytes - cursor && S.host_bytes - cursor < raw.size()) {
-                                // the read filled what was left of the staging area: the chunk may be cut.  With frames already
-                                // in this batch, send those and start the next batch with this one; else the area is too small
-                                if (got > 0) { cut_short = true; break; }
-                                if (!take_host(S, std::min(S.host_bytes * 2 + (size_t)batch * 4096, (size_t)batch * raw.size()))) break;
-                                continue;
+                    else {   // (a batch that went up through the heap may have made the library grow -- and move -- the staging area)
+                        void* v = nullptr;
+                        (void)ffs_stream_host_buffer(A.s, &v, &A.host_bytes);
+                        A.host = static_cast<uint8_t*>(v);
+                    }
+                    A.over_used = 0;
+                } else if (!A.ready) {
+                    G.cv.wait(lock, [&] { return A.ready || g_stop.load() || failed.load(); });
+                    if (!A.ready) break;
+                }
+                t_blocked += secs(t_b0, now());
+            }
+
+            uint8_t* slot = A.host + (size_t)k * A.slot_bytes;
+            A.spill[k].clear();
+            if (gpu_decode) {
+                if (have_chunk && chunk.size() <= A.slot_bytes) {
+                    std::memcpy(slot, chunk.data(), chunk.size());
+                    chunk = {slot, chunk.size()};
+                } else if (!have_chunk) {
+                    if (!read_into({slot, A.slot_bytes})) break;
+                    have_chunk = true;
+                }
+                if (chunk.data() != slot || chunk.size() >= A.slot_bytes) {
+                    // larger than its slot (the read may have been cut): into the overflow area of the same staging buffer, one such
+                    // chunk at a time (its size is only known once it has been read: the area's free end is its buffer) ...
+                    bool placed = false;
+                    {
+                        std::lock_guard<std::mutex> over_lock(*A.over_mu);
+                        const size_t at = A.over_at + A.over_used;
+                        const size_t room = at < A.host_bytes ? A.host_bytes - at : 0;
+                        if (room >= 2 * A.slot_bytes) {
+                            if (!read_into({A.host + at, room})) break;
+                            if (chunk.size() < room) {
+                                placed = true;
+                                A.over_used += (chunk.size() + 63) & ~(size_t)63;
                             }
-                        } else {
-                            chunk = reader.get_raw_chunk(offset_image_num, raw);
                         }
-                        if (chunk.size() != 0) break;
-                        std::printf("\033[1mRace Condition?!?? Got buffer size 0 for image %u. Sleeping.\033[0m\n", image_num);
-                        std::this_thread::sleep_for(100ms);
+                    }
+                    if (!placed) {   // ... or, when that is full too, through the heap -- and so will its batch
+                        A.spill[k].resize(raw_bytes);
+                        if (!read_into(A.spill[k])) break;
+                        A.spill[k].resize(chunk.size());
+                        chunk = {A.spill[k].data(), chunk.size()};
                     }
                 }
-                if (failed.load()) break;
-                if (cut_short) break;   // (this frame starts the next batch)
-                if (gpu_decode && !S.host) {   // this slot's first chunk: now the staging area can be sized
-                    if (!chunk_estimate) chunk_estimate = ((chunk.size() + chunk.size() / 4 + 4096) + 63) & ~(size_t)63;
-                    if (!take_host(S, std::min((size_t)batch * std::max(chunk_estimate, chunk.size() + 64), (size_t)batch * raw.size()))) break;
-                    std::memcpy(S.host, chunk.data(), chunk.size());
-                    chunk = {S.host, chunk.size()};
-                }
-                if (gpu_decode) {
-                    S.chunk_ptr[got] = chunk.data();
-                    S.chunk_len[got] = chunk.size();
-                    cursor = (size_t)(chunk.data() - S.host) + ((chunk.size() + 63) & ~(size_t)63);
-                    continue;
-                }
-                uint8_t* dst = S.host + (size_t)got * frame_bytes;  // decode outside the lock (:823-842)
-                switch (reader.get_raw_chunk_compression()) {
+                A.chunk_ptr[k] = chunk.data();
+                A.chunk_len[k] = chunk.size();
+            } else {
+                if (!read_into(scratch())) break;
+                switch (reader.get_raw_chunk_compression()) {  // decode outside the lock (:823-842)
                 case Reader::BITSHUFFLE_LZ4:
-                    if (chunk.size() < 12 || bshuf_decompress_lz4(chunk.data() + 12, chunk.size() - 12, dst, (size_t)width * height, bytes_per_pixel) < 0) {
+                    if (chunk.size() < 12 || bshuf_decompress_lz4(chunk.data() + 12, chunk.size() - 12, slot, (size_t)width * height, bytes_per_pixel) < 0) {
                         std::printf("Error: corrupt bitshuffle-LZ4 chunk for image %u\n", image_num);
                         failed = 1;
+                        wake_all();
                     }
                     break;
                 case Reader::BYTE_OFFSET_32:
-                    if (bytes_per_pixel == 2) byte_offset_decompress(chunk.data(), chunk.size(), reinterpret_cast<uint16_t*>(dst), (size_t)width * height);
-                    else byte_offset_decompress(chunk.data(), chunk.size(), reinterpret_cast<uint32_t*>(dst), (size_t)width * height);
+                    if (bytes_per_pixel == 2) byte_offset_decompress(chunk.data(), chunk.size(), reinterpret_cast<uint16_t*>(slot), (size_t)width * height);
+                    else byte_offset_decompress(chunk.data(), chunk.size(), reinterpret_cast<uint32_t*>(slot), (size_t)width * height);
                     break;
                 case Reader::NONE:
-                    std::memcpy(dst, chunk.data(), std::min(chunk.size(), frame_bytes));
+                    std::memcpy(slot, chunk.data(), std::min(chunk.size(), frame_bytes));
                     break;
                 }
             }
-            if (got == 0 || failed.load()) break;
-            run_done += got;
-            const auto t_sub = now();
-            t_read += secs(t_fill, t_sub);
-            if (args.read_only) { ++n_batches; completed += got; cur = (cur + 1) % n_slots; continue; }
-            const int sub = gpu_decode ? ffs_submit_compressed(S.s, S.chunk_ptr.data(), S.chunk_len.data(), got, first)
-                                       : ffs_submit(S.s, S.host, got, first);
-            if (sub != FFS_OK) {
-                std::printf("Error: %s\n", ffs_last_error(ctx));
-                failed = 1;
-                break;
+            if (failed.load()) break;
+            ++n_read;
+            t_read += secs(t_fill, now());
+
+            bool last = false;
+            {
+                std::lock_guard<std::mutex> lock(G.mu);
+                last = ++A.filled == A.n;
             }
-            if (S.v) {   // the same input through the validation context
-                const int vsub = gpu_decode ? ffs_submit_compressed(S.v, S.chunk_ptr.data(), S.chunk_len.data(), got, first)
-                                            : ffs_submit(S.v, S.host, got, first);
-                if (vsub != FFS_OK) {
-                    std::printf("Error: validation pass: %s\n", ffs_last_error(vctxs[di]));
-                    failed = 1;
-                    break;
+            if (!last) continue;
+            // the batch is complete: whoever filled its last slot sends it off
+            const auto t_s0 = now();
+            if (args.read_only) {
+                A.skipped = true;
+            } else {
+                bool spilled = false;
+                for (uint32_t i = 0; i < A.n; ++i) spilled = spilled || !A.spill[i].empty();
+                if (gpu_decode && spilled)   // (all chunks of a batch lie in the staging area or none: the others go through the heap too)
+                    for (uint32_t i = 0; i < A.n; ++i)
+                        if (A.spill[i].empty()) {
+                            const uint8_t* p = static_cast<const uint8_t*>(A.chunk_ptr[i]);
+                            A.spill[i].assign(p, p + A.chunk_len[i]);
+                            A.chunk_ptr[i] = A.spill[i].data();
+                        }
+                const int sub = gpu_decode ? ffs_submit_compressed(A.s, A.chunk_ptr.data(), A.chunk_len.data(), A.n, first)
+                                           : ffs_submit(A.s, A.host, A.n, first);
+                if (sub != FFS_OK) { fail("", ctx); break; }
+                if (A.v) {   // the same input through the validation context
+                    const int vsub = gpu_decode ? ffs_submit_compressed(A.v, A.chunk_ptr.data(), A.chunk_len.data(), A.n, first)
+                                                : ffs_submit(A.v, A.host, A.n, first);
+                    if (vsub != FFS_OK) { fail("validation pass: ", G.vctx); break; }
                 }
             }
-            S.in_flight = true;
-            t_submit += secs(t_sub, now());
-            ++n_batches;
-            // the batch before this one has had a whole read's time on the GPU: hand out its results now
-            if (n_slots == 2 && !collect(slots[cur ^ 1])) break;
-            cur = (cur + 1) % n_slots;
-        }
-        for (int k = 0; k < n_slots; ++k)   // the older batch first
-            if (!failed.load()) collect(slots[(cur + k) % n_slots]);
-        const auto t_c0 = now();
-        {   // every result is out: the streams' buffers are released after the totals are printed, not on the clock
-            // (eight workers' hipFree / hipHostUnregister calls take turns in the runtime: 35-45 ms for 16 streams)
-            std::lock_guard<std::mutex> lock(retired_mutex);
-            for (Slot& q : slots) {
-                if (q.s) { retired_streams.push_back(q.s); q.s = nullptr; }
-                if (q.v) { retired_streams.push_back(q.v); q.v = nullptr; }
+            ++n_submitted;
+            t_submit += secs(t_s0, now());
+            {
+                std::lock_guard<std::mutex> lock(G.mu);
+                A.submitted_by = thread_id;
+                A.submitted = true;
+                G.cv.notify_all();
             }
         }
         if (args.verbose) {
             std::lock_guard<std::mutex> lock(print_mutex);
-            std::printf("Thread %2d: %u batches; reading %.0f ms (%.0f ms of it in get_raw_chunk), submit calls %.0f ms, waiting for the GPU %.0f ms, results out %.0f ms, "
-                        "done %.0f ms after the start\n", thread_id, n_batches, t_read * 1e3, t_chunk * 1e3, t_submit * 1e3, t_wait * 1e3,
-                        t_emit * 1e3, secs(all_start, now()) * 1e3);
-            (void)t_c0;
+            std::printf("Thread %2d: %u chunks read in %.0f ms (%.0f ms of it in get_raw_chunk), waiting for a free assembly %.0f ms, %u batches submitted (%.0f ms), "
+                        "done %.0f ms after the start\n", thread_id, n_read, t_read * 1e3, t_chunk * 1e3, t_blocked * 1e3, n_submitted, t_submit * 1e3,
+                        secs(all_start, now()) * 1e3);
         }
     };
     {
-        // How many of the -n threads feed the GPUs.  The reference needs one thread per frame in flight because its threads
-        // decompress (service.py passes --threads 40); here a worker only moves chunks from the frame source into pinned
-        // memory and two batches per worker are in flight, so eight per GPU saturate PCIe (tools/cli_profile.sh: 8 workers
-        // 3.6-4.0 k frames/s, 12: 3.1 k, 40: 1.6 k -- beyond eight they only contend for the runtime's locks).  Threads that
+        // How many of the -n threads read.  The reference needs one thread per frame in flight because its threads decompress
+        // (service.py passes --threads 40); here a reader only moves chunks from the frame source into pinned memory, and eight
+        // per GPU saturate PCIe (tools/cli_profile.sh) -- beyond that they contend for the page cache's locks.  Threads that
         // decompress on the host (--cpu-decode, CBF, --writeout) are all used.
         uint32_t n_workers = args.threads;
-        const bool chunks_to_gpu = reader.get_raw_chunk_compression() == Reader::BITSHUFFLE_LZ4 && !args.cpu_decode && !args.writeout;
-        if (chunks_to_gpu && !args.all_threads) n_workers = std::min<uint32_t>(n_workers, 8 * n_dev);
-        if (args.verbose && n_workers != args.threads) std::printf("Workers: %u of the %u threads feed the GPU(s)\n", n_workers, args.threads);
+        if (gpu_decode && !args.all_threads) n_workers = std::min<uint32_t>(n_workers, 8 * n_dev);
+        n_workers = std::max(n_workers, n_dev);
+        if (args.verbose && n_workers != args.threads) std::printf("Workers: %u of the %u threads read for the GPU(s)\n", n_workers, args.threads);
         std::vector<std::thread> threads;
-        for (uint32_t t = 0; t < n_workers; ++t) threads.emplace_back(worker, (int)t);
-        for (auto& t : threads) t.join();
+        for (uint32_t di = 0; di < n_dev; ++di) threads.emplace_back(collector, di);
+        for (uint32_t t = 0; t < n_workers; ++t) threads.emplace_back(reader_thread, (int)t);
+        for (size_t t = n_dev; t < threads.size(); ++t) threads[t].join();   // the readers
+        wake_all();                                                          // (collectors waiting for a batch nobody will submit)
+        {   // a reader that stopped early (timeout, interrupt) leaves batches unsubmitted: the collectors give up on those
+            for (uint32_t di = 0; di < n_dev; ++di) {
+                Gpu& G = *gpus[di];
+                std::unique_lock<std::mutex> lock(G.mu);
+                bool pending = false;
+                for (Assembly& A : G.as) pending = pending || (A.batch >= 0 && !A.submitted);
+                if (pending) { g_stop.store(true); G.cv.notify_all(); }
+            }
+        }
+        for (uint32_t di = 0; di < n_dev; ++di) threads[di].join();
+        // every result is out: the streams' buffers are released after the totals are printed, not on the clock
+        for (auto& g : gpus)
+            for (Assembly& A : g->as) {
+                if (A.s) retired_streams.push_back(A.s);
+                if (A.v) retired_streams.push_back(A.v);
+            }
     }
     if (failed.load()) return 1;
 

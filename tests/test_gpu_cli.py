@@ -437,3 +437,50 @@ def test_validate_flag_cross_checks_every_image(tmp_path, algo):
         assert m[i] == int(strong.sum())
     got = {json.loads(l)["file-number"]: json.loads(l) for l in lines}
     assert sorted(got) == list(range(N))
+
+
+def _write_stream_dir(path, frames, mask=None):
+    """An Eiger-stream directory (what `ffs_hosttool mkshm` writes) from arbitrary frames: start_1 header, start_5 pixel
+    mask (int32, 0 = good) and one bitshuffle-LZ4 chunk per image."""
+    from ffs_amd import bslz4
+    os.makedirs(path)
+    N, H, W = frames.shape
+    hdr = {"nimages": N, "ntrigger": 1, "y_pixels_in_detector": H, "x_pixels_in_detector": W,
+           "bit_depth_image": frames.dtype.itemsize * 8, "countrate_correction_count_cutoff": 65535 if frames.dtype == np.uint16 else 4294967295,
+           "wavelength": 0.976, "detector_distance": 300.0, "y_pixel_size": 7.5e-05, "x_pixel_size": 7.5e-05,
+           "beam_center_y": H / 2.0, "beam_center_x": W / 2.0}
+    open(os.path.join(path, "start_1"), "w").write(json.dumps(hdr) + "\n")
+    open(os.path.join(path, "start_4"), "w").write("\n")
+    m = np.zeros((H, W), np.int32) if mask is None else (mask == 0).astype(np.int32)
+    m.tofile(os.path.join(path, "start_5"))
+    for i, f in enumerate(frames):
+        open(os.path.join(path, "image_%06d_2" % i), "wb").write(bytes(bslz4.compress(f)))
+
+
+@pytest.mark.parametrize("argv", [["--threads", "4", "--batch", "6"], ["--threads", "3", "--batch", "4", "--assemblies", "2"],
+                                  ["--threads", "1", "--batch", "16"], ["--threads", "5", "--batch", "3", "--devices", "0,0"]])
+def test_batches_assembled_by_several_readers_chunks_of_any_size(tmp_path, argv):
+    """A GPU batch is filled by all reader threads of its GPU: image i goes to slot i mod B of batch i div B, slots are sized by
+    the first chunk anybody reads (+ 2 %).  Here the first frames are empty (chunks of a few hundred bytes) and the later ones
+    are noise and spots (chunks thousands of times larger): they take the overflow area behind the slots and, when that is
+    full, the heap (their whole batch then goes up from there).  Every image must come out, in order, with the oracle's counts."""
+    rng = np.random.default_rng(5)
+    W, H, N = 300, 200, 23
+    frames = np.zeros((N, H, W), np.uint16)
+    for i in range(3, N):
+        frames[i] = rng.poisson(2.0 if i % 3 else 40.0, (H, W))
+        if i % 4 == 0:
+            frames[i] = rng.integers(0, 4000, (H, W))                       # incompressible
+        frames[i, 20 + i:23 + i, 50:53] += 500
+    shm = tmp_path / "shm"
+    _write_stream_dir(str(shm), frames)
+    rc, out, err, lines = run_with_pipe([str(shm), *argv], tmp_path)
+    assert rc == 0 and not err, (out, err)
+    got = [json.loads(l) for l in lines]
+    assert sorted(j["file-number"] for j in got) == list(range(N))
+    exp = _oracle_counts(frames, np.ones((H, W), np.uint8))
+    for j in got:
+        assert (j["num_strong_pixels"], j["n_spots_total"]) == exp[j["file-number"]], j
+    if "--devices" not in argv:
+        assert [j["file-number"] for j in got] == list(range(N))              # one collector: results leave in frame order
+    assert f"{N} images in" in out
