@@ -278,6 +278,7 @@ extern "C" int ffs_ctx_set_tuning(ffs_ctx* c, const char* key, long long value) 
     else if (k == "occupancy_bitmap") { if ((ok = in(0, 1))) t.occupancy_bitmap = (int)value; }
     else if (k == "direct_records") { if ((ok = in(0, 1) && c->n_streams_made == 0)) t.direct_records = (int)value; }
     else if (k == "decode_in_dense_stream") { if ((ok = in(0, 1))) t.decode_in_dense_stream = (int)value; }
+    else if (k == "ext_fused") { if ((ok = in(0, 1))) t.ext_fused = (int)value; }
     else if (k == "ext_rest_aside") { if ((ok = in(0, 1))) t.ext_rest_aside = (int)value; }
     else if (k == "band_taper") { if ((ok = in(0, 99))) t.band_taper = (int)value; }
     else if (k == "rows_ahead") { if ((ok = in(2, 4))) t.rows_ahead = (int)value; }

@@ -70,6 +70,10 @@ struct Tuning {
     int direct_records = 1;     // records and counters are written straight into pinned host memory
     int decode_in_dense_stream = 1;   // the decode kernel runs in the dense kernels' stream (0: in the upload stream)
     int ccl_grid = 32;          // workgroups per frame of the grid-wide sparse kernels
+    int ext_fused = 0;          // extended algorithm, 16-bit pixels: 1 = erosion fused into the final pass's tiles (k_ext_erode_final: one launch, the plane
+                                //    crosses memory once); 0 = k_ext_erode + k_ext_final.  Measured round 4: the fused kernel is SLOWER (threshold stage 0.65
+                                //    against 0.55 ms per 32 frames, profiles/r04d_ext_fused_ab.txt): every tile starts with a chain of dependent plane loads
+                                //    that its gathers then wait behind, 17 000 times per batch -- kept as an A/B partner, parity-tested
     int ext_rest_aside = 0;     // extended algorithm: 1 = erosion + final pass in the batch's sparse stream, beside the next batch's first pass; 0 = in the
                                 //    dense stream (measured round 4: no gain -- a CU full of first-pass waves has neither LDS nor registers left for the
                                 //    final pass's workgroups, so the kernels take turns either way: profiles/r04b_ext_streams_ab.txt)

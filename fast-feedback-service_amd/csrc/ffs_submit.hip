@@ -196,9 +196,13 @@ static void launch_ext_rest(ffs_stream* s, const ThresholdArgs& a, uint32_t n_fr
     // The byte mask: the streaming kernel zero-filled it if somebody wants it (k_ext_final sets 1s in it either way; without a
     // taker they land in a buffer nobody reads); after k_ext_first it is always produced, so zero it here.
     if (!ext_stream_first(a)) (void)hipMemsetAsync(a.strong_bytes, 0, (size_t)n_frames * a.bytes_frame_stride, st);
+    dim3 g3((unsigned)a.n_tiles, n_frames);
+    if (u16 && s->ctx->tune.ext_fused) {   // erosion inside the final pass's tiles: one launch, the plane crosses memory once
+        hipLaunchKernelGGL(k_ext_erode_final, g3, dim3(256), (size_t)(kTileRows + 10) * a.mpitch, st, a);
+        return;
+    }
     const unsigned erode_lanes = (a.mpitch / 4) * (unsigned)((a.H + kErodeRows - 1) / kErodeRows);
     hipLaunchKernelGGL(k_ext_erode, dim3((erode_lanes + 255) / 256, n_frames), dim3(256), 0, st, a);
-    dim3 g3((unsigned)a.n_tiles, n_frames);
     if (u16) hipLaunchKernelGGL(k_ext_final<uint16_t>, g3, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_ext_final<uint32_t>, g3, dim3(256), 0, st, a);
 }

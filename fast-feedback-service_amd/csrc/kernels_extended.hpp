@@ -127,6 +127,25 @@ __global__ __launch_bounds__(64) void k_ext_first(const ThresholdArgs a) {
 template __global__ void k_ext_first<uint16_t>(const ThresholdArgs);
 template __global__ void k_ext_first<uint32_t>(const ThresholdArgs);
 
+// One row of the horizontally eroded plane for word column w: row yy of D with "does not erode its neighbours" pixels set (beyond
+// the image width; with the device kernels' rule also masked pixels), eroded horizontally by 2.  `centre` = D's own word.
+__device__ __forceinline__ uint32_t ext_erode_hrow(const ThresholdArgs& a, const uint32_t* dp, const uint32_t* mp, int dpr, int w, int yy,
+                                                   uint32_t beyond_c, uint32_t beyond_r, bool dev_rules, uint32_t& centre) {
+    if (yy < 0 || yy >= a.H) { centre = 0; return ~0u; }
+    const uint32_t* row = dp + (uint64_t)yy * dpr;
+    const uint32_t* mrow = mp + (uint64_t)yy * dpr;
+    centre = row[w];
+    uint32_t c = centre | beyond_c, l = ~0u, r = ~0u;
+    if (w > 0) l = row[w - 1];
+    if (w + 1 < dpr) r = row[w + 1] | beyond_r;
+    if (dev_rules) {
+        c |= ~mrow[w];
+        if (w > 0) l |= ~mrow[w - 1];
+        if (w + 1 < dpr) r |= ~mrow[w + 1];
+    }
+    return c & ((c << 1) | (l >> 31)) & ((c << 2) | (l >> 30)) & ((c >> 1) | (r << 31)) & ((c >> 2) | (r << 30));
+}
+
 // X2: 5x5 erosion on bit planes.  One lane per 32-pixel word column and band of kErodeRows rows:
 // the lane walks down its column with the horizontally eroded words of the last five rows in
 // registers, so every plane word is fetched once (plus its two neighbours, which the adjacent
@@ -150,22 +169,7 @@ __global__ __launch_bounds__(256) void k_ext_erode(const ThresholdArgs a) {
     const uint32_t beyond_c = x0 + 32 > a.W ? (x0 >= a.W ? ~0u : ~((1u << (a.W - x0)) - 1u)) : 0u;
     const uint32_t beyond_r = x0 + 64 > a.W ? (x0 + 32 >= a.W ? ~0u : ~((1u << (a.W - x0 - 32)) - 1u)) : 0u;
     const bool dev_rules = a.ext_flavour == 1;  // masked pixels do not erode either (erosion.cu:101-105)
-    // row yy of the plane with "does not erode its neighbours" pixels set, eroded horizontally by 2
-    auto hrow = [&](int yy, uint32_t& centre) -> uint32_t {
-        if (yy < 0 || yy >= a.H) { centre = 0; return ~0u; }
-        const uint32_t* row = dp + (uint64_t)yy * dpr;
-        const uint32_t* mrow = mp + (uint64_t)yy * dpr;
-        centre = row[w];
-        uint32_t c = centre | beyond_c, l = ~0u, r = ~0u;
-        if (w > 0) l = row[w - 1];
-        if (w + 1 < dpr) r = row[w + 1] | beyond_r;
-        if (dev_rules) {
-            c |= ~mrow[w];
-            if (w > 0) l |= ~mrow[w - 1];
-            if (w + 1 < dpr) r |= ~mrow[w + 1];
-        }
-        return c & ((c << 1) | (l >> 31)) & ((c << 2) | (l >> 30)) & ((c >> 1) | (r << 31)) & ((c >> 2) | (r << 30));
-    };
+    auto hrow = [&](int yy, uint32_t& centre) -> uint32_t { return ext_erode_hrow(a, dp, mp, dpr, w, yy, beyond_c, beyond_r, dev_rules, centre); };
     uint32_t h0, h1, h2, h3, h4, c2, c3, c4, dummy;
     h0 = hrow(y0 - 2, dummy);
     h1 = hrow(y0 - 1, dummy);
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256) void k_ext_erode(const ThresholdArgs a) {
 
 // X3 predicate: baseline.cpp:580-645 for one pixel of the signal region E.
 template <typename PixelT>
-__device__ bool ext_final_strong(const ThresholdArgs& a, const uint8_t* img, const uint8_t* eplane, int x, int y) {
+__device__ __forceinline__ bool ext_final_strong(const ThresholdArgs& a, const uint8_t* img, const uint32_t* eplane, int e_y0, int x, int y) {
     const int W = a.W, H = a.H;
     const int xs = max(x - 5, 0), xe = min(x + 5, W - 1);  // kernel + 2, clipped (:591-598)
     const int ncol = xe - xs + 1;
@@ -204,7 +208,7 @@ __device__ bool ext_final_strong(const ThresholdArgs& a, const uint8_t* img, con
             const bool ok = yy >= 0 && yy < H;
             const int yc = ok ? yy : y;
             const uint32_t* mrow = reinterpret_cast<const uint32_t*>(a.maskbits) + (uint64_t)yc * dpr;
-            const uint32_t* erow = reinterpret_cast<const uint32_t*>(eplane) + (uint64_t)yc * dpr;
+            const uint32_t* erow = eplane + (int64_t)(yc - e_y0) * dpr;
             const unsigned long long mw = (unsigned long long)mrow[wb] | (two ? (unsigned long long)mrow[wb + 1] << 32 : 0ull);
             const unsigned long long ew = (unsigned long long)erow[wb] | (two ? (unsigned long long)erow[wb + 1] << 32 : 0ull);
             const uint32_t* prow = reinterpret_cast<const uint32_t*>(img + (uint64_t)yc * a.pitch + (uint64_t)bx * 2u);
@@ -223,7 +227,7 @@ __device__ bool ext_final_strong(const ThresholdArgs& a, const uint8_t* img, con
     } else {
         for (int yy = max(y - 5, 0); yy <= min(y + 5, H - 1); ++yy) {
             const uint32_t* mrow = reinterpret_cast<const uint32_t*>(a.maskbits) + (uint64_t)yy * dpr;
-            const uint32_t* erow = reinterpret_cast<const uint32_t*>(eplane) + (uint64_t)yy * dpr;
+            const uint32_t* erow = eplane + (int64_t)(yy - e_y0) * dpr;
             const bool two = w0 + 1 < dpr;
             const unsigned long long mw = (unsigned long long)mrow[w0] | (two ? (unsigned long long)mrow[w0 + 1] << 32 : 0ull);
             const unsigned long long ew = (unsigned long long)erow[w0] | (two ? (unsigned long long)erow[w0 + 1] << 32 : 0ull);
@@ -264,7 +268,7 @@ __device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
     return v;
 }
-__device__ __forceinline__ bool ext_final_strong4(const ThresholdArgs& a, const uint8_t* img, const uint8_t* eplane, int x0, int y, int sub) {
+__device__ __forceinline__ bool ext_final_strong4(const ThresholdArgs& a, const uint8_t* img, const uint32_t* eplane, int e_y0, int x0, int y, int sub) {
     const int H = a.H;
     const int dpr = (int)(a.mpitch >> 2);
     const int bx = x0 - 8;                         // block column 0; a multiple of 4
@@ -282,7 +286,7 @@ __device__ __forceinline__ bool ext_final_strong4(const ThresholdArgs& a, const 
         const bool ok = r < 11 && yy >= 0 && yy < H;
         const int yc = ok ? yy : y;
         const uint32_t* mrow = reinterpret_cast<const uint32_t*>(a.maskbits) + (uint64_t)yc * dpr;
-        const uint32_t* erow = reinterpret_cast<const uint32_t*>(eplane) + (uint64_t)yc * dpr;
+        const uint32_t* erow = eplane + (int64_t)(yc - e_y0) * dpr;
         const unsigned long long mw = (unsigned long long)mrow[wb] | (two ? (unsigned long long)mrow[wb + 1] << 32 : 0ull);
         const unsigned long long ew = (unsigned long long)erow[wb] | (two ? (unsigned long long)erow[wb + 1] << 32 : 0ull);
         const uint8_t* prow = img + (uint64_t)yc * a.pitch + (uint64_t)bx * 2u;   // 8-byte aligned
@@ -334,5 +338,7 @@ template <typename PixelT>
 __global__ __launch_bounds__(256) void k_ext_final(const ThresholdArgs a) { exact_tile<PixelT, 256, kExactListCap, sizeof(PixelT) == 2 ? 2 : 1>(a); }
 template __global__ void k_ext_final<uint16_t>(const ThresholdArgs);
 template __global__ void k_ext_final<uint32_t>(const ThresholdArgs);
+// erosion + final pass in one launch (16-bit pixels; dynamic LDS: 18 rows of the plane = 18 * mpitch bytes)
+__global__ __launch_bounds__(256) void k_ext_erode_final(const ThresholdArgs a) { exact_tile<uint16_t, 256, kExactListCap, 3>(a); }
 
 }  // namespace ffsamd

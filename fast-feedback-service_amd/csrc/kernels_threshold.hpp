@@ -119,15 +119,24 @@ __device__ bool exact_strong(const ThresholdArgs& a, const uint8_t* img, int x, 
 }
 
 // extended algorithm's final test (kernels_extended.hpp)
+// (the signal-region plane E: `eplane` = the frame's plane in global memory, row 0 first, rows `edpr` dwords apart; MODE 3 passes
+// the tile's rows of it in LDS instead -- row `e_y0` first)
 template <typename PixelT>
-__device__ bool ext_final_strong(const ThresholdArgs& a, const uint8_t* img, const uint8_t* eplane, int x, int y);
-__device__ __forceinline__ bool ext_final_strong4(const ThresholdArgs& a, const uint8_t* img, const uint8_t* eplane, int x0, int y, int sub);
+__device__ __forceinline__ bool ext_final_strong(const ThresholdArgs& a, const uint8_t* img, const uint32_t* eplane, int e_y0, int x, int y);
+__device__ __forceinline__ bool ext_final_strong4(const ThresholdArgs& a, const uint8_t* img, const uint32_t* eplane, int e_y0, int x0, int y, int sub);
+// 5 x 5 erosion of the first-pass plane D, one row of one 32-pixel word column: see kernels_extended.hpp
+__device__ __forceinline__ uint32_t ext_erode_hrow(const ThresholdArgs& a, const uint32_t* dp, const uint32_t* mp, int dpr, int w, int yy,
+                                                   uint32_t beyond_c, uint32_t beyond_r, bool dev_rules, uint32_t& centre);
 
 // MODE 0: candidates come from (and strong pixels go back to) a.bits, predicate exact_strong.
 // MODE 1: extended algorithm -- candidates are the signal-region plane a.eplane (read-only: other
 //         tiles read it for their 11x11 windows), predicate ext_final_strong, result in a.bits.
 // MODE 2: the same with a list entry per aligned group of FOUR pixels that holds a candidate (16-bit pixels,
 //         ext_final_strong4: the four windows share their loads and column sums).
+// MODE 3: MODE 2 with the erosion fused in (round 4): the tile computes the rows y0 - 5 .. y0 + 12 of the signal region E from rows
+//         y0 - 7 .. y0 + 14 of the first-pass plane a.dplane into LDS (dynamic: 18 rows of the plane), writes its own eight rows
+//         of E to a.eplane (for --writeout / ffs_stream_debug_bitplane) and takes every window's E bits from LDS: one launch and a
+//         round trip of the plane less than k_ext_erode + MODE 2.
 template <typename PixelT, int NT, int LISTCAP, int MODE = 0>
 __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
     // The stage is latency-bound (sparse gathers).  Measured dead ends: a smaller LDS footprint
@@ -148,13 +157,53 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
     const uint8_t* eframe = MODE >= 1 ? a.eplane + (uint64_t)frame * a.plane_frame_stride : nullptr;
     const uint32_t* gin = MODE >= 1 ? reinterpret_cast<const uint32_t*>(eframe + (uint64_t)y0 * a.mpitch) : gwords;
     uint8_t* sbytes = a.strong_bytes + (uint64_t)frame * a.bytes_frame_stride;
+    // where the windows' E bits come from: the frame's plane in global memory (row 0 first), or the tile's 18 rows in LDS
+    [[maybe_unused]] const uint32_t* esrc = reinterpret_cast<const uint32_t*>(eframe);
+    [[maybe_unused]] int e_y0 = 0;
 
     if (tid == 0) { s_cnt = 0; s_total = 0; s_strong = 0; }
+    if constexpr (MODE == 3) {
+        extern __shared__ uint32_t s_E[];   // [18][dpr]: rows y0 - 5 .. y0 + 12 of the signal region
+        constexpr int kERows = kTileRows + 10;
+        const uint32_t* dp = reinterpret_cast<const uint32_t*>(a.dplane + (uint64_t)frame * a.plane_frame_stride);
+        const uint32_t* mp = reinterpret_cast<const uint32_t*>(a.maskbits);
+        const bool dev_rules = a.ext_flavour == 1;
+        // two halves of the rows per word column, each marching down with the horizontally eroded words of five rows in registers
+        for (int item = tid; item < 2 * dpr; item += NT) {
+            const int half = item >= dpr ? 1 : 0, w = item - half * dpr;
+            const int x0 = w * 32;
+            const uint32_t beyond_c = x0 + 32 > a.W ? (x0 >= a.W ? ~0u : ~((1u << (a.W - x0)) - 1u)) : 0u;
+            const uint32_t beyond_r = x0 + 64 > a.W ? (x0 + 32 >= a.W ? ~0u : ~((1u << (a.W - x0 - 32)) - 1u)) : 0u;
+            const int r0 = half * (kERows / 2), r1 = r0 + kERows / 2;          // E rows [r0, r1) of the 18
+            const int ya = y0 - 5 + r0;                                          // first image row of this half
+            uint32_t h0, h1, h2, h3, h4, c2, c3, c4, dummy;
+            h0 = ext_erode_hrow(a, dp, mp, dpr, w, ya - 2, beyond_c, beyond_r, dev_rules, dummy);
+            h1 = ext_erode_hrow(a, dp, mp, dpr, w, ya - 1, beyond_c, beyond_r, dev_rules, dummy);
+            h2 = ext_erode_hrow(a, dp, mp, dpr, w, ya, beyond_c, beyond_r, dev_rules, c2);
+            h3 = ext_erode_hrow(a, dp, mp, dpr, w, ya + 1, beyond_c, beyond_r, dev_rules, c3);
+#pragma unroll
+            for (int r = 0; r < kERows / 2; ++r) {
+                h4 = ext_erode_hrow(a, dp, mp, dpr, w, ya + r + 2, beyond_c, beyond_r, dev_rules, c4);
+                s_E[(r0 + r) * dpr + w] = c2 & h0 & h1 & h2 & h3 & h4;   // (rows outside the image: c2 = 0)
+                h0 = h1; h1 = h2; h2 = h3; h3 = h4;
+                c2 = c3; c3 = c4;
+            }
+            (void)r1;
+        }
+        __syncthreads();
+        // the tile's own rows of E leave for the global plane (what k_ext_erode wrote)
+        uint32_t* eout = reinterpret_cast<uint32_t*>(a.eplane + (uint64_t)frame * a.plane_frame_stride + (uint64_t)y0 * a.mpitch);
+        for (int g = tid; g < ndw; g += NT) eout[g] = s_E[5 * dpr + g];
+        esrc = s_E;
+        e_y0 = y0 - 5;
+    }
     // what a list entry stands for: a candidate pixel, or (MODE 2) the first bit of a group of four that holds one
-    auto entries = [](uint32_t w) -> uint32_t { return MODE == 2 ? (w | (w >> 1) | (w >> 2) | (w >> 3)) & 0x11111111u : w; };
+    auto entries = [](uint32_t w) -> uint32_t { return MODE >= 2 ? (w | (w >> 1) | (w >> 2) | (w >> 3)) & 0x11111111u : w; };
     uint32_t mine = 0;
     for (int g = tid; g < ndw; g += NT) {
-        const uint32_t w = gin[g];
+        uint32_t w;
+        if constexpr (MODE == 3) w = esrc[5 * dpr + g];
+        else w = gin[g];
         s_words[g] = w;
         mine += __popc(entries(w));
     }
@@ -178,7 +227,7 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
     };
     auto flush = [&]() {
         const uint32_t n = s_cnt;
-        if constexpr (MODE == 2) {
+        if constexpr (MODE >= 2) {
             // an entry = an aligned group of four pixels, taken by a quad of lanes (whole quads are in or out of the loop)
             const int sub = tid & 3;
             for (uint32_t e = (uint32_t)tid >> 2; e < n; e += NT / 4) {
@@ -189,8 +238,8 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
                 const int y = y0 + row;
                 const bool want = (s_words[g] >> (bit + (uint32_t)sub)) & 1u;   // (only this lane ever changes this bit)
                 bool strong;
-                if (x >= 8 && x + 12 <= a.pitch_px) strong = ext_final_strong4(a, img, eframe, x, y, sub);   // (quad-uniform branch)
-                else strong = want && ext_final_strong<PixelT>(a, img, eframe, x + sub, y);                   // next to the frame's left or right edge
+                if (x >= 8 && x + 12 <= a.pitch_px) strong = ext_final_strong4(a, img, esrc, e_y0, x, y, sub);   // (quad-uniform branch)
+                else strong = want && ext_final_strong<PixelT>(a, img, esrc, e_y0, x + sub, y);                   // next to the frame's left or right edge
                 if (want) {
                     if (strong) sbytes[(uint64_t)y * a.bpitch + x + sub] = 1;
                     else atomicAnd(&s_words[g], ~(1u << (bit + (uint32_t)sub)));
@@ -205,7 +254,7 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
             const int x = (int)((g - row * dpr) * 32u + bit);
             const int y = y0 + row;
             bool strong;
-            if constexpr (MODE == 1) strong = ext_final_strong<PixelT>(a, img, eframe, x, y);
+            if constexpr (MODE == 1) strong = ext_final_strong<PixelT>(a, img, esrc, e_y0, x, y);
             else strong = exact_strong<PixelT>(a, img, x, y);
             if (strong) {
                 sbytes[(uint64_t)y * a.bpitch + x] = 1;

@@ -27,16 +27,18 @@ CASES = [
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d-%s" % (c["W"], c["H"], np.dtype(c["dtype"]).name))
 @pytest.mark.parametrize("flavour", [0, 1])
-@pytest.mark.parametrize("variant", [2, 0])
+@pytest.mark.parametrize("variant", [2, 0, 3])
 def test_every_stage_matches_oracle(ffs, case, flavour, variant):
     # tuning "ext_first_pass": 2 = the streaming kernel decides the first pass exactly in its drain (16-bit default),
     # 0 = the one-pixel-per-lane first-pass kernel (what 32-bit pixels always use)
+    # variant 3: the streaming first pass with the erosion fused into the final pass's tiles (tuning "ext_fused" = 1: an A/B partner,
+    # slower than the two kernels it replaces -- DESIGN.md section 4 -- and held to the same planes)
     if variant != 2 and case["dtype"] == np.uint32:
         pytest.skip("32-bit pixels have one first-pass kernel")
     img, mask = make_frame(**case)
     H, W = img.shape
     ctx = ffs.Context(W, H, img.dtype, max_batch=2)
-    ctx.set_tuning(ext_first_pass=variant)
+    ctx.set_tuning(ext_first_pass=2 if variant == 3 else variant, ext_fused=1 if variant == 3 else 0)
     ctx.set_mask(mask)
     ctx.set_params(algorithm=ffs.ALGO_DISPERSION_EXTENDED, extended_flavour=flavour, want_strong_mask=1,
                    want_strong_list=1, want_reflections=1)
