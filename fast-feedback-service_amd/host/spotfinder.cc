@@ -216,10 +216,17 @@ class PipeHandler {
   public:
     explicit PipeHandler(int fd) : fd_(fd) { std::printf("PipeHandler initialized with pipe_fd: %d\n", fd); }
     ~PipeHandler() { close(fd_); }
-    void send(const std::string& line) {
+    void send(const std::string& line) { send_lines(line + "\n"); }
+    // whole lines, each ending in a newline: one write for a batch's worth (a write per line was 7 000 system calls a second on
+    // the one thread that also frees the GPU's staging areas)
+    void send_lines(const std::string& s) {
         std::lock_guard<std::mutex> lock(m_);
-        const std::string s = line + "\n";
-        if (write(fd_, s.c_str(), s.size()) == -1) std::cerr << "Error writing to pipe: " << std::strerror(errno) << std::endl;
+        size_t at = 0;
+        while (at < s.size()) {
+            const ssize_t w = write(fd_, s.c_str() + at, s.size() - at);
+            if (w == -1) { if (errno == EINTR) continue; std::cerr << "Error writing to pipe: " << std::strerror(errno) << std::endl; return; }
+            at += (size_t)w;
+        }
     }
 };
 
@@ -712,6 +719,10 @@ int main(int argc, char** argv) {
                     // reference's rotation_slices_mutex), held only while the transfer is enqueued
                     if (ffs_stack3d_add_batch(stack, A.s) != FFS_OK) { fail("", ctx); break; }
                 }
+                // what this batch prints and sends goes out in one piece each (the collector is the one thread between the GPU and a
+                // free staging area: a printf and a write per image, into pipes a Python caller drains, were on that path)
+                std::string text, json_lines;
+                char line_buf[512];
                 for (uint32_t i = 0; i < nres; ++i) {
                     const ffs_frame_result& r = res[i];
                     const uint32_t image_num = (uint32_t)r.frame_id;
@@ -774,36 +785,48 @@ int main(int argc, char** argv) {
                             }
                             j += "]";
                         }
-                        pipe->send(j + "}");
+                        json_lines += j;
+                        json_lines += "}\n";
                     }
-                    std::lock_guard<std::mutex> lock(print_mutex);
                     if (vres) {  // :1012-1053
                         const ffs_frame_result& v = vres[i];
                         const bool same = r.strong_mask && v.strong_mask && std::memcmp(r.strong_mask, v.strong_mask, (size_t)width * height) == 0
                                           && r.num_strong_pixels == v.num_strong_pixels && r.n_boxes == v.n_boxes;
-                        if (same) std::printf("Thread %2u, Image %4u: Compared: \033[32mMatch %u px\033[0m\n", thread_id, image_num, r.num_strong_pixels);
+                        if (same) std::snprintf(line_buf, sizeof line_buf, "Thread %2u, Image %4u: Compared: \033[32mMatch %u px\033[0m\n", thread_id, image_num, r.num_strong_pixels);
                         else {
-                            std::printf("Thread %2u, Image %4u: Compared: \033[1;31mMismatch (%u px from kernel)\033[0m\n", thread_id, image_num, r.num_strong_pixels);
+                            std::snprintf(line_buf, sizeof line_buf, "Thread %2u, Image %4u: Compared: \033[1;31mMismatch (%u px from kernel)\033[0m\n", thread_id, image_num, r.num_strong_pixels);
                             validate_mismatches += 1;
                         }
+                        text += line_buf;
                     }
-                    std::printf("Extracted %u spots\n", r.n_components);  // connected_components.cc:119
-                    if (prm.min_spot_size > 0)
-                        std::printf("Removed %u spots with size < %u pixels\n", r.n_components - r.n_boxes, prm.min_spot_size);
-                    if (prm.want_reflections && r.n_filtered_sep > 0)
-                        std::printf("Filtered %u spots with peak-centroid distance > %s\n", r.n_filtered_sep, fmt_num(prm.max_peak_centroid_separation).c_str());
+                    std::snprintf(line_buf, sizeof line_buf, "Extracted %u spots\n", r.n_components);  // connected_components.cc:119
+                    text += line_buf;
+                    if (prm.min_spot_size > 0) {
+                        std::snprintf(line_buf, sizeof line_buf, "Removed %u spots with size < %u pixels\n", r.n_components - r.n_boxes, prm.min_spot_size);
+                        text += line_buf;
+                    }
+                    if (prm.want_reflections && r.n_filtered_sep > 0) {
+                        std::snprintf(line_buf, sizeof line_buf, "Filtered %u spots with peak-centroid distance > %s\n", r.n_filtered_sep, fmt_num(prm.max_peak_centroid_separation).c_str());
+                        text += line_buf;
+                    }
                     if (args.threads == 1) {  // :1056-1076 (timings are per batch here)
-                        std::printf("Thread %2u finished image %4u\n       Copy: %5.1f ms\n     Kernel: %5.1f ms\n  Post Copy: %5.1f ms\n"
+                        std::snprintf(line_buf, sizeof line_buf, "Thread %2u finished image %4u\n       Copy: %5.1f ms\n     Kernel: %5.1f ms\n  Post Copy: %5.1f ms\n"
                                     "       Post: %5.1f ms\n             \xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\xe2\x95\x90\n"
                                     "     Total:  %5.1f ms (%.1f GBps)\n    %u strong pixels\n    %u filtered reflections (%u pixels)\n",
                                     thread_id, image_num, tm[0] / nres, tm[1] / nres, tm[3] / nres, tm[2] / nres, tm[4] / nres,
                                     (double)frame_bytes * nres / (tm[4] * 1e-3) / 1e9, r.num_strong_pixels, r.n_boxes,
                                     r.num_strong_pixels_filtered);
                     } else {  // :1078-1085
-                        std::printf("Thread %2u finished image %4u with %5u strong pixels, %4u filtered reflections (%u pixels)\n",
+                        std::snprintf(line_buf, sizeof line_buf, "Thread %2u finished image %4u with %5u strong pixels, %4u filtered reflections (%u pixels)\n",
                                     thread_id, image_num, r.num_strong_pixels, r.n_boxes, r.num_strong_pixels_filtered);
                     }
+                    text += line_buf;
                     completed += 1;
+                }
+                if (pipe && !json_lines.empty()) pipe->send_lines(json_lines);
+                {
+                    std::lock_guard<std::mutex> lock(print_mutex);
+                    std::fwrite(text.data(), 1, text.size(), stdout);
                 }
                 t_emit += secs(t_e0, now());
             } else {

@@ -14,7 +14,8 @@ for rep in 1 2 3; do
   for n in 1000 4096; do
     for exe in $P $B/spotfinder; do
       [ -x $exe ] || continue
-      echo "$(basename $(dirname $exe))/$(basename $exe) $n: $($exe $T/shm --threads 16 --images $n 2>&1 | grep -E 'images in' | sed -e 's/\x1b\[[0-9;]*m//g')"
+      # (as the service runs it: JSON lines into an inherited pipe, stdout into another)
+      echo "$(basename $(dirname $exe))/$(basename $exe) $n: $($exe $T/shm --threads 16 --images $n --pipe_fd 3 3> >(cat > /dev/null) 2>&1 | grep -E 'images in' | sed -e 's/\x1b\[[0-9;]*m//g')"
     done
   done
 done
