@@ -654,8 +654,10 @@ def main():
     ap.add_argument("--algorithm", default="dispersion", choices=["dispersion", "dispersion_extended"],
                     help="dispersion = the headline metric; dispersion_extended = the second algorithm of the "
                          "same CLI flag (SURVEY 8f), reported as its own metric")
-    ap.add_argument("--gather-every", type=int, default=4,
-                    help="N>1: batches whose spot lists are gathered by one RCCL collective")
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N>1: batches whose spot lists are gathered by one RCCL collective (8: the count exchange of gather k has "
+                         "2.6 ms -- eight steps -- to get through the GPU's queues before gather k + 1 needs it; with 4 the submit "
+                         "thread waited for it 0.4 ms per step, profiles/r04h_gather_ab.txt)")
     ap.add_argument("--gather", default="rows", choices=["rows", "padded"],
                     help="N>1: rows = all_gather of the ranks' row counts, then exactly the written (frame_id, x, y, z) rows point to "
                          "point to rank 0 (north_star's gather); padded = one all_gather_into_tensor of fixed-size blocks to every rank (A/B)")
@@ -769,66 +771,116 @@ def main():
     rows_mode = args.gather == "rows"
     if use_dist and rows_mode:
         # rows of a group's G batches end to end (+ one scratch row ffs_stream_spot_centres puts its counts in)
-        pack_host = [torch.empty((G * spot_cap + 1, 4), dtype=torch.float32).pin_memory() for _ in range(2)]
+        pin = (lambda t: t.pin_memory()) if os.environ.get("FFS_BENCH_PACK_PINNED", "1") != "0" else (lambda t: t)
+        pack_host = [pin(torch.empty((G * spot_cap + 1, 4), dtype=torch.float32)) for _ in range(2)]
         pack_dev = [torch.empty((G * spot_cap + 1, 4), dtype=torch.float32, device=dev) for _ in range(2)]
         recv_buf = [torch.empty((world * G * spot_cap if rank == 0 else 1, 4), dtype=torch.float32, device=dev) for _ in range(2)]
         buf_free = [None, None]
+        pack_np = [t.numpy() for t in pack_host]
     elif use_dist:
         pack_host = [torch.empty((G, spot_cap + 1, 4), dtype=torch.float32).pin_memory() for _ in range(2)]
         pack_dev = [torch.empty((G, spot_cap + 1, 4), dtype=torch.float32, device=dev) for _ in range(2)]
         gather_buf = [torch.empty((world * G, spot_cap + 1, 4), dtype=torch.float32, device=dev) for _ in range(2)]
         buf_free = [None, None]            # event after which pack_host[b] may be overwritten
+        pack_np = [t.numpy() for t in pack_host]
     cur, pending = 0, 0
     rows_at = 0             # rows mode: rows packed into pack_host[cur] so far
     gather_s = [0.0, 0.0]   # host seconds: packing, collectives
+    gather_t = {"h2d": 0.0, "begin": 0.0, "finish": 0.0, "buf_sync": 0.0}   # where a flush's host time goes
     last_gather = [None]    # index of the gather buffer the newest collective filled
     gathered_rows = [0, 0]  # rows mode: rows landed on rank 0, collectives
     tags_seen = set()
 
-    def flush_gather():
-        nonlocal cur, pending, rows_at
-        if not use_dist or pending == 0:
-            return
-        tg = time.perf_counter()
+    # The (frame_id, x, y, z) rows come out of the library with one memcpy per batch (ffs_stream_spot_centres: the rows are laid
+    # down while ffs_wait assembles the reflections; walking the 72-byte records again was 0.3 ms per batch, as long as a step),
+    # and one gather is always in flight: a flush begins gather k (counts all_gather, nothing waited for) and finishes gather
+    # k - 1 (its counts are on the host by then: sends / receives posted).  (A helper thread for the packing was tried: handing
+    # a job to a Python thread costs 0.5-0.7 ms of interpreter-lock hand-over, more than the work.)
+    in_flight = [None]      # rows mode: (handle, buffer index) of the gather begun and not yet finished
+    gather_scratch = None
+    # (the gather's copies and collectives stay on torch's current stream: a stream of their own -- one more beside the library's
+    # four -- made every collective's launch wait longer for a hardware queue: 70 k frames/s against 83 k in the one-rank rehearsal)
+    if use_dist and rows_mode:
+        from ffs_amd import dist as D
+        gather_scratch = D.RowGatherScratch(dev, slots=3)
+
+    def pack_job(stream, b, slot):
+        nonlocal rows_at
         if rows_mode:
-            from ffs_amd import dist as D
-            n = rows_at
-            if n:
-                pack_dev[cur][:n].copy_(pack_host[cur][:n], non_blocking=True)
-            got, counts, reqs = D.gather_rows_to_root(pack_dev[cur], n, tag=rank + 1, root=0, recv_buf=recv_buf[cur])
-            for r in reqs:
-                r.wait()                    # (nccl: orders the current stream behind the transfers, no host wait)
-            gathered_rows[0] += int(counts[:, 0].sum())
-            gathered_rows[1] += 1
-            tags_seen.update(int(t) for t in counts[:, 1] if t)
-            rows_at = 0
+            room = G * spot_cap - rows_at
+            rows_at += stream.pack_spot_centres(pack_np[b][rows_at:], room)   # (FFS_ERR_OVERFLOW when a batch does not fit)
         else:
-            for g in range(pending, G):      # unused slots of a partial group: zero spots
-                pack_host[cur][g, spot_cap] = 0          # (rows written, rows wanted) = (0, 0)
-            pack_dev[cur].copy_(pack_host[cur], non_blocking=True)
-            dist.all_gather_into_tensor(gather_buf[cur].view(-1), pack_dev[cur].view(-1))
+            row = pack_np[b][slot]
+            stream.pack_spot_centres(row, spot_cap)
+            row[spot_cap].view(np.uint32)[2] = rank + 1          # who packed this block (n_ranks_seen)
+
+    def finish_rows_gather():
+        from ffs_amd import dist as D
+        if in_flight[0] is None:
+            return
+        h, b = in_flight[0]
+        in_flight[0] = None
+        t0 = time.perf_counter()
+        got, counts, reqs = D.gather_rows_finish(h, pack_dev[b], root=0, recv_buf=recv_buf[b])
+        for r in reqs:
+            r.wait()                        # (nccl: orders the current stream behind the transfers, no host wait)
+        gather_t["finish"] += time.perf_counter() - t0
+        gathered_rows[0] += int(counts[:, 0].sum())
+        gathered_rows[1] += 1
+        tags_seen.update(int(t) for t in counts[:, 1] if t)
         ev = torch.cuda.Event()
         ev.record()
-        buf_free[cur] = ev
-        last_gather[0] = cur
-        cur, pending = cur ^ 1, 0
+        buf_free[b] = ev
+
+    def flush_gather(last=False):
+        if not use_dist:
+            return
+        _flush_gather(last)
+
+    def _flush_gather(last):
+        nonlocal cur, pending, rows_at
+        tg = time.perf_counter()
+        if pending:
+            if rows_mode:
+                from ffs_amd import dist as D
+                n = rows_at
+                rows_at = 0
+                t0 = time.perf_counter()
+                if n:
+                    pack_dev[cur][:n].copy_(pack_host[cur][:n], non_blocking=True)
+                t1 = time.perf_counter()
+                h = D.gather_rows_begin(n, rank + 1, dev, scratch=gather_scratch)
+                gather_t["h2d"] += t1 - t0
+                gather_t["begin"] += time.perf_counter() - t1
+                finish_rows_gather()                 # the one before this
+                in_flight[0] = (h, cur)
+            else:
+                for g in range(pending, G):      # unused slots of a partial group: zero spots
+                    pack_host[cur][g, spot_cap] = 0          # (rows written, rows wanted) = (0, 0)
+                pack_dev[cur].copy_(pack_host[cur], non_blocking=True)
+                dist.all_gather_into_tensor(gather_buf[cur].view(-1), pack_dev[cur].view(-1))
+                ev = torch.cuda.Event()
+                ev.record()
+                buf_free[cur] = ev
+            last_gather[0] = cur
+            cur, pending = cur ^ 1, 0
+        if last and rows_mode:
+            finish_rows_gather()                     # every frame's spots are on rank 0 before the clock stops
         gather_s[1] += time.perf_counter() - tg
 
     def gather(results, stream):
-        nonlocal pending, rows_at
+        nonlocal pending
         if not use_dist:
             return
         tg = time.perf_counter()
-        if pending == 0 and buf_free[cur] is not None:
-            buf_free[cur].synchronize()
-        # (frame_id, x, y, z) rows straight from the library's reflection records (C loop)
-        if rows_mode:
-            room = G * spot_cap - rows_at
-            rows_at += stream.pack_spot_centres(pack_host[cur][rows_at:].numpy(), room)   # (raises FFS_ERR_OVERFLOW when a batch does not fit)
-        else:
-            row = pack_host[cur][pending].numpy()
-            stream.pack_spot_centres(row, spot_cap)
-            row[spot_cap].view(np.uint32)[2] = rank + 1          # who packed this block (n_ranks_seen)
+        if pending == 0:
+            if rows_mode and in_flight[0] is not None and in_flight[0][1] == cur:
+                finish_rows_gather()                 # (this buffer's gather is still in flight: only with fewer than two flushes between)
+            if buf_free[cur] is not None:
+                t0 = time.perf_counter()
+                buf_free[cur].synchronize()
+                gather_t["buf_sync"] += time.perf_counter() - t0
+        pack_job(stream, cur, pending)
         pending += 1
         gather_s[0] += time.perf_counter() - tg
         if pending == G:
@@ -860,7 +912,7 @@ def main():
                 gather(None, done)
                 spots += nbx
                 strong_px += nst
-        flush_gather()                   # every frame's spots are gathered before the clock stops
+        flush_gather(last=True)          # every frame's spots are gathered before the clock stops
         return spots
 
     def barrier():
@@ -1082,7 +1134,8 @@ def main():
         if use_dist:
             n_timed = args.warmup + (len(times) + 2) * args.steps
             out["config"]["gather_host_ms_per_step"] = {"pack": round(gather_s[0] / n_timed * 1e3, 4),
-                                                        "collective": round(gather_s[1] / n_timed * 1e3, 4)}
+                                                        "collective": round(gather_s[1] / n_timed * 1e3, 4),
+                                                        **{k: round(v / n_timed * 1e3, 4) for k, v in gather_t.items()}}
             # bytes that land per step: on rank 0 only (rows), or on EVERY rank (padded blocks)
             out["config"]["gather_bytes_per_step"] = (int(gathered_rows[0] * 16 / max(1, gathered_rows[1]) / G) if rows_mode
                                                       else int(world * (spot_cap + 1) * 16))

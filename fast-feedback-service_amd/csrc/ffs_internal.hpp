@@ -240,6 +240,7 @@ struct ffs_stream {
     std::vector<ffs_frame_result> results;
     std::vector<ffs_box> boxes;
     std::vector<ffs_reflection> refls;
+    std::vector<float> centres;   // (frame id bits, com_x, com_y, com_z) per reflection of the last batch, filled with `refls` (ffs_stream_spot_centres)
 };
 
 // Results of a frame that did not fit the stream's lists, from its re-run on the one-frame stream

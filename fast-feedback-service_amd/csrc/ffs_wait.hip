@@ -208,6 +208,10 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
     for (const OverflowFrame& o : s->ovf) extra += o.boxes.size();
     s->boxes.resize(total_recs + extra);
     if (p.want_reflections) s->refls.resize(total_recs + extra); else s->refls.clear();
+    // the centres as (frame id, x, y, z) rows, written while each record is in hand: ffs_stream_spot_centres hands them out with one
+    // memcpy (walking the 72-byte reflections again cost a caller 0.3 ms per batch of 45 000 -- as long as the GPU takes for the batch)
+    s->centres.resize(p.want_reflections ? (total_recs + extra) * 4 : 0);
+    float* co = s->centres.data();
     std::vector<size_t> box_at(n), refl_at(n);
     ffs_box* bo = s->boxes.data();
     ffs_reflection* ro = s->refls.data();
@@ -223,9 +227,20 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
         if (const OverflowFrame* o = overflow_frame(f)) {  // re-run on the one-frame stream: skip the cut records
             wrec += nc;
             for (const ffs_box& b : o->boxes) bo[nbx++] = b;
-            if (want_refl) for (const ffs_reflection& r : o->refls) ro[nrf++] = r;
+            if (want_refl) {
+                const uint32_t idb = (uint32_t)((uint64_t)(s->first_id + f) & 0xFFFFFFFFull);
+                float idf;
+                std::memcpy(&idf, &idb, 4);
+                for (const ffs_reflection& r : o->refls) {
+                    co[4 * nrf] = idf; co[4 * nrf + 1] = r.com_x; co[4 * nrf + 2] = r.com_y; co[4 * nrf + 3] = r.com_z;
+                    ro[nrf++] = r;
+                }
+            }
             continue;
         }
+        const uint32_t id_bits = (uint32_t)((uint64_t)(s->first_id + f) & 0xFFFFFFFFull);   // (a bit pattern: as a float VALUE ids collide from 2^24 on)
+        float id_lane;
+        std::memcpy(&id_lane, &id_bits, 4);
         for (uint32_t q = 0; q < nc; ++q, ++wrec) {
             const uint32_t npx = wrec->npx_flags & 0x3FFFFFFFu, flags = wrec->npx_flags >> 30;
             if (min_size == 0 || npx >= min_size) bo[nbx++] = ffs_box{wrec->x_min, wrec->y_min, wrec->x_max, wrec->y_max, (int32_t)npx};
@@ -240,12 +255,13 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
                 r.peak_centroid_distance = wrec->peak_centroid_distance;
                 r.flags = 0;
                 r.sum_intensity = wrec->sum_intensity;
+                co[4 * nrf] = id_lane; co[4 * nrf + 1] = r.com_x; co[4 * nrf + 2] = r.com_y; co[4 * nrf + 3] = 0.5f;
                 ro[nrf++] = r;
             }
         }
     }
     s->boxes.resize(nbx);
-    if (want_refl) s->refls.resize(nrf);
+    if (want_refl) { s->refls.resize(nrf); s->centres.resize(nrf * 4); }
     for (uint32_t f = 0; f < n; ++f) {
         ffs_frame_result& r = s->results[f];
         const uint32_t* sm = h_sm + (size_t)f * 8;
@@ -313,26 +329,11 @@ extern "C" int ffs_stream_timings(ffs_stream* s, float ms[5]) {
 
 extern "C" int ffs_stream_spot_centres(ffs_stream* s, float* rows4, uint32_t cap, uint32_t* n_written) {
     if (!s || !rows4) return FFS_ERR_INVALID;
-    if (s->busy) {
-        s->ctx->err = "ffs_stream_spot_centres: a batch is in flight";
-        return FFS_ERR_INVALID;
-    }
-    uint32_t n = 0;
-    uint64_t wanted = 0;
-    for (const ffs_frame_result& r : s->results) {
-        // the id's low 32 bits as a bit pattern: as a float VALUE ids would collide from 2^24 on
-        const uint32_t id_bits = (uint32_t)((uint64_t)r.frame_id & 0xFFFFFFFFull);
-        float id;
-        std::memcpy(&id, &id_bits, 4);
-        wanted += r.n_reflections;
-        for (uint32_t q = 0; q < r.n_reflections && n < cap; ++q, ++n) {
-            float* row = rows4 + (size_t)n * 4;
-            row[0] = id;
-            row[1] = r.reflections[q].com_x;
-            row[2] = r.reflections[q].com_y;
-            row[3] = r.reflections[q].com_z;
-        }
-    }
+    // (reads the result arrays of the last ffs_wait only: they stay as they are while the NEXT batch is in flight, so a caller may
+    // pack one batch's centres on a helper thread while it submits the next -- until the next ffs_wait on this stream)
+    const uint64_t wanted = s->centres.size() / 4;
+    const uint32_t n = (uint32_t)std::min<uint64_t>(wanted, cap);
+    if (n) std::memcpy(rows4, s->centres.data(), (size_t)n * 16);
     // last row: (rows written, rows wanted) as uint32 bit patterns -- wanted > written tells the receiver
     // that `cap` was too small (nothing is dropped silently)
     float* last = rows4 + (size_t)cap * 4;

@@ -100,6 +100,97 @@ def all_gather_fixed(t, group=None):
     return torch.cat(out, 0)
 
 
+class _RowGather:
+    """A gather in flight between gather_rows_begin and gather_rows_finish."""
+    __slots__ = ("counts_dev", "counts_host", "event", "world", "rank", "group")
+
+
+class RowGatherScratch:
+    """The small tensors a GPU row gather needs, allocated ONCE (a pinned allocation and a host-to-device copy out of pageable
+    memory per gather cost 1.3 ms of host time per flush -- four steps' worth -- in bench.py's one-rank rehearsal): (count, tag)
+    in pinned host memory and on the device, every rank's counts on the device and in pinned host memory; `slots` sets of them,
+    used in turn (a set is free again once its gather has been finished)."""
+
+    def __init__(self, device, group=None, slots: int = 2):
+        import torch
+        import torch.distributed as dist
+        self.world = dist.get_world_size(group)
+        self.sets = [dict(me_host=torch.zeros(2, dtype=torch.int64).pin_memory(),
+                          me_dev=torch.zeros(2, dtype=torch.int64, device=device),
+                          counts_dev=torch.zeros(2 * self.world, dtype=torch.int64, device=device),
+                          counts_host=torch.zeros(2 * self.world, dtype=torch.int64).pin_memory(),
+                          event=torch.cuda.Event()) for _ in range(slots)]
+        self.next = 0
+
+    def take(self):
+        s = self.sets[self.next]
+        self.next = (self.next + 1) % len(self.sets)
+        return s
+
+
+def gather_rows_begin(n: int, tag: int, device, group=None, scratch: RowGatherScratch | None = None) -> _RowGather:
+    """First half of the row gather: the all_gather of every rank's (row count, tag).  On a GPU group nothing here waits for the
+    device -- the counts travel into pinned host memory behind an event that gather_rows_finish waits for -- so a caller that
+    finishes gather k while beginning gather k + 1 never stalls its submit loop on a collective.  `scratch`: preallocated
+    tensors (RowGatherScratch) for callers that gather often."""
+    import torch
+    import torch.distributed as dist
+    h = _RowGather()
+    h.world, h.rank, h.group = dist.get_world_size(group), dist.get_rank(group), group
+    if scratch is not None:
+        s = scratch.take()
+        s["me_host"][0] = int(n)
+        s["me_host"][1] = int(tag)
+        s["me_dev"].copy_(s["me_host"], non_blocking=True)
+        dist.all_gather_into_tensor(s["counts_dev"], s["me_dev"], group=group)
+        s["counts_host"].copy_(s["counts_dev"], non_blocking=True)
+        s["event"].record()
+        h.counts_dev, h.counts_host, h.event = s["counts_dev"], s["counts_host"], s["event"]
+        return h
+    me = torch.tensor([int(n), int(tag)], dtype=torch.int64, device=device)
+    h.counts_dev = all_gather_fixed(me, group)
+    if h.counts_dev.is_cuda:
+        h.counts_host = torch.empty(h.counts_dev.shape, dtype=torch.int64).pin_memory()
+        h.counts_host.copy_(h.counts_dev, non_blocking=True)
+        h.event = torch.cuda.Event()
+        h.event.record()
+    else:
+        h.counts_host, h.event = h.counts_dev, None
+    return h
+
+
+def gather_rows_finish(h: _RowGather, rows, root: int = 0, recv_buf=None):
+    """Second half: with the counts on the host, EXACTLY the written rows travel point to point to `root` (one group of sends and
+    receives).  Returns (gathered, counts, requests) as gather_rows_to_root does."""
+    import torch
+    import torch.distributed as dist
+    if h.event is not None:
+        h.event.synchronize()
+    counts = h.counts_host.numpy().reshape(h.world, 2).copy()
+    n = int(counts[h.rank, 0])
+    ops, gathered = [], None
+    if h.rank == root:
+        total = int(counts[:, 0].sum())
+        if recv_buf is None:
+            recv_buf = torch.empty((max(total, 1), 4), dtype=rows.dtype, device=rows.device)
+        if recv_buf.shape[0] < total:
+            raise SpotGatherTruncated(f"{total} rows gathered, room for {recv_buf.shape[0]}")
+        off = 0
+        for r in range(h.world):
+            c = int(counts[r, 0])
+            if r == h.rank:
+                if c:
+                    recv_buf[off:off + c].copy_(rows[:c])
+            elif c:
+                ops.append(dist.P2POp(dist.irecv, recv_buf[off:off + c], r, h.group))
+            off += c
+        gathered = recv_buf[:total]
+    elif n:
+        ops.append(dist.P2POp(dist.isend, rows[:n], root, h.group))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    return gathered, counts, reqs
+
+
 def gather_rows_to_root(rows, n: int, tag: int = 0, root: int = 0, group=None, recv_buf=None):
     """The gather `north_star` words ("a simple RCCL-over-xGMI gather of the per-frame spot lists"): one tiny
     all_gather of every rank's row count, then EXACTLY the written rows travel, point to point, to `root` -- no padding, and
@@ -107,33 +198,9 @@ def gather_rows_to_root(rows, n: int, tag: int = 0, root: int = 0, group=None, r
     tensor under "nccl" = RCCL: the sends and receives go out as one group; CPU tensor under "gloo").  `tag` travels with the
     count (bench.py: rank + 1).  Returns (gathered, counts, requests): on `root` `gathered` is the (sum of counts, 4) tensor
     of all ranks' rows in rank order (a view of `recv_buf` when given, which must hold them), None elsewhere; `counts` is the
-    (world, 2) int64 array of (rows, tag) per rank; wait on `requests` before reading `gathered` / reusing `rows`."""
-    import torch
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    me = torch.tensor([int(n), int(tag)], dtype=torch.int64, device=rows.device)
-    counts = all_gather_fixed(me, group).cpu().numpy().reshape(world, 2)
-    ops, gathered = [], None
-    if rank == root:
-        total = int(counts[:, 0].sum())
-        if recv_buf is None:
-            recv_buf = torch.empty((max(total, 1), 4), dtype=rows.dtype, device=rows.device)
-        if recv_buf.shape[0] < total:
-            raise SpotGatherTruncated(f"{total} rows gathered, room for {recv_buf.shape[0]}")
-        off = 0
-        for r in range(world):
-            c = int(counts[r, 0])
-            if r == rank:
-                if c:
-                    recv_buf[off:off + c].copy_(rows[:c])
-            elif c:
-                ops.append(dist.P2POp(dist.irecv, recv_buf[off:off + c], r, group))
-            off += c
-        gathered = recv_buf[:total]
-    elif n:
-        ops.append(dist.P2POp(dist.isend, rows[:int(n)], root, group))
-    reqs = dist.batch_isend_irecv(ops) if ops else []
-    return gathered, counts, reqs
+    (world, 2) int64 array of (rows, tag) per rank; wait on `requests` before reading `gathered` / reusing `rows`.
+    (= gather_rows_begin + gather_rows_finish back to back; bench.py keeps one gather in flight between the two.)"""
+    return gather_rows_finish(gather_rows_begin(n, tag, rows.device, group), rows, root, recv_buf)
 
 
 def rows_by_frame(rows: np.ndarray) -> dict:

@@ -245,7 +245,8 @@ int ffs_stream_timings(ffs_stream *s, float ms[5]);
  * low 32 bits of the frame id as a BIT PATTERN (read it as uint32: as a float value ids would collide
  * from 2^24 on).  Writes at most `cap` rows, then one more row whose first two lanes are, again as uint32
  * bit patterns, (rows written, rows wanted): rows4 must hold (cap + 1) * 4 floats.  Returns
- * FFS_ERR_OVERFLOW (rows written are valid) when wanted > cap.  Needs want_reflections. */
+ * FFS_ERR_OVERFLOW (rows written are valid) when wanted > cap.  Needs want_reflections.  Reads the last ffs_wait's results
+ * only: may run (on another thread) while the stream's next batch is in flight, until the next ffs_wait on this stream. */
 int ffs_stream_spot_centres(ffs_stream *s, float *rows4, uint32_t cap, uint32_t *n_written);
 
 /* ---- measurement entry points (bench.py roofline leg, tools/) -------------------------------- */
