@@ -151,7 +151,9 @@ int ffs_ctx_set_params(ffs_ctx *ctx, const ffs_params *p);
  * per context, never through the environment; nothing here can change a result.  Keys (default):
  *   "threshold_path"   (0) 0 = windows the streaming kernel cannot vouch for go onto a list (fix-up kernel),
  *                          1 = they are marked in the plane and an exact kernel filters it (also the fall-back
- *                          when that list overflows)
+ *                          when that list overflows), 2 = no streaming kernel at all: the window of EVERY valid pixel is
+ *                          gathered from memory and decided by the exact kernel (~10 ms per Eiger frame: the independent
+ *                          partner `spotfinder --validate` compares the hot path with, spotfinder.cc:1012-1053)
  *   "ext_first_pass"   (2) extended algorithm, 16-bit pixels: 2 = streaming kernel, 0 = plain one-pixel-per-lane kernel
  *   "sparse_stage"     (2) one launch per batch, a workgroup per frame: 3 = always, 2 = unless the stream's previous batch
  *                          held a frame with more strong pixels than that workgroup's LDS holds; 1 = four grid-wide kernels
@@ -168,7 +170,10 @@ int ffs_ctx_set_params(ffs_ctx *ctx, const ffs_params *p);
  *                          (before the first stream is created)
  *   "direct_records"   (1) records written straight into pinned host memory (before the first stream is created)
  *   "chain_first" (2), "bright_cap" (2^20), "frames_per_group", "target_waves" (16384), "dense_mask" (0),
- *   "occupancy_bitmap" (1), "decode_in_dense_stream" (1): see DESIGN.md.
+ *   "occupancy_bitmap" (1), "decode_in_dense_stream" (1), "rows_ahead" (2), "ccl_grid" (32): see DESIGN.md.
+ *   "band_taper" (0), "ext_rest_aside" (0), "ext_fused" (0): round 4's A/B partners (tapered bands of the streaming kernels;
+ *                          extended algorithm: erosion + final pass in the sparse stream / fused into one kernel) -- measured, no
+ *                          gain, off (DESIGN.md sections 3.2c, 4)
  * The reference has no counterpart (its launch wrapper has one path, spotfinder/spotfinder.cu:148-189). */
 int ffs_ctx_set_tuning(ffs_ctx *ctx, const char *key, long long value);
 
