@@ -635,6 +635,7 @@ int main(int argc, char** argv) {
         std::vector<const void*> chunk_ptr;
         std::vector<size_t> chunk_len;
         std::vector<std::vector<uint8_t>> spill;   // chunks that did not fit their slot (their whole batch then goes up from here)
+        std::vector<uint8_t> slot_filled;          // (under the GPU's mutex) which slots of the batch hold their image
         // state, under the GPU's mutex
         int64_t batch = -1;            // the global batch this assembly holds, -1: free
         uint64_t next_q = 0;           // the GPU-local batch number it serves next (claims happen in order)
@@ -668,9 +669,11 @@ int main(int argc, char** argv) {
             A.chunk_ptr.resize(batch);
             A.chunk_len.resize(batch);
             A.spill.resize(batch);
+            A.slot_filled.assign(batch, 0);
         }
         gpus.push_back(std::move(g));
     }
+    std::atomic<bool> readers_done{false};   // no batch will be submitted any more: collectors stop at the first one that is missing
     std::atomic<size_t> chunk_estimate{0};   // staging bytes per compressed chunk, from the first chunk anybody reads
     std::atomic<uint32_t> validate_mismatches{0};
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -695,8 +698,10 @@ int main(int argc, char** argv) {
             Assembly& A = G.as[q % K];
             {
                 std::unique_lock<std::mutex> lock(G.mu);
-                G.cv.wait(lock, [&] { return (A.batch == (int64_t)b && A.submitted) || g_stop.load() || failed.load(); });
-                if (!(A.batch == (int64_t)b && A.submitted)) break;   // interrupted / timed out / failed: what is not submitted is dropped
+                // (an interrupt or a time-out stops the READERS; what has been submitted -- and, below, every image that was read --
+                // still comes out, as the reference's workers finish the image they hold: spotfinder.cc:770-790)
+                G.cv.wait(lock, [&] { return (A.batch == (int64_t)b && A.submitted) || readers_done.load() || failed.load(); });
+                if (failed.load() || !(A.batch == (int64_t)b && A.submitted)) break;
             }
             const uint32_t thread_id = (uint32_t)A.submitted_by;
             if (!A.skipped) {
@@ -848,6 +853,37 @@ int main(int argc, char** argv) {
         }
     };
 
+    // the first n frames of an assembly's batch go to the GPU (n = all of them, or what had been read when the readers stopped)
+    auto submit_batch = [&](Gpu& G, Assembly& A, uint32_t n, uint32_t first, int thread_id) -> bool {
+        if (args.read_only) {
+            A.skipped = true;
+        } else {
+            bool spilled = false;
+            for (uint32_t i = 0; i < n; ++i) spilled = spilled || !A.spill[i].empty();
+            if (gpu_decode && spilled)   // (all chunks of a batch lie in the staging area or none: the others go through the heap too)
+                for (uint32_t i = 0; i < n; ++i)
+                    if (A.spill[i].empty()) {
+                        const uint8_t* p = static_cast<const uint8_t*>(A.chunk_ptr[i]);
+                        A.spill[i].assign(p, p + A.chunk_len[i]);
+                        A.chunk_ptr[i] = A.spill[i].data();
+                    }
+            const int sub = gpu_decode ? ffs_submit_compressed(A.s, A.chunk_ptr.data(), A.chunk_len.data(), n, first)
+                                       : ffs_submit(A.s, A.host, n, first);
+            if (sub != FFS_OK) { fail("", G.ctx); return false; }
+            if (A.v) {   // the same input through the validation context
+                const int vsub = gpu_decode ? ffs_submit_compressed(A.v, A.chunk_ptr.data(), A.chunk_len.data(), n, first)
+                                            : ffs_submit(A.v, A.host, n, first);
+                if (vsub != FFS_OK) { fail("validation pass: ", G.vctx); return false; }
+            }
+        }
+        std::lock_guard<std::mutex> lock(G.mu);
+        A.n = n;
+        A.submitted_by = thread_id;
+        A.submitted = true;
+        G.cv.notify_all();
+        return true;
+    };
+
     // ---- a reader: chunks from the frame source into the slots of its GPU's assemblies ----------------------------------------
     auto reader_thread = [&](int thread_id) {
         const uint32_t di = (uint32_t)thread_id % n_dev;
@@ -928,6 +964,7 @@ int main(int argc, char** argv) {
                     A.filled = 0;
                     A.submitted = false;
                     A.skipped = false;
+                    std::fill(A.slot_filled.begin(), A.slot_filled.end(), (uint8_t)0);
                     if (!A.s) {   // first use: the stream(s) and the pinned staging area, outside the lock
                         A.ready = false;
                         lock.unlock();
@@ -1028,40 +1065,15 @@ int main(int argc, char** argv) {
             bool last = false;
             {
                 std::lock_guard<std::mutex> lock(G.mu);
+                A.slot_filled[k] = 1;
                 last = ++A.filled == A.n;
             }
             if (!last) continue;
             // the batch is complete: whoever filled its last slot sends it off
             const auto t_s0 = now();
-            if (args.read_only) {
-                A.skipped = true;
-            } else {
-                bool spilled = false;
-                for (uint32_t i = 0; i < A.n; ++i) spilled = spilled || !A.spill[i].empty();
-                if (gpu_decode && spilled)   // (all chunks of a batch lie in the staging area or none: the others go through the heap too)
-                    for (uint32_t i = 0; i < A.n; ++i)
-                        if (A.spill[i].empty()) {
-                            const uint8_t* p = static_cast<const uint8_t*>(A.chunk_ptr[i]);
-                            A.spill[i].assign(p, p + A.chunk_len[i]);
-                            A.chunk_ptr[i] = A.spill[i].data();
-                        }
-                const int sub = gpu_decode ? ffs_submit_compressed(A.s, A.chunk_ptr.data(), A.chunk_len.data(), A.n, first)
-                                           : ffs_submit(A.s, A.host, A.n, first);
-                if (sub != FFS_OK) { fail("", ctx); break; }
-                if (A.v) {   // the same input through the validation context
-                    const int vsub = gpu_decode ? ffs_submit_compressed(A.v, A.chunk_ptr.data(), A.chunk_len.data(), A.n, first)
-                                                : ffs_submit(A.v, A.host, A.n, first);
-                    if (vsub != FFS_OK) { fail("validation pass: ", G.vctx); break; }
-                }
-            }
+            if (!submit_batch(G, A, A.n, first, thread_id)) break;
             ++n_submitted;
             t_submit += secs(t_s0, now());
-            {
-                std::lock_guard<std::mutex> lock(G.mu);
-                A.submitted_by = thread_id;
-                A.submitted = true;
-                G.cv.notify_all();
-            }
         }
         if (args.verbose) {
             std::lock_guard<std::mutex> lock(print_mutex);
@@ -1083,16 +1095,25 @@ int main(int argc, char** argv) {
         for (uint32_t di = 0; di < n_dev; ++di) threads.emplace_back(collector, di);
         for (uint32_t t = 0; t < n_workers; ++t) threads.emplace_back(reader_thread, (int)t);
         for (size_t t = n_dev; t < threads.size(); ++t) threads[t].join();   // the readers
-        wake_all();                                                          // (collectors waiting for a batch nobody will submit)
-        {   // a reader that stopped early (timeout, interrupt) leaves batches unsubmitted: the collectors give up on those
+        // Readers that stopped early (a time-out: the data set ended before --images; an interrupt) leave batches half filled.  The
+        // reference's workers finish the image they hold, so every image that WAS read still goes through: the leading filled
+        // slots of such a batch are submitted as a shorter batch (images arrive in order; one behind a missing image is dropped).
+        if (!failed.load())
             for (uint32_t di = 0; di < n_dev; ++di) {
                 Gpu& G = *gpus[di];
-                std::unique_lock<std::mutex> lock(G.mu);
-                bool pending = false;
-                for (Assembly& A : G.as) pending = pending || (A.batch >= 0 && !A.submitted);
-                if (pending) { g_stop.store(true); G.cv.notify_all(); }
+                for (Assembly& A : G.as) {
+                    uint32_t prefix = 0, first = 0;
+                    {
+                        std::lock_guard<std::mutex> lock(G.mu);
+                        if (A.batch < 0 || A.submitted || !A.ready) continue;
+                        while (prefix < A.n && A.slot_filled[prefix]) ++prefix;
+                        first = (uint32_t)((uint64_t)A.batch * batch);
+                    }
+                    if (prefix > 0) (void)submit_batch(G, A, prefix, first, 0);
+                }
             }
-        }
+        readers_done.store(true);
+        wake_all();                                                          // (collectors waiting for a batch nobody will submit)
         for (uint32_t di = 0; di < n_dev; ++di) threads[di].join();
         // every result is out: the streams' buffers are released after the totals are printed, not on the clock
         for (auto& g : gpus)

@@ -484,3 +484,59 @@ def test_batches_assembled_by_several_readers_chunks_of_any_size(tmp_path, argv)
     if "--devices" not in argv:
         assert [j["file-number"] for j in got] == list(range(N))              # one collector: results leave in frame order
     assert f"{N} images in" in out
+
+
+def test_data_set_that_ends_early_reports_every_image_that_was_read(tmp_path):
+    """A live stream directory whose header promises 11 images and holds 8: the readers give up after `--timeout`
+    ("Timeout waiting for image 8", spotfinder.cc:776-787), and every image that WAS read still comes out -- the reference's
+    workers finish the image they hold -- although the last GPU batch is only partly filled (batch 3: images 6, 7 of 6..8)."""
+    rng = np.random.default_rng(9)
+    W, H, N_have, N_said = 300, 200, 8, 11
+    frames = rng.poisson(2.0, (N_have, H, W)).astype(np.uint16)
+    for i in range(N_have):
+        frames[i, 30 + i:33 + i, 60:63] += 400
+    shm = tmp_path / "shm"
+    _write_stream_dir(str(shm), frames)
+    hdr = json.loads((shm / "start_1").read_text())
+    hdr["nimages"] = N_said
+    (shm / "start_1").write_text(json.dumps(hdr) + "\n")
+    for argv in (["--threads", "3", "--batch", "3"], ["--threads", "2", "--batch", "4", "--cpu-decode"]):
+        rc, out, err, lines = run_with_pipe([str(shm), "--timeout", "1.5", *argv], tmp_path)
+        assert rc == 0 and not err, (out, err)
+        assert "Timeout waiting for image 8" in out
+        got = [json.loads(l) for l in lines]
+        assert [j["file-number"] for j in got] == list(range(N_have))
+        exp = _oracle_counts(frames, np.ones((H, W), np.uint8))
+        for j in got:
+            assert (j["num_strong_pixels"], j["n_spots_total"]) == exp[j["file-number"]]
+        assert f"{N_have} images in" in out
+
+
+def test_interrupt_stops_the_readers_and_reports_what_was_read(tmp_path):
+    """SIGINT (spotfinder.cc:43-54, "Running interrupted by user request"): the readers stop, what has been read is processed and
+    reported, the summary line counts exactly the JSON lines that went out, exit code 0."""
+    import signal
+    import time
+    r, w = os.pipe()
+    proc = subprocess.Popen([SPOTFINDER, "synth:tiny:200000", "--threads", "2", "--pipe_fd", str(w)], pass_fds=[w], cwd=tmp_path,
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    os.close(w)
+    lines = []
+    import threading
+
+    def drain():
+        with os.fdopen(r) as f:
+            for ln in f:
+                lines.append(ln)
+    th = threading.Thread(target=drain, daemon=True)
+    th.start()
+    time.sleep(1.5)
+    proc.send_signal(signal.SIGINT)
+    out, err = proc.communicate(timeout=60)
+    th.join(10)
+    assert proc.returncode == 0 and not err, (out[-500:], err)
+    assert "Running interrupted by user request" in out
+    m = re.search(r"(\d+) images in", strip_ansi(out))
+    assert m and 0 < int(m.group(1)) < 200000
+    nums = [json.loads(l)["file-number"] for l in lines if l.strip()]
+    assert len(nums) == int(m.group(1)) and nums == list(range(len(nums)))      # a contiguous prefix, in order, nothing lost
