@@ -641,6 +641,7 @@ int main(int argc, char** argv) {
         uint64_t next_q = 0;           // the GPU-local batch number it serves next (claims happen in order)
         uint32_t n = 0, filled = 0;
         bool ready = false;            // staging area in place: slots may be filled
+        bool creating = false;         // somebody is making the stream and pinning the staging area
         bool submitted = false, skipped = false;
         int submitted_by = 0;
     };
@@ -838,6 +839,13 @@ int main(int argc, char** argv) {
                 completed += A.n;   // --read-only: nothing was submitted
             }
             ++n_batches;
+            if (args.verbose && n_batches <= 5 && !A.skipped) {
+                float tm2[5] = {0};
+                ffs_stream_timings(A.s, tm2);
+                std::lock_guard<std::mutex> lock(print_mutex);
+                std::printf("GPU %d collector: batch %u out %.1f ms after the start (device: copy+decode %.2f, threshold %.2f, sparse %.2f, total %.2f ms)\n",
+                            devices[di], n_batches - 1, secs(all_start, now()) * 1e3, tm2[0], tm2[1], tm2[2], tm2[4]);
+            }
             {
                 std::lock_guard<std::mutex> lock(G.mu);
                 A.batch = -1;
@@ -884,6 +892,42 @@ int main(int argc, char** argv) {
         return true;
     };
 
+    // An assembly's stream(s) and pinned staging area, made by whoever asks first (the others wait).  The first K readers of a GPU
+    // each make one assembly as soon as the size of a chunk is known, side by side: made one after the other, each when its first
+    // batch was claimed, the first four batches of a run went through at one per 10 ms (a 150 MB staging area takes 6 ms to pin).
+    auto ensure_assembly = [&](Gpu& G, Assembly& A, uint32_t index, int thread_id) -> bool {
+        std::unique_lock<std::mutex> lock(G.mu);
+        if (A.ready) return true;
+        if (A.creating) {
+            G.cv.wait(lock, [&] { return A.ready || g_stop.load() || failed.load(); });
+            return A.ready;
+        }
+        A.creating = true;
+        lock.unlock();
+        const auto t_c0 = now();
+        bool ok = ffs_stream_create(G.ctx, &A.s) == FFS_OK && (!G.vctx || ffs_stream_create(G.vctx, &A.v) == FFS_OK);
+        const auto t_c1 = now();
+        // chunks: B tight slots (the first chunk's size + 2 %: what lies in consecutive slots crosses PCIe as ONE copy --
+        // a copy per chunk cost 5 % of the frame rate) and behind them an overflow area for the chunks that do not fit theirs
+        A.slot_bytes = gpu_decode ? chunk_estimate.load() : frame_bytes;
+        A.over_at = (size_t)batch * A.slot_bytes;
+        const size_t over = gpu_decode ? std::max((size_t)batch * A.slot_bytes / 4, std::min(3 * A.slot_bytes, frame_bytes + 4096)) : 0;
+        void* v = nullptr;
+        ok = ok && ffs_stream_reserve_host(A.s, A.over_at + over) == FFS_OK && ffs_stream_host_buffer(A.s, &v, &A.host_bytes) == FFS_OK;
+        A.host = static_cast<uint8_t*>(v);
+        if (!ok) { fail("", G.ctx); return false; }
+        lock.lock();
+        A.ready = true;
+        G.cv.notify_all();
+        lock.unlock();
+        if (args.verbose) {
+            std::lock_guard<std::mutex> pl(print_mutex);
+            std::printf("Thread %2d: assembly %u of GPU %d ready (stream %.1f ms, %.0f MB of staging %.1f ms) %.0f ms after the start\n", thread_id,
+                        index, devices[G.index], secs(t_c0, t_c1) * 1e3, A.host_bytes / 1e6, secs(t_c1, now()) * 1e3, secs(all_start, now()) * 1e3);
+        }
+        return true;
+    };
+
     // ---- a reader: chunks from the frame source into the slots of its GPU's assemblies ----------------------------------------
     auto reader_thread = [&](int thread_id) {
         const uint32_t di = (uint32_t)thread_id % n_dev;
@@ -900,6 +944,7 @@ int main(int argc, char** argv) {
         };
         double t_read = 0, t_chunk = 0, t_submit = 0, t_blocked = 0;
         uint32_t n_read = 0, n_submitted = 0;
+        bool made_mine = false;
         auto last_received = now();
         while (!g_stop.load() && !failed.load()) {
             const uint64_t j = G.next_slot.fetch_add(1);
@@ -952,6 +997,11 @@ int main(int argc, char** argv) {
                 chunk_estimate.compare_exchange_strong(expect, ((chunk.size() + (size_t)(chunk.size() * (double)args.slot_margin / 100.0) + 16384) + 63) & ~(size_t)63);
             }
 
+            if (!made_mine) {   // the GPU's first K readers make one assembly each, side by side (see ensure_assembly)
+                made_mine = true;
+                const uint32_t local = (uint32_t)thread_id / n_dev;
+                if (local < K && !ensure_assembly(G, G.as[local], local, thread_id)) break;
+            }
             // this batch's assembly: claimed by the first of its readers to get here (in order: batch q - K must have been collected)
             {
                 const auto t_b0 = now();
@@ -965,31 +1015,10 @@ int main(int argc, char** argv) {
                     A.submitted = false;
                     A.skipped = false;
                     std::fill(A.slot_filled.begin(), A.slot_filled.end(), (uint8_t)0);
-                    if (!A.s) {   // first use: the stream(s) and the pinned staging area, outside the lock
-                        A.ready = false;
+                    if (!A.ready) {   // first use (usually made ahead, below): the stream(s) and the pinned staging area, outside the lock
                         lock.unlock();
-                        const auto t_c0 = now();
-                        bool ok = ffs_stream_create(ctx, &A.s) == FFS_OK && (!G.vctx || ffs_stream_create(G.vctx, &A.v) == FFS_OK);
-                        const auto t_c1 = now();
-                        // chunks: B tight slots (the first chunk's size + 2 %: what lies in consecutive slots crosses PCIe as ONE copy --
-                        // a copy per chunk cost 5 % of the frame rate) and behind them an overflow area for the chunks that do not fit theirs
-                        A.slot_bytes = gpu_decode ? chunk_estimate.load() : frame_bytes;
-                        A.over_at = (size_t)batch * A.slot_bytes;
-                        const size_t over = gpu_decode ? std::max((size_t)batch * A.slot_bytes / 4, std::min(3 * A.slot_bytes, frame_bytes + 4096)) : 0;
-                        void* v = nullptr;
-                        ok = ok && ffs_stream_reserve_host(A.s, A.over_at + over) == FFS_OK
-                             && ffs_stream_host_buffer(A.s, &v, &A.host_bytes) == FFS_OK;
-                        A.host = static_cast<uint8_t*>(v);
+                        if (!ensure_assembly(G, A, (uint32_t)(q % K), thread_id)) break;
                         lock.lock();
-                        if (!ok) { lock.unlock(); fail("", ctx); break; }
-                        A.ready = true;
-                        G.cv.notify_all();
-                        if (args.verbose) {
-                            std::lock_guard<std::mutex> pl(print_mutex);
-                            std::printf("Thread %2d: assembly %llu of GPU %d ready (stream %.1f ms, %.0f MB of staging %.1f ms) %.0f ms after the start\n", thread_id,
-                                        (unsigned long long)(q % K), devices[di], secs(t_c0, t_c1) * 1e3, A.host_bytes / 1e6, secs(t_c1, now()) * 1e3,
-                                        secs(all_start, now()) * 1e3);
-                        }
                     }
                     else {   // (a batch that went up through the heap may have made the library grow -- and move -- the staging area)
                         void* v = nullptr;
@@ -1074,6 +1103,11 @@ int main(int argc, char** argv) {
             if (!submit_batch(G, A, A.n, first, thread_id)) break;
             ++n_submitted;
             t_submit += secs(t_s0, now());
+            if (args.verbose && b < 5) {
+                std::lock_guard<std::mutex> lock(print_mutex);
+                std::printf("Thread %2d: batch %llu submitted %.1f ms after the start (the call took %.2f ms)\n", thread_id, (unsigned long long)b,
+                            secs(all_start, now()) * 1e3, secs(t_s0, now()) * 1e3);
+            }
         }
         if (args.verbose) {
             std::lock_guard<std::mutex> lock(print_mutex);

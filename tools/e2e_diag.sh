@@ -14,6 +14,6 @@ $B/spotfinder $T/shm --threads 16 --images $N > /dev/null 2>&1      # first pass
 for rep in 1 2; do
 for f in "${sets[@]}"; do
   echo "== $f (rep $rep)"
-  $B/spotfinder $T/shm --threads 16 --images $N -v $f 2>&1 | grep -E "images in|collector|^Thread +[0-9]+: [0-9]+ chunks|assembly .* ready|Workers joined" | sed -e 's/\x1b\[[0-9;]*m//g' | awk '/chunks read/{c++; if (c<=3) print; next} {print}'
+  $B/spotfinder $T/shm --threads 16 --images $N -v $f 2>&1 | grep -E "images in|collector|^Thread +[0-9]+: [0-9]+ chunks|assembly .* ready|Workers joined|submitted" | sed -e 's/\x1b\[[0-9;]*m//g' | awk '/chunks read/{c++; if (c<=3) print; next} {print}'
 done
 done
