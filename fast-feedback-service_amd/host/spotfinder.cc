@@ -461,11 +461,14 @@ int main(int argc, char** argv) {
     // bitshuffle-LZ4 chunks go to the GPU as they are (read straight into the pinned staging area) unless the pixels are
     // needed on the host (--writeout) or --cpu-decode asks for the reference's way
     const bool gpu_decode = reader.get_raw_chunk_compression() == Reader::BITSHUFFLE_LZ4 && !args.cpu_decode && !args.writeout;
-    // frames per GPU batch: chunks -- 16 (120 MB of staging per batch for Eiger-16M: the threshold kernels are tuned for 16-32
-    // frames and PCIe, not the GPU, is the limit); decoded frames are five times larger: 4.  Never more than half the data set per GPU.
+    // frames per GPU batch.  Chunks: 16 for long runs (120 MB of staging per batch for Eiger-16M: the threshold kernels are tuned
+    // for 16-32 frames and PCIe, not the GPU, is the limit), 8 for runs below 2048 images per GPU -- a stream's device buffers
+    // (37 MB per frame of the batch) are prepared by the driver on FIRST USE at ~60 GB/s, so four assemblies of 16 frames cost a
+    // run its first 40 ms, of 8 frames 20 ms (1000 frames: 6.0 k frames/s against 5.2-5.5 k).  Decoded frames are five times
+    // larger: 4.  Never more than half the data set per GPU.
     const uint32_t n_dev_arg = (uint32_t)std::max<size_t>(1, args.devices.size());
-    const uint32_t batch = args.batch ? args.batch
-                                      : std::max<uint32_t>(1, std::min<uint32_t>(gpu_decode ? 16u : 4u, num_images / (2 * n_dev_arg)));
+    const uint32_t batch_dflt = !gpu_decode ? 4u : (num_images >= 2048u * n_dev_arg ? 16u : 8u);
+    const uint32_t batch = args.batch ? args.batch : std::max<uint32_t>(1, std::min<uint32_t>(batch_dflt, num_images / (2 * n_dev_arg)));
     std::printf("Image:       %4u x %4u = %u px\n", width, height, width * height);
     std::printf("GPU batches: %u frames per submit, filled by all readers of a GPU; %s\n", batch,
                 args.single_buffer ? "one batch in flight" : (gpu_decode ? "four batches in flight per GPU" : "three batches in flight per GPU"));
