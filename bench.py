@@ -669,6 +669,9 @@ def main():
     ap.add_argument("--no-cli-e2e", action="store_true",
                     help="skip the end-to-end leg of the drop-in binary (bin/spotfinder on a 1000-frame Eiger-stream directory)")
     ap.add_argument("--cli-images", type=int, default=1000)
+    ap.add_argument("--cli-long-images", type=int, default=4096,
+                    help="images of the long end-to-end run (every image a 7.5 MB file in /dev/shm: 30 GB of tmpfs for 4096); 0 skips it; "
+                         "shrunk by itself when the file system or the memory cgroup has not the room")
     ap.add_argument("--single-process", action="store_true",
                     help="--gpus N driven from ONE process: a context and a host thread per GPU behind ffs_multi_init "
                          "(the C++ driver's model) instead of one rank per GPU")
@@ -694,7 +697,7 @@ def main():
     e2e = None
     if (world == 1 and rank == 0 and not args.no_cli_e2e and args.workload == "eiger16m"
             and args.algorithm == "dispersion"):
-        e2e = cli_e2e(n_images=args.cli_images)
+        e2e = cli_e2e(n_images=args.cli_images, long_images=args.cli_long_images)
 
     import torch
     if world > 1 and torch.cuda.device_count() <= local_rank:
