@@ -14,8 +14,10 @@ WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), relays rank 0's one JSON li
 exits with the worst child's code -- without ever touching the GPU in the launching process.
 Under torch.distributed.run it is a rank as before.  Every rank processes its own shard of
 the frame queue (weak scaling; frames are independent, spotfinder/spotfinder.cc:686,752) and
-the per-frame spot lists are gathered to every rank with one RCCL collective per
-`--gather-every` batches.  `--single-process` drives the N GPUs from ONE process instead --
+the per-frame spot lists are gathered to rank 0 once per `--gather-every` batches: an
+all_gather of the ranks' row counts, then exactly the written rows by RCCL send / recv
+(`--gather padded`: round 3's all_gather of fixed-size blocks to every rank, for A/B).
+Every batch waited for is checked against committed oracle results ("results_checked").  `--single-process` drives the N GPUs from ONE process instead --
 one context and one host thread per GPU behind ffs_multi_init, the C++ driver's model
 (`spotfinder --gpus N`) -- so both designs get a curve.
 
