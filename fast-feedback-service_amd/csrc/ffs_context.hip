@@ -155,11 +155,73 @@ extern "C" int ffs_ctx_create(int device, uint32_t width, uint32_t height, int p
     return FFS_OK;
 }
 
+// ---- helper threads of ffs_wait's result assembly (ffs_internal.hpp) ---------------------------------------------------
+void AssemblyPool::start(int n_threads) {
+    for (int t = 0; t < n_threads; ++t)
+        threads.emplace_back([this] {
+            uint64_t seen = 0;
+            for (;;) {
+                const std::function<void(uint32_t)>* fn = nullptr;
+                uint32_t n = 0;
+                {
+                    std::unique_lock<std::mutex> lock(mu);
+                    cv.wait(lock, [&] { return stop || generation != seen; });
+                    if (stop) return;
+                    seen = generation;
+                    fn = job;
+                    n = n_items;
+                    if (fn) active.fetch_add(1);   // (under the lock: run() clears `job` under it before it waits for `active`)
+                }
+                if (!fn) continue;
+                for (;;) {
+                    const uint32_t i = next.fetch_add(1);
+                    if (i >= n) break;
+                    (*fn)(i);
+                    done.fetch_add(1, std::memory_order_release);
+                }
+                active.fetch_sub(1, std::memory_order_release);
+            }
+        });
+}
+void AssemblyPool::run(uint32_t n, const std::function<void(uint32_t)>& fn) {
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        job = &fn;
+        n_items = n;
+        next.store(0);
+        done.store(0);
+        ++generation;
+    }
+    cv.notify_all();
+    for (;;) {   // the caller works too: with sleepy helpers this is the whole job at the speed of one thread
+        const uint32_t i = next.fetch_add(1);
+        if (i >= n) break;
+        fn(i);
+        done.fetch_add(1, std::memory_order_release);
+    }
+    while (done.load(std::memory_order_acquire) < n) __builtin_ia32_pause();   // (the helpers' last items: microseconds)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        job = nullptr;      // a helper that wakes late finds no job ...
+    }
+    while (active.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();   // ... and those that took this one have left it: `fn` may go
+}
+AssemblyPool::~AssemblyPool() {
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        stop = true;
+    }
+    cv.notify_all();
+    for (auto& t : threads) t.join();
+}
+
 extern "C" void ffs_ctx_destroy(ffs_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (auto* st : c->stack_pool) stack3d_free(st);
     c->stack_pool.clear();
+    delete c->assembly;
+    c->assembly = nullptr;
     if (c->d_maskbits) (void)hipFree(c->d_maskbits);
     if (c->d_ginfo) (void)hipFree(c->d_ginfo);
     if (c->d_mmap) (void)hipFree(c->d_mmap);

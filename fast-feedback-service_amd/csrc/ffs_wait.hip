@@ -204,47 +204,66 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
     // (written through raw pointers into arrays sized for the worst case: 45 000 records per batch of the bench frames, and the
     // last wait of a run does this on the clock -- push_back's capacity check per record was a third of it)
     s->results.assign(n, ffs_frame_result{});
-    size_t extra = 0;
-    for (const OverflowFrame& o : s->ovf) extra += o.boxes.size();
-    s->boxes.resize(total_recs + extra);
-    if (p.want_reflections) s->refls.resize(total_recs + extra); else s->refls.clear();
-    // the centres as (frame id, x, y, z) rows, written while each record is in hand: ffs_stream_spot_centres hands them out with one
-    // memcpy (walking the 72-byte reflections again cost a caller 0.3 ms per batch of 45 000 -- as long as the GPU takes for the batch)
-    s->centres.resize(p.want_reflections ? (total_recs + extra) * 4 : 0);
-    float* co = s->centres.data();
-    std::vector<size_t> box_at(n), refl_at(n);
-    ffs_box* bo = s->boxes.data();
-    ffs_reflection* ro = s->refls.data();
-    size_t nbx = 0, nrf = 0;
     const uint32_t min_size = p.min_spot_size;
     const bool want_refl = p.want_reflections != 0;
-    const WireRec2* wrec = reinterpret_cast<const WireRec2*>(s->h_recs);
-    for (uint32_t f = 0; f < n; ++f) {
-        box_at[f] = nbx;
-        refl_at[f] = nrf;
-        const uint32_t nc = std::min<uint32_t>(h_nc[f], s->max_comp);
-        if (s->chain_mode) wrec = reinterpret_cast<const WireRec2*>(s->h_recs) + (size_t)f * s->max_comp;  // k_frame_chain: every frame has its own record area
-        if (const OverflowFrame* o = overflow_frame(f)) {  // re-run on the one-frame stream: skip the cut records
-            wrec += nc;
-            for (const ffs_box& b : o->boxes) bo[nbx++] = b;
-            if (want_refl) {
-                const uint32_t idb = (uint32_t)((uint64_t)(s->first_id + f) & 0xFFFFFFFFull);
-                float idf;
-                std::memcpy(&idf, &idb, 4);
-                for (const ffs_reflection& r : o->refls) {
-                    co[4 * nrf] = idf; co[4 * nrf + 1] = r.com_x; co[4 * nrf + 2] = r.com_y; co[4 * nrf + 3] = r.com_z;
-                    ro[nrf++] = r;
-                }
+    // Where each frame's boxes / reflections / records lie follows from the per-frame summaries the sparse stage wrote (boxes =
+    // summary[0], reflections = summary[2]; a frame that was re-run on the one-frame stream: what that run returned), so the
+    // frames can be assembled independently -- by the caller and the context's helper threads (AssemblyPool) when the batch is large.
+    std::vector<size_t> box_at(n + 1), refl_at(n + 1), rec_at(n);
+    {
+        size_t nb = 0, nr = 0, at = 0;
+        for (uint32_t f = 0; f < n; ++f) {
+            box_at[f] = nb;
+            refl_at[f] = nr;
+            const uint32_t nc = std::min<uint32_t>(h_nc[f], s->max_comp);
+            rec_at[f] = s->chain_mode ? (size_t)f * s->max_comp : at;   // k_frame_chain: every frame has its own record area
+            at += nc;
+            if (const OverflowFrame* o = overflow_frame(f)) {
+                nb += o->boxes.size();
+                nr += want_refl ? o->refls.size() : 0;
+            } else {
+                nb += h_sm[(size_t)f * 8 + 0];
+                nr += want_refl ? h_sm[(size_t)f * 8 + 2] : 0;
             }
-            continue;
         }
+        box_at[n] = nb;
+        refl_at[n] = nr;
+    }
+    s->boxes.resize(box_at[n]);
+    s->refls.resize(refl_at[n]);
+    // the centres as (frame id, x, y, z) rows, written while each record is in hand: ffs_stream_spot_centres hands them out with one
+    // memcpy (walking the 72-byte reflections again cost a caller 0.3 ms per batch of 45 000 -- as long as the GPU takes for the batch)
+    s->centres.resize(refl_at[n] * 4);
+    ffs_box* const bo = s->boxes.data();
+    ffs_reflection* const ro = s->refls.data();
+    float* const co = s->centres.data();
+    const WireRec2* const recs0 = reinterpret_cast<const WireRec2*>(s->h_recs);
+    std::atomic<bool> consistent{true};
+    const std::function<void(uint32_t)> assemble = [&](uint32_t f) {
+        size_t nbx = box_at[f], nrf = refl_at[f];
         const uint32_t id_bits = (uint32_t)((uint64_t)(s->first_id + f) & 0xFFFFFFFFull);   // (a bit pattern: as a float VALUE ids collide from 2^24 on)
         float id_lane;
         std::memcpy(&id_lane, &id_bits, 4);
+        if (const OverflowFrame* o = overflow_frame(f)) {  // re-run on the one-frame stream: its cut records are skipped
+            for (const ffs_box& b : o->boxes) bo[nbx++] = b;
+            if (want_refl)
+                for (const ffs_reflection& r : o->refls) {
+                    co[4 * nrf] = id_lane; co[4 * nrf + 1] = r.com_x; co[4 * nrf + 2] = r.com_y; co[4 * nrf + 3] = r.com_z;
+                    ro[nrf++] = r;
+                }
+            return;
+        }
+        const uint32_t nc = std::min<uint32_t>(h_nc[f], s->max_comp);
+        const WireRec2* wrec = recs0 + rec_at[f];
+        const size_t box_end = box_at[f + 1], refl_end = refl_at[f + 1];
         for (uint32_t q = 0; q < nc; ++q, ++wrec) {
             const uint32_t npx = wrec->npx_flags & 0x3FFFFFFFu, flags = wrec->npx_flags >> 30;
-            if (min_size == 0 || npx >= min_size) bo[nbx++] = ffs_box{wrec->x_min, wrec->y_min, wrec->x_max, wrec->y_max, (int32_t)npx};
+            if (min_size == 0 || npx >= min_size) {
+                if (nbx >= box_end) { consistent = false; return; }   // (never: the summary counts what this loop counts)
+                bo[nbx++] = ffs_box{wrec->x_min, wrec->y_min, wrec->x_max, wrec->y_max, (int32_t)npx};
+            }
             if (want_refl && flags == 0) {
+                if (nrf >= refl_end) { consistent = false; return; }
                 ffs_reflection r{};
                 r.x_min = wrec->x_min; r.x_max = wrec->x_max; r.y_min = wrec->y_min; r.y_max = wrec->y_max;
                 r.z_min = 0; r.z_max = 0;
@@ -259,9 +278,31 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
                 ro[nrf++] = r;
             }
         }
+        if (nbx != box_end || nrf != refl_end) consistent = false;
+    };
+    // assemble: boxes = components surviving the min-size filter (connected_components.cc:122-135),
+    // reflections = components surviving filter_reflections (:207-236); both keep label order.
+    bool pooled = false;
+    if (total_recs >= 8192 && n >= 4) {
+        if (!c->assembly) {
+            std::lock_guard<std::mutex> lock(c->stream_mu);
+            if (!c->assembly) {
+                AssemblyPool* pool = new (std::nothrow) AssemblyPool();
+                if (pool) { pool->start(3); c->assembly = pool; }
+            }
+        }
+        if (c->assembly && c->assembly->owner.try_lock()) {   // (another stream's wait has the helpers: assemble here)
+            c->assembly->run(n, assemble);
+            c->assembly->owner.unlock();
+            pooled = true;
+        }
     }
-    s->boxes.resize(nbx);
-    if (want_refl) { s->refls.resize(nrf); s->centres.resize(nrf * 4); }
+    if (!pooled)
+        for (uint32_t f = 0; f < n; ++f) assemble(f);
+    if (!consistent.load()) {
+        c->err = "ffs_wait: the records of a frame do not match its summary counts";
+        return FFS_ERR_DEVICE;
+    }
     for (uint32_t f = 0; f < n; ++f) {
         ffs_frame_result& r = s->results[f];
         const uint32_t* sm = h_sm + (size_t)f * 8;

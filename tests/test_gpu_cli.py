@@ -503,7 +503,7 @@ def test_data_set_that_ends_early_reports_every_image_that_was_read(tmp_path):
     for argv in (["--threads", "3", "--batch", "3"], ["--threads", "2", "--batch", "4", "--cpu-decode"]):
         rc, out, err, lines = run_with_pipe([str(shm), "--timeout", "1.5", *argv], tmp_path)
         assert rc == 0 and not err, (out, err)
-        assert "Timeout waiting for image 8" in out
+        assert re.search(r"Timeout waiting for image (8|9|10)\b", out)   # (whichever reader's patience runs out first says so)
         got = [json.loads(l) for l in lines]
         assert [j["file-number"] for j in got] == list(range(N_have))
         exp = _oracle_counts(frames, np.ones((H, W), np.uint8))
