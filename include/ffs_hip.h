@@ -231,6 +231,8 @@ int ffs_submit_compressed(ffs_stream *s, const void *const *chunks, const size_t
 int ffs_decode_only(ffs_stream *s, const void *const *chunks, const size_t *chunk_bytes,
                     uint32_t n_frames, uint32_t iters, float *ms_decode, void *host_out);
 
+/* (ffs_wait turns the batch's records into the arrays below; for large batches the frames are spread over the calling thread and
+ * three helper threads that belong to the context -- created on first use, joined by ffs_ctx_destroy.) */
 int ffs_wait(ffs_stream *s, const ffs_frame_result **results, uint32_t *n_results);
 
 /* The whole batch's boxes and reflections as two contiguous arrays (frame i's slice starts
