@@ -410,7 +410,10 @@ def cli_e2e(n_images=1000, threads=None, batch=None, cpu_decode_images=256, keep
         # write() moves every page to the active list, one lock for all readers: 12-24 GB/s per host whatever reads
         # (tools/ubench/cold_read.cc) -- the later passes are what the driver itself can do
         out["first_pass_over_fresh_files"] = run([], n_images)
-        gpu = run([], n_images)
+        # (a 1000-image run lasts 0.17 s: one run moves +-8 % with whatever else the host's memory system is doing -- the median of three)
+        runs = [run([], n_images) for _ in range(3)]
+        good = sorted((r for r in runs if "frames_per_s" in r), key=lambda r: r["frames_per_s"])
+        gpu = dict(good[len(good) // 2], runs_frames_per_s=[r.get("frames_per_s") for r in runs], value_from="median of three runs") if good else runs[0]
         out["gpu_decode"] = gpu
         out["frames_per_s"] = gpu.get("frames_per_s")
         out["cpu_decode"] = run(["--cpu-decode"], min(n_images, cpu_decode_images))
