@@ -363,6 +363,14 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     (void)hipSetDevice(s->ctx->device);
     if (s->job.joinable()) s->job.join();
     mark_idle(s);   // (a stream may be closed with its batch still in flight)
+#ifdef FFS_EXPERIMENTS
+    if (s->phase_n) {
+        const double k = 1.0 / (double)s->phase_n;
+        std::fprintf(stderr, "[ffs exp] sparse launch, %llu frames: init %.1f | L1 / E %.1f | S + L2 %.1f | X U %.1f | P %.1f | R %.1f | whole %.1f us per frame\n",
+                     s->phase_n, s->phase_sum[0] * k, s->phase_sum[1] * k, s->phase_sum[2] * k, s->phase_sum[3] * k, s->phase_sum[4] * k, s->phase_sum[5] * k, s->phase_sum[6] * k);
+    }
+    if (s->h_phase_ts) (void)hipHostFree(s->h_phase_ts);
+#endif
     if (s->big) ffs_stream_destroy(s->big);
     if (s->st_up && s->st_up != s->st) (void)hipStreamSynchronize(s->st_up);
     if (s->st) (void)hipStreamSynchronize(s->st);

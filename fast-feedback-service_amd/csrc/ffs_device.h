@@ -8,7 +8,10 @@
 #ifdef FFS_EXPERIMENTS
 #define FFS_DBG(args, bit) (((args).dbg & (bit)) != 0)
 #define FFS_STOP_AFTER(A, phase) if ((A).stop_after == (phase)) return
+// (experiments) device timestamps at the phase boundaries of the sparse launch, one set per frame: tools/chain_phase_times.sh
+#define FFS_PHASE_TS(A, idx) do { if ((A).phase_ts && threadIdx.x == 0) (A).phase_ts[(size_t)blockIdx.x * 8 + (idx)] = wall_clock64(); } while (0)
 #else
+#define FFS_PHASE_TS(A, idx) do {} while (0)
 #define FFS_DBG(args, bit) false
 #define FFS_STOP_AFTER(A, phase) do {} while (0)
 #endif

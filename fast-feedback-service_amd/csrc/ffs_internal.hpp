@@ -264,6 +264,11 @@ struct ffs_stream {
     std::vector<ffs_frame_result> results;
     std::vector<ffs_box> boxes;
     std::vector<ffs_reflection> refls;
+#ifdef FFS_EXPERIMENTS
+    unsigned long long *h_phase_ts = nullptr, *h_phase_ts_dev = nullptr;   // device timestamps of the sparse launch's phases (pinned, [B][8])
+    double phase_sum[8] = {};       // accumulated phase durations, us (printed when the stream is destroyed; FFS_EXP_CHAIN_TS)
+    unsigned long long phase_n = 0;
+#endif
     std::vector<float> centres;   // (frame id bits, com_x, com_y, com_z) per reflection of the last batch, filled with `refls` (ffs_stream_spot_centres)
 };
 

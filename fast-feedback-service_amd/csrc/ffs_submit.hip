@@ -500,6 +500,13 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
         A.rec_stride = s->max_comp;
 #ifdef FFS_EXPERIMENTS
         A.stop_after = c->tune.exp.chain_stop;
+        if (std::getenv("FFS_EXP_CHAIN_TS")) {
+            if (!s->h_phase_ts && hipHostMalloc(reinterpret_cast<void**>(&s->h_phase_ts), (size_t)s->max_batch * 64, hipHostMallocDefault) == hipSuccess) {
+                std::memset(s->h_phase_ts, 0, (size_t)s->max_batch * 64);
+                (void)hipHostGetDevicePointer(reinterpret_cast<void**>(&s->h_phase_ts_dev), s->h_phase_ts, 0);
+            }
+            A.phase_ts = s->h_phase_ts_dev;
+        }
 #endif
         A.t = ta_launch;
         A.fix_bright = (chain_first && !use_log) ? 1 : 0;

@@ -44,6 +44,17 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
         for (uint32_t f = 0; f < n; ++f) overflow |= s->h_counts[10 * B + 1 + f];
     }
     mark_idle(s);
+#ifdef FFS_EXPERIMENTS
+    if (s->h_phase_ts && s->chain_mode) {   // phase durations of this batch's sparse launch, averaged over its frames (100 MHz counter)
+        for (uint32_t f = 0; f < n; ++f) {
+            const unsigned long long* t = s->h_phase_ts + (size_t)f * 8;
+            if (t[6] <= t[0]) continue;
+            for (int k = 0; k < 6; ++k) s->phase_sum[k] += (double)(t[k + 1] - t[k]) * 0.01;
+            s->phase_sum[6] += (double)(t[6] - t[0]) * 0.01;
+            ++s->phase_n;
+        }
+    }
+#endif
     s->ovf.clear();
     if (overflow) {
         s->bits_dirty = true;

@@ -120,6 +120,7 @@ struct ChainArgs {
     uint32_t* fix_done;     // workgroups through with the bright list (the last one zeroes the list's count)
     int stop_after;         // (timing experiments) 1..4: return after phase A / E / U / P
     int runs_ok;            // 1: frames beyond kChainLdsEntries strong pixels take the run-based phases (16-bit pixels, W <= kChainRunMaxW); 2: every frame
+    unsigned long long* phase_ts;   // (timing experiments) [frames][8] device timestamps at the phase boundaries, or null
 };
 
 __device__ __forceinline__ void chain_record(const SegArgs& sa, uint32_t W, uint32_t num_pixels, unsigned long long sum_i,
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
     __shared__ uint32_t s_lst[kChainWaves][16];   // LOG: per chain wave, where each strip's entries start in the band's row of entries
 
     const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    FFS_PHASE_TS(A, 0);
     const int n_tiles = a.n_tiles;
     const uint32_t W = (uint32_t)a.W, H = (uint32_t)a.H;
     const int dpr = a.mpitch >> 2;
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
     uint32_t run_flag = 0;   // 16: more runs than the LDS plan holds; 32: a wave log (or the list of undecided pixels) overflowed; 64: a frame beyond
                              // the LDS forest met in the wave logs (the host runs the batch again another way)
     FFS_STOP_AFTER(A, 1);
+    FFS_PHASE_TS(A, 1);
 
     uint32_t* gk = a.list_k + (uint64_t)frame * a.cap;
     uint32_t* gi = a.list_i + (uint64_t)frame * a.cap;
@@ -630,6 +633,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
     }
     __syncthreads();
     FFS_STOP_AFTER(A, 2);
+    FFS_PHASE_TS(A, 2);
 
     // ---- S: per-row counts -> list offset of the first strong pixel of every row (and of "row H" = n) ------
     {
@@ -763,6 +767,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
         if (run_flag) n = 0;   // (nothing was placed: the phases below have nothing to do)
         __syncthreads();
         FFS_STOP_AFTER(A, 5);
+        FFS_PHASE_TS(A, 3);
     }
 
     WireRec2* recs = reinterpret_cast<WireRec2*>(sa.recs) + (uint64_t)frame * A.rec_stride;
@@ -837,6 +842,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
         }
         __syncthreads();
         FFS_STOP_AFTER(A, 3);
+        FFS_PHASE_TS(A, 4);
 
         // ---- P: pixel values; roots, numbered in list order ---------------------------------------------------------
         // This thread's entries stay in registers through phase R: k, intensity and a 16-bit id (first the root's list
@@ -911,6 +917,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
             if (i0 + q < i1) set_id(q, spar[get_id(q)]);
         __syncthreads();   // the forest is dead from here on: its LDS becomes accumulators + record staging
         FFS_STOP_AFTER(A, 4);
+        FFS_PHASE_TS(A, 5);
 
         // ---- R: kChainSlots components at a time --------------------------------------------------------------
         ChainAcc* s_acc = reinterpret_cast<ChainAcc*>(s_big);
@@ -1217,6 +1224,7 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
         a.num_strong[frame] = total;
         a.n_comp[frame] = before;
         const size_t B = A.max_batch;
+        FFS_PHASE_TS(A, 6);
         A.h_counts[frame] = total;
         A.h_counts[B + frame] = before;
         A.h_counts[10 * B + 1 + frame] = flags;
