@@ -23,7 +23,10 @@ extern "C" int ffs_bench_threshold(ffs_stream* s, const void* device_pixels, siz
         rc = ensure_extended_buffers(s);
         if (rc != FFS_OK) return rc;
     }
+    s->ext_e_clean = false;
     ThresholdArgs ta = make_threshold_args(s, device_pixels, pitch, fstride, n_frames);
+    const bool e_sparse = ext && c->tune.ext_erode != 0 && c->tune.ext_e_sparse;   // (the hot path clears the signal-region plane behind the previous batch)
+    ta.eplane_clean = e_sparse ? 1 : 0;
     if (!ext) (void)wave_logs_for(s, ta, n_frames);   // (the kernel as the hot path launches it)
     const Layout& L = c->L;
     std::vector<hipEvent_t> ev(4 * (size_t)iters, nullptr);
@@ -41,6 +44,7 @@ extern "C" int ffs_bench_threshold(ffs_stream* s, const void* device_pixels, siz
         err = hipMemsetAsync(s->d_bits, 0, (size_t)s->max_batch * L.plane_frame_stride, s->st);
         if (err == hipSuccess) err = hipMemsetAsync(s->d_tile_counts, 0, tile_counts_bytes(s), s->st);
         if (err == hipSuccess) err = hipMemsetAsync(s->d_occ, 0, (size_t)s->max_batch * occ_frame_words(L) * 4, s->st);
+        if (err == hipSuccess && e_sparse) err = hipMemsetAsync(s->d_eplane, 0, (size_t)s->max_batch * L.plane_frame_stride, s->st);
         if (err != hipSuccess) break;
         bench_launch_dense(s, ta, n_frames, ev[4 * i], ev[4 * i + 1]);
         err = hipEventRecord(ev[4 * i + 2], s->st);

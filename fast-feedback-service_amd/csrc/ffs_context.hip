@@ -341,6 +341,8 @@ extern "C" int ffs_ctx_set_tuning(ffs_ctx* c, const char* key, long long value) 
     else if (k == "direct_records") { if ((ok = in(0, 1) && c->n_streams_made == 0)) t.direct_records = (int)value; }
     else if (k == "decode_in_dense_stream") { if ((ok = in(0, 1))) t.decode_in_dense_stream = (int)value; }
     else if (k == "ext_fused") { if ((ok = in(0, 1))) t.ext_fused = (int)value; }
+    else if (k == "ext_erode") { if ((ok = in(0, 2))) t.ext_erode = (int)value; }
+    else if (k == "ext_e_sparse") { if ((ok = in(0, 1))) t.ext_e_sparse = (int)value; }
     else if (k == "ext_rest_aside") { if ((ok = in(0, 1))) t.ext_rest_aside = (int)value; }
     else if (k == "band_taper") { if ((ok = in(0, 99))) t.band_taper = (int)value; }
     else if (k == "rows_ahead") { if ((ok = in(2, 4))) t.rows_ahead = (int)value; }
@@ -378,7 +380,7 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     // (d_n_comp, d_summary and d_overflow live inside the d_num_strong allocation)
     if (s->h_pack_tab) (void)hipHostFree(s->h_pack_tab);
     // (the stream's device buffers are one slab; what is allocated on first use is freed by itself)
-    void* dev[] = {s->d_slab, s->d_pack_k, s->d_pack_i, s->d_pack_tab, s->d_comp, s->d_tab, s->d_dplane, s->d_dplane2, s->d_eplane, s->d_wlog, s->d_wlog_n, s->d_wpix};
+    void* dev[] = {s->d_slab, s->d_pack_k, s->d_pack_i, s->d_pack_tab, s->d_comp, s->d_tab, s->d_ext_pair[0], s->d_ext_pair[1], s->d_wlog, s->d_wlog_n, s->d_wpix};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     void* host[] = {s->h_tab, s->h_counts, s->h_recs, s->h_list_k, s->h_list_i, s->h_mask};

@@ -85,6 +85,7 @@ struct ThresholdArgs {
     // extended dispersion (kernels_extended.hpp)
     uint8_t* dplane;           // first-pass "not background" bit planes [n][H][mpitch]
     uint8_t* eplane;           // eroded signal-region bit planes [n][H][mpitch]
+    int eplane_clean;          // the signal-region plane is all zero (cleared behind the previous batch): the erosion stores its non-zero words only
     int ext_strips, ext_band_rows, ext_bands;
     int ext_flavour;           // 0 = baseline.cpp rules, 1 = device-kernel rules
     int ext_variant;           // first pass, 16-bit pixels: 2 = streaming kernel (k_stream_u16<true>), 0 = k_ext_first

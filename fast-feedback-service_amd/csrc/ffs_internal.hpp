@@ -72,6 +72,10 @@ struct Tuning {
     int direct_records = 1;     // records and counters are written straight into pinned host memory
     int decode_in_dense_stream = 1;   // the decode kernel runs in the dense kernels' stream (0: in the upload stream)
     int ccl_grid = 32;          // workgroups per frame of the grid-wide sparse kernels
+    int ext_erode = 2;          // extended algorithm, erosion: 0 = k_ext_erode (a lane per word column, three loads per row), 1 / 2 = k_ext_erode_strips
+                                //    (a wave per 62 word columns and 32 / 16 rows, one load per row, neighbours by DPP; non-zero words only
+                                //    when the plane was cleared behind the previous batch)
+    int ext_e_sparse = 0;       // ... 1 = the signal-region plane is cleared behind the previous batch and the strip erosion stores its non-zero words only
     int ext_fused = 0;          // extended algorithm, 16-bit pixels: 1 = erosion fused into the final pass's tiles (k_ext_erode_final: one launch, the plane
                                 //    crosses memory once); 0 = k_ext_erode + k_ext_final.  Measured round 4: the fused kernel is SLOWER (threshold stage 0.65
                                 //    against 0.55 ms per 32 frames, profiles/r04d_ext_fused_ab.txt): every tile starts with a chain of dependent plane loads
@@ -209,8 +213,14 @@ struct ffs_stream {
     // turns: the one the previous batch used is cleared in the sparse stream behind this batch's sparse launch -- done before
     // this batch's last event, i.e. before the stream's next submit -- instead of by a fill in the dense stream ahead of every
     // first pass; the last batch's plane stays readable (ffs_stream_debug_bitplane, --writeout).
+    // Round 4: the signal-region plane has a twin too (the erosion then stores only the words that hold a pixel of the region); a
+    // first-pass plane and a signal-region plane are ONE allocation (d_ext_pair), so one fill clears both.
     uint8_t* d_dplane2 = nullptr;
-    bool dplane2_clean = false;                        // the plane the NEXT batch takes is zero
+    uint8_t* d_eplane2 = nullptr;
+    uint8_t* d_ext_pair[2] = {nullptr, nullptr};
+    bool dplane2_clean = false;                        // the first-pass plane the NEXT batch takes is zero
+    bool eplane2_clean = false;                        // ... and so is the signal-region plane behind it
+    bool ext_e_clean = false;                          // this batch's signal-region plane is zero (make_threshold_args passes it on)
     uint8_t* d_comp = nullptr;                         // compressed chunks (allocated on first use)
     uint2 *d_tab = nullptr, *h_tab = nullptr;          // per-block (offset, length) tables
     uint32_t dec_blocks = 0, dec_last = 0, dec_tail = 0, dec_block_elems = 0;

@@ -125,6 +125,7 @@ ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t pitch, 
     }
     a.dplane = s->d_dplane;
     a.eplane = s->d_eplane;
+    a.eplane_clean = s->ext_e_clean ? 1 : 0;
     a.ext_flavour = p.extended_flavour;
     a.ext_variant = (c->pixel_bytes == 2 && s->force_path < 0) ? c->tune.ext_first_pass : 0;
     a.ext_strips = (L.pitch_px + kExtOwnedPx - 1) / kExtOwnedPx;
@@ -201,8 +202,18 @@ static void launch_ext_rest(ffs_stream* s, const ThresholdArgs& a, uint32_t n_fr
         hipLaunchKernelGGL(k_ext_erode_final, g3, dim3(256), (size_t)(kTileRows + 10) * a.mpitch, st, a);
         return;
     }
-    const unsigned erode_lanes = (a.mpitch / 4) * (unsigned)((a.H + kErodeRows - 1) / kErodeRows);
-    hipLaunchKernelGGL(k_ext_erode, dim3((erode_lanes + 255) / 256, n_frames), dim3(256), 0, st, a);
+    const int erode = s->ctx->tune.ext_erode;
+    if (erode != 0) {
+        const unsigned strips = (a.mpitch / 4 + 61) / 62, rows = erode == 1 ? 32 : 16;
+        const dim3 ge(strips * 8u * (((unsigned)((a.H + rows - 1) / rows) + 7u) / 8u), n_frames);
+        if (erode == 1 && a.eplane_clean) hipLaunchKernelGGL((k_ext_erode_strips<32, true>), ge, dim3(64), 0, st, a);
+        else if (erode == 1) hipLaunchKernelGGL((k_ext_erode_strips<32, false>), ge, dim3(64), 0, st, a);
+        else if (a.eplane_clean) hipLaunchKernelGGL((k_ext_erode_strips<16, true>), ge, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_ext_erode_strips<16, false>), ge, dim3(64), 0, st, a);
+    } else {
+        const unsigned erode_lanes = (a.mpitch / 4) * (unsigned)((a.H + kErodeRows - 1) / kErodeRows);
+        hipLaunchKernelGGL(k_ext_erode, dim3((erode_lanes + 255) / 256, n_frames), dim3(256), 0, st, a);
+    }
     if (u16) hipLaunchKernelGGL(k_ext_final<uint16_t>, g3, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_ext_final<uint32_t>, g3, dim3(256), 0, st, a);
 }
@@ -212,11 +223,15 @@ int ensure_extended_buffers(ffs_stream* s) {
     ffs_ctx* c = s->ctx;
     const size_t bytes = (size_t)s->max_batch * c->L.plane_frame_stride;
     s->dplane2_clean = false;
-    if (dmalloc(&s->d_dplane, bytes) != hipSuccess || dmalloc(&s->d_dplane2, bytes) != hipSuccess || dmalloc(&s->d_eplane, bytes) != hipSuccess) {
+    if (dmalloc(&s->d_ext_pair[0], 2 * bytes) != hipSuccess || dmalloc(&s->d_ext_pair[1], 2 * bytes) != hipSuccess) {
         (void)hipGetLastError();
         c->err = "hipMalloc(extended dispersion planes) failed";
         return FFS_ERR_NOMEM;
     }
+    s->d_dplane = s->d_ext_pair[0];
+    s->d_eplane = s->d_ext_pair[0] + bytes;
+    s->d_dplane2 = s->d_ext_pair[1];
+    s->d_eplane2 = s->d_ext_pair[1] + bytes;
     return FFS_OK;
 }
 
@@ -318,9 +333,14 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
     if (ext) {
         const int rc = ensure_extended_buffers(s);
         if (rc != FFS_OK) return rc;
-        std::swap(s->d_dplane, s->d_dplane2);   // this batch's plane: the one cleared behind the previous batch (d_dplane2 keeps that batch's)
+        std::swap(s->d_dplane, s->d_dplane2);   // this batch's planes: the ones cleared behind the previous batch (d_dplane2 / d_eplane2 keep that batch's)
+        std::swap(s->d_eplane, s->d_eplane2);
         ext_plane_clean = s->dplane2_clean;
+        s->ext_e_clean = s->dplane2_clean && s->eplane2_clean && c->tune.ext_erode != 0 && c->tune.ext_e_sparse;
         s->dplane2_clean = false;
+        s->eplane2_clean = false;
+    } else {
+        s->ext_e_clean = false;
     }
     const bool counts_were_clean = !s->counts_dirty;
     const ThresholdArgs ta = make_threshold_args(s, d_img, pitch, fstride, n);
@@ -526,8 +546,10 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
         HIP_TRY(c, hipGetLastError());
         if (ext && ext_stream_first(ta) && s->st2 != s->st) {
             // the plane the previous batch used (nobody reads it any more) is cleared here, beside the dense kernels, for the next batch
-            HIP_TRY(c, hipMemsetAsync(s->d_dplane2, 0, (size_t)s->max_batch * L.plane_frame_stride, s->st2));
+            // (with the strip erosion the signal-region plane behind it too: one fill, the two are one allocation)
+            HIP_TRY(c, hipMemsetAsync(s->d_dplane2, 0, (size_t)s->max_batch * L.plane_frame_stride * (c->tune.ext_erode != 0 && c->tune.ext_e_sparse ? 2u : 1u), s->st2));
             s->dplane2_clean = true;
+            s->eplane2_clean = c->tune.ext_erode != 0 && c->tune.ext_e_sparse;
         }
         HIP_TRY(c, hipEventRecord(s->ev[4], s->st2));
         s->ev3_is_ev4 = true;

@@ -184,6 +184,76 @@ __global__ __launch_bounds__(256) void k_ext_erode(const ThresholdArgs a) {
     }
 }
 
+// X2, round 4: the same erosion with a wave per (62 word columns, band of ROWS rows).  k_ext_erode's lanes fetched three words
+// per row (their own and both neighbours') eight rows at a time: a wave lived through five dependent round trips, 3-4 waves a
+// CU on average (rocprofv3 counters, profiles/r04e_pmc_threshold_eiger16m_extended_b32.json: 0.18 GB in 54 us).  Here a lane
+// fetches ONE word per row -- ROWS + 4 loads, all in flight before the first is used -- and takes its neighbours' words from
+// the lanes beside it (DPP wave shifts; lanes 0 and 63 carry the words of the strips on either side and own no output).
+// SPARSE: the signal-region plane is known to be zero (cleared behind the previous batch, like the first-pass plane), so only
+// the words that hold a pixel of E are stored: a few per cent of them.
+template <int ROWS, bool SPARSE>
+__global__ __launch_bounds__(64) void k_ext_erode_strips(const ThresholdArgs a) {
+    const int dpr = (int)(a.mpitch >> 2);
+    const int n_strips = (dpr + 61) / 62;
+    const int lane = threadIdx.x;
+    // (XCD-aware block map, as the streaming kernels': the strips of a band share lines of the plane, so they share blockIdx % 8)
+    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
+    const int strip = qb % n_strips, band = xcd + 8 * (qb / n_strips);
+    if (band * ROWS >= a.H) return;
+    const int frame = blockIdx.y;
+    const int w = strip * 62 + lane - 1;
+    const bool in_w = w >= 0 && w < dpr;
+    const int y0 = band * ROWS;
+    const uint32_t* __restrict__ dp = reinterpret_cast<const uint32_t*>(a.dplane + (uint64_t)frame * a.plane_frame_stride);
+    const uint32_t* __restrict__ mp = reinterpret_cast<const uint32_t*>(a.maskbits);
+    uint32_t* __restrict__ ep = reinterpret_cast<uint32_t*>(a.eplane + (uint64_t)frame * a.plane_frame_stride);
+    const rsrc_t r_d = make_rsrc(dp, (uint32_t)a.H * a.mpitch);
+    const rsrc_t r_m = make_rsrc(mp, (uint32_t)a.H * a.mpitch);
+    constexpr uint32_t kOob = 0x80000000u;
+    const bool dev_rules = a.ext_flavour == 1;  // masked pixels do not erode either (erosion.cu:101-105)
+    // bits of this word column that lie beyond the image width never erode anything; neither does a column outside the plane
+    const int x0 = w * 32;
+    const uint32_t beyond = !in_w ? ~0u : x0 + 32 > a.W ? (x0 >= a.W ? ~0u : ~((1u << (a.W - x0)) - 1u)) : 0u;
+    uint32_t d[ROWS + 4], m[ROWS + 4];
+#pragma unroll
+    for (int r = 0; r < ROWS + 4; ++r) {
+        const int yy = y0 - 2 + r;
+        const uint32_t off = (in_w && yy >= 0 && yy < a.H) ? (uint32_t)w * 4u : kOob;   // (out of range reads 0)
+        d[r] = __builtin_amdgcn_raw_buffer_load_b32(r_d, off, (uint32_t)max(yy, 0) * a.mpitch, 0);
+        m[r] = ~0u;
+    }
+    if (dev_rules) {   // (uniform)
+#pragma unroll
+        for (int r = 0; r < ROWS + 4; ++r) {
+            const int yy = y0 - 2 + r;
+            const uint32_t off = (in_w && yy >= 0 && yy < a.H) ? (uint32_t)w * 4u : kOob;
+            m[r] = __builtin_amdgcn_raw_buffer_load_b32(r_m, off, (uint32_t)max(yy, 0) * a.mpitch, 0);
+        }
+    }
+    uint32_t h[ROWS + 4];
+#pragma unroll
+    for (int r = 0; r < ROWS + 4; ++r) {
+        const int yy = y0 - 2 + r;
+        uint32_t c = d[r] | beyond | ~m[r];
+        if (yy < 0 || yy >= a.H) c = ~0u;        // rows outside the image never erode (uniform)
+        const uint32_t l = (uint32_t)__builtin_amdgcn_update_dpp((int)~0u, (int)c, 0x138, 0xf, 0xf, false);   // wave_shr:1: lane i <- lane i - 1
+        const uint32_t rr = (uint32_t)__builtin_amdgcn_update_dpp((int)~0u, (int)c, 0x130, 0xf, 0xf, false);  // wave_shl:1: lane i <- lane i + 1
+        h[r] = c & ((c << 1) | (l >> 31)) & ((c << 2) | (l >> 30)) & ((c >> 1) | (rr << 31)) & ((c >> 2) | (rr << 30));
+    }
+    const bool owner = in_w && lane >= 1 && lane <= 62;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int y = y0 + r;
+        if (y >= a.H) break;   // (uniform)
+        const uint32_t e = d[r + 2] & h[r] & h[r + 1] & h[r + 2] & h[r + 3] & h[r + 4];
+        if (owner && (!SPARSE || e != 0u)) ep[(uint64_t)y * dpr + w] = e;
+    }
+}
+template __global__ void k_ext_erode_strips<32, false>(const ThresholdArgs);
+template __global__ void k_ext_erode_strips<32, true>(const ThresholdArgs);
+template __global__ void k_ext_erode_strips<16, false>(const ThresholdArgs);
+template __global__ void k_ext_erode_strips<16, true>(const ThresholdArgs);
+
 // X3 predicate: baseline.cpp:580-645 for one pixel of the signal region E.
 template <typename PixelT>
 __device__ __forceinline__ bool ext_final_strong(const ThresholdArgs& a, const uint8_t* img, const uint32_t* eplane, int e_y0, int x, int y) {

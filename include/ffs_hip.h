@@ -174,6 +174,11 @@ int ffs_ctx_set_params(ffs_ctx *ctx, const ffs_params *p);
  *   "band_taper" (0), "ext_rest_aside" (0), "ext_fused" (0): round 4's A/B partners (tapered bands of the streaming kernels;
  *                          extended algorithm: erosion + final pass in the sparse stream / fused into one kernel) -- measured, no
  *                          gain, off (DESIGN.md sections 3.2c, 4)
+ *   "ext_erode"        (2) extended algorithm, the erosion kernel: 2 / 1 = a wave per 62 word columns of the bit plane and 16 / 32
+ *                          rows (one load per row and lane, all in flight, neighbours' words by DPP, XCD-aware block map), 0 = round 1's
+ *                          kernel (a lane per word column, three loads per row); "ext_e_sparse" (0): 1 = the signal-region plane is
+ *                          cleared behind the previous batch and only its non-zero words are stored (measured: the fill costs the
+ *                          first pass more than the stores cost the erosion)
  * The reference has no counterpart (its launch wrapper has one path, spotfinder/spotfinder.cu:148-189). */
 int ffs_ctx_set_tuning(ffs_ctx *ctx, const char *key, long long value);
 

@@ -27,18 +27,21 @@ CASES = [
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d-%s" % (c["W"], c["H"], np.dtype(c["dtype"]).name))
 @pytest.mark.parametrize("flavour", [0, 1])
-@pytest.mark.parametrize("variant", [2, 0, 3])
+@pytest.mark.parametrize("variant", [2, 0, 3, 4, 5])
 def test_every_stage_matches_oracle(ffs, case, flavour, variant):
     # tuning "ext_first_pass": 2 = the streaming kernel decides the first pass exactly in its drain (16-bit default),
     # 0 = the one-pixel-per-lane first-pass kernel (what 32-bit pixels always use)
     # variant 3: the streaming first pass with the erosion fused into the final pass's tiles (tuning "ext_fused" = 1: an A/B partner,
     # slower than the two kernels it replaces -- DESIGN.md section 4 -- and held to the same planes)
-    if variant != 2 and case["dtype"] == np.uint32:
+    # variants 4 / 5: the erosion kernels beside the default (tuning "ext_erode": 0 = a lane per word column, 2 = strips of 16 rows;
+    # default 1 = strips of 32 rows)
+    if variant in (0, 3) and case["dtype"] == np.uint32:
         pytest.skip("32-bit pixels have one first-pass kernel")
     img, mask = make_frame(**case)
     H, W = img.shape
     ctx = ffs.Context(W, H, img.dtype, max_batch=2)
-    ctx.set_tuning(ext_first_pass=2 if variant == 3 else variant, ext_fused=1 if variant == 3 else 0)
+    ctx.set_tuning(ext_first_pass=0 if variant == 0 else 2, ext_fused=1 if variant == 3 else 0,
+                   ext_erode={4: 0, 5: 2}.get(variant, 1))
     ctx.set_mask(mask)
     ctx.set_params(algorithm=ffs.ALGO_DISPERSION_EXTENDED, extended_flavour=flavour, want_strong_mask=1,
                    want_strong_list=1, want_reflections=1)
@@ -77,6 +80,32 @@ def test_batch_of_different_frames_and_parameters(ffs):
     ctx.set_params(algorithm=ffs.ALGO_DISPERSION, extended_flavour=0, min_count=2, nsig_b=6.0, nsig_s=3.0, max_valid=-1,
                    min_spot_size=3)
     assert_frame_matches_oracle(st.process(frames[1])[0], frames[1], mask)
+
+
+@pytest.mark.parametrize("erode", [1, 2, 0])
+@pytest.mark.parametrize("flavour", [0, 1])
+def test_planes_of_successive_batches(ffs, erode, flavour):
+    """From a stream's second batch on the signal-region plane was cleared BEHIND the batch before (its twin), and the strip
+    erosion stores only the words that hold a pixel of the region: every batch's planes must be that batch's, whatever the
+    two batches before left in them (dense frames, then sparse and empty ones, batches of different lengths)."""
+    W, H = 700, 260
+    specs = [dict(seed=60, n_spots=400), dict(seed=61, n_spots=3), dict(seed=62, n_spots=0), dict(seed=63, n_spots=250, masked=True),
+             dict(seed=64, n_spots=1), dict(seed=65, n_spots=120), dict(seed=66, n_spots=0), dict(seed=67, n_spots=300)]
+    frames = [make_frame(W=W, H=H, **sp)[0] for sp in specs]
+    mask = make_frame(W=W, H=H, seed=63, n_spots=1, masked=True)[1]
+    ctx = ffs.Context(W, H, np.uint16, max_batch=3)
+    ctx.set_tuning(ext_erode=erode)
+    ctx.set_mask(mask)
+    ctx.set_params(algorithm=ffs.ALGO_DISPERSION_EXTENDED, extended_flavour=flavour, want_reflections=1)
+    st = ctx.stream()
+    want = [O.dispersion_extended(img, mask, flavour=flavour, debug=True) for img in frames]
+    for batch in ([0, 1, 2], [3], [4, 5], [6, 7, 0], [2, 6], [0, 3, 7], [1]):
+        res = st.process(np.stack([frames[i] for i in batch]))
+        for f, i in enumerate(batch):
+            strong, first, eroded = want[i]
+            assert np.array_equal(st.debug_bitplane(f, 1), first), (batch, f)
+            assert np.array_equal(st.debug_bitplane(f, 2), eroded), (batch, f)
+            assert_frame_matches_oracle(res[f], frames[i], mask, strong=strong)
 
 
 def test_empty_and_fully_masked(ffs):
