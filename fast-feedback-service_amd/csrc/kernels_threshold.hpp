@@ -140,7 +140,12 @@ __device__ __forceinline__ uint32_t ext_erode_hrow(const ThresholdArgs& a, const
 template <typename PixelT, int NT, int LISTCAP, int MODE = 0>
 __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
     // The stage is latency-bound (sparse gathers).  Measured dead ends: a smaller LDS footprint
-    // (more tiles resident) and one-wave workgroups both made it slower.
+    // (more tiles resident) and one-wave workgroups both made it slower.  Round 4, extended algorithm (MODE 2, profiles/r04r_ext_final_*):
+    // of 155 us per 32 Eiger frames the tiles' heads (their words of the plane) are 14, the candidates' windows 92, lists / barriers /
+    // results 50.  Tried and dropped, each bit-exact: a third fewer vector instructions per candidate (v_dot2 sums, a float32 test
+    // ahead of the float64 one), the head's loads all in flight, an XCD-aware tile map -- no difference or 3 % slower together; 64 VGPRs
+    // for eight tiles a CU -- spills, +40 us; a workgroup per RANGE of tiles with the next tile's words prefetched -- 109 VGPRs, four
+    // workgroups a CU, +55 us; 16-byte pixel gathers and 8-byte plane gathers (five lane-loads a row instead of nine) -- +100 us.
     __shared__ uint32_t s_words[kTileRows * 320];  // tile bit-plane words (pitch_px <= 10240)
     __shared__ uint32_t s_list[LISTCAP];
     __shared__ uint32_t s_cnt, s_total, s_strong;
@@ -208,6 +213,7 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
         mine += __popc(entries(w));
     }
     __syncthreads();
+    if (FFS_DBG(a, 2048)) return;   // (experiments build: what the tiles' head costs)
     if (mine) atomicAdd(&s_total, mine);
     __syncthreads();
     const uint32_t total = s_total;  // block-uniform
@@ -226,7 +232,7 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
         }
     };
     auto flush = [&]() {
-        const uint32_t n = s_cnt;
+        const uint32_t n = FFS_DBG(a, 512) ? 0u : s_cnt;   // (experiments build: no candidate is looked at)
         if constexpr (MODE >= 2) {
             // an entry = an aligned group of four pixels, taken by a quad of lanes (whole quads are in or out of the loop)
             const int sub = tid & 3;
@@ -294,7 +300,7 @@ __device__ __forceinline__ void exact_tile(const ThresholdArgs& a) {
     uint32_t cnt = 0;
     for (int g = tid; g < ndw; g += NT) {
         const uint32_t w = s_words[g];
-        gwords[g] = w;
+        if (!FFS_DBG(a, 1024) || w) gwords[g] = w;   // (experiments build, bit 1024: the non-zero words only)
         cnt += __popc(w);
         if constexpr (MODE >= 1) {
             // the extended algorithm's final plane: its occupancy bitmap (one bit per 16-byte segment of a plane row) lets the
