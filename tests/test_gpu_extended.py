@@ -82,19 +82,20 @@ def test_batch_of_different_frames_and_parameters(ffs):
     assert_frame_matches_oracle(st.process(frames[1])[0], frames[1], mask)
 
 
-@pytest.mark.parametrize("erode", [1, 2, 0])
+@pytest.mark.parametrize("erode,sparse", [(2, 0), (2, 1), (1, 1), (1, 0), (0, 0)])
 @pytest.mark.parametrize("flavour", [0, 1])
-def test_planes_of_successive_batches(ffs, erode, flavour):
-    """From a stream's second batch on the signal-region plane was cleared BEHIND the batch before (its twin), and the strip
-    erosion stores only the words that hold a pixel of the region: every batch's planes must be that batch's, whatever the
-    two batches before left in them (dense frames, then sparse and empty ones, batches of different lengths)."""
+def test_planes_of_successive_batches(ffs, erode, sparse, flavour):
+    """The planes of a stream take turns (the first-pass plane always; with tuning "ext_e_sparse" = 1 the signal-region plane too:
+    it is then cleared BEHIND the batch before, and the strip erosion stores only the words that hold a pixel of the region):
+    every batch's planes must be that batch's, whatever the two batches before left in them (dense frames, then sparse and
+    empty ones, batches of different lengths).  All erosion kernels (tuning "ext_erode")."""
     W, H = 700, 260
     specs = [dict(seed=60, n_spots=400), dict(seed=61, n_spots=3), dict(seed=62, n_spots=0), dict(seed=63, n_spots=250, masked=True),
              dict(seed=64, n_spots=1), dict(seed=65, n_spots=120), dict(seed=66, n_spots=0), dict(seed=67, n_spots=300)]
     frames = [make_frame(W=W, H=H, **sp)[0] for sp in specs]
     mask = make_frame(W=W, H=H, seed=63, n_spots=1, masked=True)[1]
     ctx = ffs.Context(W, H, np.uint16, max_batch=3)
-    ctx.set_tuning(ext_erode=erode)
+    ctx.set_tuning(ext_erode=erode, ext_e_sparse=sparse)
     ctx.set_mask(mask)
     ctx.set_params(algorithm=ffs.ALGO_DISPERSION_EXTENDED, extended_flavour=flavour, want_reflections=1)
     st = ctx.stream()
