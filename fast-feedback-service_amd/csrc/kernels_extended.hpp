@@ -404,8 +404,10 @@ __device__ __forceinline__ bool ext_final_strong4(const ThresholdArgs& a, const 
 }
 
 // (16-bit pixels: four pixels per quad of lanes, MODE 2 of the tile skeleton; 32-bit pixels: one pixel per lane)
+// (seven workgroups a CU: 72 VGPRs without a vector spill where the compiler took 80 for six; 186-187 against 189-190 us with the erosion,
+// profiles/r04x_ext_final_7_waves_per_simd_ab.txt -- eight need 64 VGPRs and spill: +40 us)
 template <typename PixelT>
-__global__ __launch_bounds__(256) void k_ext_final(const ThresholdArgs a) { exact_tile<PixelT, 256, kExactListCap, sizeof(PixelT) == 2 ? 2 : 1>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_ext_final(const ThresholdArgs a) { exact_tile<PixelT, 256, kExactListCap, sizeof(PixelT) == 2 ? 2 : 1>(a); }
 template __global__ void k_ext_final<uint16_t>(const ThresholdArgs);
 template __global__ void k_ext_final<uint32_t>(const ThresholdArgs);
 // erosion + final pass in one launch (16-bit pixels; dynamic LDS: 18 rows of the plane = 18 * mpitch bytes)
