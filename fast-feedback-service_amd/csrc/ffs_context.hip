@@ -10,6 +10,71 @@ static_assert(offsetof(ReflOut, sum_intensity) == offsetof(ffs_reflection, sum_i
 
 thread_local std::string g_create_error;
 
+// ---- lifecycle (ffs_internal.hpp) -------------------------------------------------------------------------------
+// The registry is never destructed (a leaked singleton): destroy calls may arrive from static destructors of the caller that run
+// after this library's own.
+static void ctx_destroy_internal(ffs_ctx* c);
+namespace {
+struct Registry {
+    std::mutex mu;
+    std::unordered_set<const void*> live[3];
+    std::atomic<bool> exiting{false};
+    bool exit_hook_installed = false;
+};
+Registry& registry() {
+    static Registry* r = new Registry();
+    return *r;
+}
+// Runs when the process exits (exit() or return from main) with the HIP runtime still up: installed by the first ffs_ctx_create,
+// i.e. after the runtime registered its own exit handlers, and handlers run in reverse order.  Nothing is freed here -- the
+// process is going away -- but nothing of ours may still be running when the runtime takes its queues and the pinned memory down:
+// the helper threads of compressed submits and of ffs_wait's assembly are joined, and each context's device is drained (a sparse
+// launch in flight writes its records straight into pinned host memory).
+static void on_process_exit() {
+    Registry& r = registry();
+    std::vector<ffs_ctx*> ctxs;
+    {
+        std::lock_guard<std::mutex> lock(r.mu);
+        r.exiting.store(true);
+        for (const void* h : r.live[kHandleCtx]) ctxs.push_back(static_cast<ffs_ctx*>(const_cast<void*>(h)));
+    }
+    for (ffs_ctx* c : ctxs) {
+        std::vector<ffs_stream*> streams;
+        {
+            std::lock_guard<std::mutex> lock(c->stream_mu);
+            streams = c->live_streams;
+        }
+        for (ffs_stream* s : streams)
+            if (s->job.joinable()) s->job.join();
+        if (hipSetDevice(c->device) == hipSuccess) (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+        if (AssemblyPool* pool = c->assembly.load(std::memory_order_acquire)) pool->stop_and_join();
+    }
+}
+}  // namespace
+
+void handle_add(HandleKind kind, const void* h) {
+    Registry& r = registry();
+    std::lock_guard<std::mutex> lock(r.mu);
+    r.live[kind].insert(h);
+    if (!r.exit_hook_installed) {
+        r.exit_hook_installed = true;
+        std::atexit(on_process_exit);
+    }
+}
+bool handle_take(HandleKind kind, const void* h) {
+    Registry& r = registry();
+    std::lock_guard<std::mutex> lock(r.mu);
+    if (r.exiting.load()) return false;
+    return r.live[kind].erase(h) != 0;
+}
+bool handle_live(HandleKind kind, const void* h) {
+    Registry& r = registry();
+    std::lock_guard<std::mutex> lock(r.mu);
+    return r.live[kind].count(h) != 0;
+}
+bool process_exiting() { return registry().exiting.load(); }
+
 extern "C" void ffs_default_params(ffs_params* p) {
     if (!p) return;
     std::memset(p, 0, sizeof(*p));
@@ -122,7 +187,7 @@ extern "C" int ffs_ctx_create(int device, uint32_t width, uint32_t height, int p
     if (e == hipSuccess) e = hipMalloc(&c->d_mmap, (size_t)L.H * L.pitch_px + 256);
     if (e != hipSuccess) {
         g_create_error = std::string("hipMalloc(mask): ") + hipGetErrorString(e);
-        ffs_ctx_destroy(c);
+        ctx_destroy_internal(c);
         return FFS_ERR_NOMEM;
     }
     // the hot path's code object is loaded here, not by the first worker's first stream (~30 ms), and k_frame_chain's
@@ -140,18 +205,18 @@ extern "C" int ffs_ctx_create(int device, uint32_t width, uint32_t height, int p
                 if (es == hipSuccess) es = hipEventCreate(&e);
         if (es != hipSuccess) {
             g_create_error = std::string("creating the context's HIP streams: ") + hipGetErrorString(es);
-            ffs_ctx_destroy(c);
+            ctx_destroy_internal(c);
             return FFS_ERR_DEVICE;
         }
     }
-    *out = c;
     int rc = ffs_ctx_set_mask(c, nullptr);
     if (rc != FFS_OK) {
         g_create_error = c->err;
-        ffs_ctx_destroy(c);
-        *out = nullptr;
+        ctx_destroy_internal(c);
         return rc;
     }
+    handle_add(kHandleCtx, c);   // (the runtime is up by now: the exit handler this installs runs before the runtime's own)
+    *out = c;
     return FFS_OK;
 }
 
@@ -206,22 +271,47 @@ void AssemblyPool::run(uint32_t n, const std::function<void(uint32_t)>& fn) {
     }
     while (active.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();   // ... and those that took this one have left it: `fn` may go
 }
-AssemblyPool::~AssemblyPool() {
+void AssemblyPool::stop_and_join() {
     {
         std::lock_guard<std::mutex> lock(mu);
         stop = true;
     }
     cv.notify_all();
-    for (auto& t : threads) t.join();
+    for (auto& t : threads)
+        if (t.joinable()) t.join();   // (a helper inside a job finishes its items first)
 }
+AssemblyPool::~AssemblyPool() { stop_and_join(); }
 
 extern "C" void ffs_ctx_destroy(ffs_ctx* c) {
-    if (!c) return;
+    if (!c || !handle_take(kHandleCtx, c)) return;   // (destroyed already, or the process is exiting: ffs_internal.hpp, lifecycle)
+    // the streams and stacks the caller still holds go first: each keeps a pointer to this context.  Their handles leave the registry
+    // here, so the caller's own destroy calls on them -- in whatever order its teardown makes them -- find nothing to do.
+    std::vector<ffs_stream*> streams;
+    std::vector<ffs_stack3d*> stacks;
+    {
+        std::lock_guard<std::mutex> lock(c->stream_mu);
+        streams.swap(c->live_streams);
+        stacks.swap(c->live_stacks);
+    }
+    for (ffs_stream* s : streams)
+        if (handle_take(kHandleStream, s)) stream_destroy_internal(s);
+    for (ffs_stack3d* st : stacks)
+        if (handle_take(kHandleStack, st)) {
+            g_live_stacks.fetch_sub(1);
+            stack3d_free(st);
+        }
+    ctx_destroy_internal(c);
+}
+
+static void ctx_destroy_internal(ffs_ctx* c) {
     (void)hipSetDevice(c->device);
     for (auto* st : c->stack_pool) stack3d_free(st);
     c->stack_pool.clear();
-    delete c->assembly;
-    c->assembly = nullptr;
+    if (AssemblyPool* pool = c->assembly.exchange(nullptr)) {
+        pool->owner.lock();     // (a wait of another thread that is using the helpers -- the caller's mistake -- is let finish)
+        pool->owner.unlock();
+        delete pool;            // joins the helpers
+    }
     if (c->d_maskbits) (void)hipFree(c->d_maskbits);
     if (c->d_ginfo) (void)hipFree(c->d_ginfo);
     if (c->d_mmap) (void)hipFree(c->d_mmap);
@@ -361,7 +451,17 @@ extern "C" int ffs_ctx_set_tuning(ffs_ctx* c, const char* key, long long value) 
 // ---- streams ---------------------------------------------------------------------------------------
 
 extern "C" void ffs_stream_destroy(ffs_stream* s) {
-    if (!s) return;
+    if (!s || !handle_take(kHandleStream, s)) return;   // (destroyed already -- by its context's ffs_ctx_destroy, or twice)
+    {
+        ffs_ctx* c = s->ctx;   // alive: a context takes its streams with it, and this one was still in the registry
+        std::lock_guard<std::mutex> lock(c->stream_mu);
+        auto& v = c->live_streams;
+        v.erase(std::remove(v.begin(), v.end(), s), v.end());
+    }
+    stream_destroy_internal(s);
+}
+
+void stream_destroy_internal(ffs_stream* s) {
     (void)hipSetDevice(s->ctx->device);
     if (s->job.joinable()) s->job.join();
     mark_idle(s);   // (a stream may be closed with its batch still in flight)
@@ -373,7 +473,7 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
     }
     if (s->h_phase_ts) (void)hipHostFree(s->h_phase_ts);
 #endif
-    if (s->big) ffs_stream_destroy(s->big);
+    if (s->big) stream_destroy_internal(s->big);
     if (s->st_up && s->st_up != s->st) (void)hipStreamSynchronize(s->st_up);
     if (s->st) (void)hipStreamSynchronize(s->st);
     if (s->st2 && s->st2 != s->st) { (void)hipStreamSynchronize(s->st2); if (!s->st2_shared) (void)hipStreamDestroy(s->st2); }
@@ -401,7 +501,14 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
 
 extern "C" int ffs_stream_create(ffs_ctx* c, ffs_stream** out) {
     if (!c || !out) return FFS_ERR_INVALID;
-    return stream_create_sized(c, c->max_batch, c->cap, c->max_comp, out);
+    const int rc = stream_create_sized(c, c->max_batch, c->cap, c->max_comp, out);
+    if (rc != FFS_OK) return rc;
+    {
+        std::lock_guard<std::mutex> lock(c->stream_mu);
+        c->live_streams.push_back(*out);
+    }
+    handle_add(kHandleStream, *out);
+    return FFS_OK;
 }
 
 int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uint32_t max_comp, ffs_stream** out) {
@@ -420,7 +527,7 @@ int stream_create_sized(ffs_ctx* c, uint32_t max_batch, uint32_t cap, uint32_t m
         hipError_t e_ = (expr);                                                 \
         if (e_ != hipSuccess) {                                                 \
             c->err = std::string(#expr) + ": " + hipGetErrorString(e_);         \
-            ffs_stream_destroy(s);                                              \
+            stream_destroy_internal(s);                                         \
             return e_ == hipErrorOutOfMemory ? FFS_ERR_NOMEM : FFS_ERR_DEVICE;  \
         }                                                                       \
     } while (0)

@@ -23,6 +23,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -119,6 +120,7 @@ struct AssemblyPool {
     bool stop = false;
     void start(int n_threads);
     void run(uint32_t n, const std::function<void(uint32_t)>& fn);   // fn(i) for i in [0, n), on the caller and the helpers
+    void stop_and_join();                // the helpers leave (after the job they are in) and are joined; run() then works on the caller alone
     ~AssemblyPool();
 };
 
@@ -151,7 +153,11 @@ struct ffs_ctx {
     hipStream_t up_st = nullptr;     // ... and the one stream of uploads and decoding
     hipStream_t sparse_st[2] = {nullptr, nullptr};  // ... the sparse launches of the context's streams, alternating
     int n_streams_made = 0;
-    std::mutex stream_mu;            // guards the lazy creation of the shared streams, the stack pool and the event ring
+    std::mutex stream_mu;            // guards the lazy creation of the shared streams, the stack pool, the event ring and the two lists below
+    // What the context's users have created on it and not destroyed yet: ffs_ctx_destroy closes these first (a stream or a stack
+    // keeps a pointer to its context), and the process's exit handler finds in-flight work through them (lifecycle, below).
+    std::vector<ffs_stream*> live_streams;
+    std::vector<ffs_stack3d*> live_stacks;
     std::vector<ffs_stack3d*> stack_pool;   // destroyed 3D stacks kept with their buffers for the next sweep (stream_mu)
     // Pinned host memory costs ~170 ms per GB to allocate and ~100 ms per GB to free, and the runtime serialises both
     // across threads (tools/ubench/alloc_cost.hip): the staging buffers of destroyed streams are kept for the next
@@ -166,7 +172,7 @@ struct ffs_ctx {
     std::atomic<uint32_t> chain_ev_next{0};     // slots handed out so far
     std::atomic<int> chain_ev_newest{-1};       // slot of the newest recorded start, -1: none yet
     bool chain_ok = false;           // k_frame_chain may use its dynamic LDS on this device
-    AssemblyPool* assembly = nullptr;   // helper threads of ffs_wait (created on first use, stream_mu)
+    std::atomic<AssemblyPool*> assembly{nullptr};   // helper threads of ffs_wait (created on first use under stream_mu; read without it)
     ThreadError err;  // the calling thread's most recent error on any context
 };
 
@@ -336,6 +342,28 @@ template <typename T>
 static hipError_t dmalloc(T** p, size_t n_bytes) {
     return hipMalloc(reinterpret_cast<void**>(p), n_bytes + 256);
 }
+
+// ---- lifecycle: which handles are alive ---------------------------------------------------------------------
+// Every handle the ABI has given out is in a process-wide registry until it is destroyed -- by its own destroy call, or by the
+// ffs_ctx_destroy of its context, which closes a context's streams and stacks before the context itself.  A destroy call on a handle
+// that is not (or no longer) in the registry does nothing, so the ORDER in which a caller (a binding's finalisers, a C++ driver's
+// unwinding, a test that leaks) lets go of contexts, streams and stacks cannot reach freed memory.  When the process exits with
+// handles alive, the library's own exit handler -- registered after the HIP runtime has initialised, so it runs BEFORE the runtime's
+// handlers -- joins the helper threads and waits for the work in flight (kernels that write into pinned host memory); every destroy
+// call after that is a no-op and the runtime's own teardown takes the memory.  DESIGN.md section 10c.
+enum HandleKind { kHandleCtx = 0, kHandleStream = 1, kHandleStack = 2 };
+void handle_add(HandleKind kind, const void* h);
+bool handle_take(HandleKind kind, const void* h);   // removes h; false: not a live handle (destroyed already, or the process is exiting)
+bool handle_live(HandleKind kind, const void* h);
+bool process_exiting();
+// A stream handle that its context's ffs_ctx_destroy (or an earlier ffs_stream_destroy) has closed is refused by submit and wait
+// with FFS_ERR_INVALID and a text in ffs_last_error(NULL), instead of being followed into freed memory.
+static inline bool stream_handle_ok(const ffs_stream* s) {
+    if (handle_live(kHandleStream, s)) return true;
+    g_create_error = "stale ffs_stream handle: the stream was destroyed (with its context, or by ffs_stream_destroy)";
+    return false;
+}
+void stream_destroy_internal(ffs_stream* s);         // what ffs_stream_destroy does once the handle is out of the registry
 
 // ---- functions one unit calls in another ----------------------------------------------------------------------
 // ffs_context.hip

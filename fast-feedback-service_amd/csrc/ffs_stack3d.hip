@@ -107,17 +107,25 @@ extern "C" int ffs_stack3d_create(ffs_ctx* c, uint64_t max_total, ffs_stack3d** 
     if (!c || !out) return FFS_ERR_INVALID;
     *out = nullptr;
     const int rc = stack3d_create_impl(c, max_total, out);
-    if (rc == FFS_OK) g_live_stacks.fetch_add(1);
-    return rc;
+    if (rc != FFS_OK) return rc;
+    g_live_stacks.fetch_add(1);
+    {
+        std::lock_guard<std::mutex> lock(c->stream_mu);
+        c->live_stacks.push_back(*out);
+    }
+    handle_add(kHandleStack, *out);
+    return FFS_OK;
 }
 
 extern "C" void ffs_stack3d_destroy(ffs_stack3d* st) {
-    if (!st) return;
+    if (!st || !handle_take(kHandleStack, st)) return;   // (destroyed already -- by its context's ffs_ctx_destroy, or twice)
     g_live_stacks.fetch_sub(1);
-    ffs_ctx* c = st->ctx;
+    ffs_ctx* c = st->ctx;   // alive: a context takes its stacks with it, and this one was still in the registry
     (void)hipSetDevice(c->device);
     {
         std::lock_guard<std::mutex> lock(c->stream_mu);
+        auto& v = c->live_stacks;
+        v.erase(std::remove(v.begin(), v.end(), st), v.end());
         if (c->stack_pool.size() < 2) {   // keep it, emptied, for the next sweep
             for (int k = 0; k < ffs_stack3d::kSlots; ++k)
                 if (st->slot_used[k]) {

@@ -605,7 +605,7 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
 
 extern "C" int ffs_submit_device(ffs_stream* s, const void* device_pixels, size_t pitch, size_t fstride,
                                  uint32_t n_frames, int64_t first_frame_id) {
-    if (!s || !device_pixels) return FFS_ERR_INVALID;
+    if (!s || !device_pixels || !stream_handle_ok(s)) return FFS_ERR_INVALID;
     ffs_ctx* c = s->ctx;
     if (s->busy) {
         c->err = "stream already has a batch in flight: call ffs_wait() first";
@@ -623,7 +623,7 @@ extern "C" int ffs_submit_device(ffs_stream* s, const void* device_pixels, size_
 }
 
 extern "C" int ffs_submit(ffs_stream* s, const void* host_pixels, uint32_t n_frames, int64_t first_frame_id) {
-    if (!s || !host_pixels) return FFS_ERR_INVALID;
+    if (!s || !host_pixels || !stream_handle_ok(s)) return FFS_ERR_INVALID;
     ffs_ctx* c = s->ctx;
     if (s->busy) {
         c->err = "stream already has a batch in flight: call ffs_wait() first";
@@ -944,5 +944,6 @@ extern "C" int ffs_decode_only(ffs_stream* s, const void* const* chunks, const s
 
 extern "C" int ffs_submit_compressed(ffs_stream* s, const void* const* chunks, const size_t* chunk_bytes,
                                      uint32_t n_frames, int64_t first_frame_id) {
-    return guarded(s ? s->ctx : nullptr, [&] { return ffs_submit_compressed_impl(s, chunks, chunk_bytes, n_frames, first_frame_id); });
+    if (!s || !stream_handle_ok(s)) return FFS_ERR_INVALID;
+    return guarded(s->ctx, [&] { return ffs_submit_compressed_impl(s, chunks, chunk_bytes, n_frames, first_frame_id); });
 }

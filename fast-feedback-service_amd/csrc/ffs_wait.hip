@@ -107,7 +107,7 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
             uint64_t need_comp = h_ns[f] > s->cap ? need_cap : std::max<uint64_t>(h_nc[f], s->max_comp);  // list truncated: count unknown
             for (int attempt = 0;; ++attempt) {
                 if (s->big && (s->big->cap < need_cap || s->big->max_comp < need_comp)) {
-                    ffs_stream_destroy(s->big);
+                    stream_destroy_internal(s->big);
                     s->big = nullptr;
                 }
                 if (!s->big) {
@@ -295,16 +295,26 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
     // reflections = components surviving filter_reflections (:207-236); both keep label order.
     bool pooled = false;
     if (total_recs >= 8192 && n >= 4) {
-        if (!c->assembly) {
+        AssemblyPool* pool = c->assembly.load(std::memory_order_acquire);
+        if (!pool && !process_exiting()) {
             std::lock_guard<std::mutex> lock(c->stream_mu);
-            if (!c->assembly) {
-                AssemblyPool* pool = new (std::nothrow) AssemblyPool();
-                if (pool) { pool->start(3); c->assembly = pool; }
+            pool = c->assembly.load(std::memory_order_acquire);
+            if (!pool) {
+                pool = new (std::nothrow) AssemblyPool();
+                if (pool) {
+                    try {
+                        pool->start(3);
+                    } catch (...) {   // (no more threads to be had: whatever did start is joined, and this wait assembles on its own)
+                        delete pool;
+                        pool = nullptr;
+                    }
+                }
+                if (pool) c->assembly.store(pool, std::memory_order_release);   // (published with its members built and its threads started)
             }
         }
-        if (c->assembly && c->assembly->owner.try_lock()) {   // (another stream's wait has the helpers: assemble here)
-            c->assembly->run(n, assemble);
-            c->assembly->owner.unlock();
+        if (pool && pool->owner.try_lock()) {   // (another stream's wait has the helpers: assemble here)
+            pool->run(n, assemble);
+            pool->owner.unlock();
             pooled = true;
         }
     }
@@ -446,5 +456,6 @@ extern "C" int ffs_stream_debug_bitplane(ffs_stream* s, uint32_t frame, int whic
 }
 
 extern "C" int ffs_wait(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_results) {
-    return guarded(s ? s->ctx : nullptr, [&] { return ffs_wait_impl(s, results, n_results); });
+    if (!s || !stream_handle_ok(s)) return FFS_ERR_INVALID;
+    return guarded(s->ctx, [&] { return ffs_wait_impl(s, results, n_results); });
 }

@@ -1018,6 +1018,7 @@ int main(int argc, char** argv) {
                     A.submitted = false;
                     A.skipped = false;
                     std::fill(A.slot_filled.begin(), A.slot_filled.end(), (uint8_t)0);
+                    A.over_used = 0;   // (before the lock is dropped below: the batch's other readers take the overflow area as soon as they see `ready`)
                     if (!A.ready) {   // first use (usually made ahead, below): the stream(s) and the pinned staging area, outside the lock
                         lock.unlock();
                         if (!ensure_assembly(G, A, (uint32_t)(q % K), thread_id)) break;
@@ -1028,7 +1029,6 @@ int main(int argc, char** argv) {
                         (void)ffs_stream_host_buffer(A.s, &v, &A.host_bytes);
                         A.host = static_cast<uint8_t*>(v);
                     }
-                    A.over_used = 0;
                 } else if (!A.ready) {
                     G.cv.wait(lock, [&] { return A.ready || g_stop.load() || failed.load(); });
                     if (!A.ready) break;
@@ -1131,7 +1131,23 @@ int main(int argc, char** argv) {
         std::vector<std::thread> threads;
         for (uint32_t di = 0; di < n_dev; ++di) threads.emplace_back(collector, di);
         for (uint32_t t = 0; t < n_workers; ++t) threads.emplace_back(reader_thread, (int)t);
+        // The signal handler only sets g_stop (nothing else is safe there), so somebody has to tell the threads parked on a GPU's
+        // condition variable: readers waiting for a free assembly are woken by the collector only when a batch COMPLETES, and after an
+        // interrupt none may -- the readers that hold its slots return without filling them.  (The reference's workers poll: :770-790.)
+        std::atomic<bool> watch_over{false};
+        std::thread stop_watcher([&] {
+            bool told = false;
+            while (!watch_over.load()) {
+                if (!told && (g_stop.load() || failed.load())) {
+                    wake_all();
+                    told = true;
+                }
+                std::this_thread::sleep_for(20ms);
+            }
+        });
         for (size_t t = n_dev; t < threads.size(); ++t) threads[t].join();   // the readers
+        watch_over.store(true);
+        stop_watcher.join();
         // Readers that stopped early (a time-out: the data set ended before --images; an interrupt) leave batches half filled.  The
         // reference's workers finish the image they hold, so every image that WAS read still goes through: the leading filled
         // slots of such a batch are submitted as a shorter batch (images arrive in order; one behind a missing image is dropped).

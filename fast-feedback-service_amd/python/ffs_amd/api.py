@@ -1,10 +1,8 @@
 """ctypes binding of include/ffs_hip.h (one class per opaque handle)."""
 from __future__ import annotations
 
-import atexit
 import ctypes as C
 import os
-import weakref
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -194,22 +192,6 @@ def _copy_array(ptr, n, ctype_struct, dt):
     return np.frombuffer(raw, dtype=dt).copy()
 
 
-# Objects that own something on the device, closed in order -- stacks, streams, contexts -- when the interpreter exits: what is
-# still alive then (a script's globals) would otherwise be finalised in whatever order module teardown picks, possibly beside the
-# HIP runtime's own exit handlers (seen once in a 300-context soak on the system runtime: an abort after the last line of output).
-_live = {"stack": weakref.WeakSet(), "stream": weakref.WeakSet(), "context": weakref.WeakSet()}
-
-
-@atexit.register
-def _close_all():
-    for kind in ("stack", "stream", "context"):
-        for obj in list(_live[kind]):
-            try:
-                obj.close()
-            except Exception:
-                pass
-
-
 class Context:
     def __init__(self, width: int, height: int, dtype=np.uint16, max_batch: int = 1,
                  device: int = 0, max_strong_per_frame: int = 0):
@@ -226,7 +208,6 @@ class Context:
             raise FfsError(rc, self._lib.ffs_last_error(None).decode())
         self._h = h
         self.params = default_params()
-        _live["context"].add(self)
 
     def _check(self, rc):
         if rc != 0:
@@ -295,7 +276,6 @@ class Stream:
         h = C.c_void_p()
         ctx._check(self._lib.ffs_stream_create(ctx._h, C.byref(h)))
         self._h = h
-        _live["stream"].add(self)
 
     def host_buffer(self) -> np.ndarray:
         """The stream's pinned staging area as a (max_batch, H, W) array."""
@@ -498,7 +478,6 @@ class Stack3D:
         h = C.c_void_p()
         ctx._check(self._lib.ffs_stack3d_create(ctx._h, max_total_strong, C.byref(h)))
         self._h = h
-        _live["stack"].add(self)
 
     def add_batch(self, stream: Stream):
         self.ctx._check(self._lib.ffs_stack3d_add_batch(self._h, stream._h))

@@ -127,6 +127,18 @@ int ffs_device_total_mem(int device, uint64_t *bytes);
  * connected_components.cc:24-32, has no bound), at the price of that extra pass. */
 int ffs_ctx_create(int device, uint32_t width, uint32_t height, int pixel_bytes,
                    uint32_t max_batch, uint32_t max_strong_per_frame, ffs_ctx **out);
+/* Lifetime rules (the reference: RAII members of one worker thread, spotfinder.cc:729-742; CUDA_CHECK aborts by exception,
+ * include/cuda_common.hpp:28-45 -- here nothing aborts):
+ *  - ffs_ctx_destroy() first closes the streams and 3D stacks that were created on the context and are still alive (waiting for
+ *    their work in flight), then the context.  Their handles are dead from then on.
+ *  - every destroy call is idempotent: on a handle that was destroyed already (by its own destroy call or with its context) it does
+ *    nothing, so a caller's teardown -- finalisers of a binding, unwinding of a driver -- may let go of contexts, streams and stacks
+ *    in ANY order.  ffs_submit* / ffs_wait on such a handle return FFS_ERR_INVALID.  (Handles are compared by address: do not keep a
+ *    dead handle across the creation of new ones.)
+ *  - no other thread may be inside a call on a handle, or on a child of a context, while it is being destroyed.
+ *  - a process may exit (exit(), return from main, an interpreter shutting down) with handles alive and batches in flight: the
+ *    library's exit handler, which runs before the HIP runtime's own, joins its helper threads and drains the devices; destroy calls
+ *    that arrive after that (static destructors, late finalisers) do nothing.  _exit() / quick_exit() skip it, like any handler. */
 void ffs_ctx_destroy(ffs_ctx *ctx);
 /* Text of the calling thread's most recent error (kept per thread: worker threads drive their own
  * streams of one context).  ctx may be NULL: last error of ffs_ctx_create. */
@@ -190,6 +202,7 @@ int ffs_ctx_set_tuning(ffs_ctx *ctx, const char *key, long long value);
  * two or more batches in flight (two or more ffs_streams) for throughput -- a batch's sparse stage runs beside
  * the next batch's threshold kernel. */
 int ffs_stream_create(ffs_ctx *ctx, ffs_stream **out);
+/* Waits for the stream's batch in flight, if any, and frees its buffers (idempotent: see ffs_ctx_destroy). */
 void ffs_stream_destroy(ffs_stream *s);
 
 /* The stream's pinned staging area (max_batch dense frames): decode straight into it, as the
@@ -305,6 +318,7 @@ int ffs_selftest_sqrt(ffs_ctx *ctx, uint64_t begin, uint64_t end, uint64_t *sum_
 /* ---- rotation sweeps: 3D connected components (replaces
  *      ConnectedComponents::find_3d_components, connected_components.cc:270-470) -------------- */
 int ffs_stack3d_create(ffs_ctx *ctx, uint64_t max_total_strong, ffs_stack3d **out);
+/* (idempotent: see ffs_ctx_destroy; the stack's buffers are kept by the context for its next sweep) */
 void ffs_stack3d_destroy(ffs_stack3d *st);
 /* Adds the strong pixels of every frame of the stream's last completed batch, keyed by frame_id
  * (the reference keys its rotation_slices map by image number, spotfinder.cc:913-918). */

@@ -540,3 +540,38 @@ def test_interrupt_stops_the_readers_and_reports_what_was_read(tmp_path):
     assert m and 0 < int(m.group(1)) < 200000
     nums = [json.loads(l)["file-number"] for l in lines if l.strip()]
     assert len(nums) == int(m.group(1)) and nums == list(range(len(nums)))      # a contiguous prefix, in order, nothing lost
+
+
+def test_interrupt_wakes_readers_parked_for_a_free_assembly(tmp_path):
+    """More readers than slots (20 threads, K = 3 assemblies of 2 images): after the six images the live stream directory holds,
+    six readers poll for images that never come and the others are parked waiting for a free assembly -- which only a completed
+    batch frees, and after SIGINT none completes.  One signal must end the run: the parked readers are told (the signal handler
+    itself can only set a flag), the six images that were read are reported, exit code 0.  Reference: its workers poll the stop
+    flag between images, spotfinder.cc:770-790."""
+    import signal
+    import time
+    rng = np.random.default_rng(11)
+    W, H, N_have, N_said = 300, 200, 6, 100
+    frames = rng.poisson(2.0, (N_have, H, W)).astype(np.uint16)
+    for i in range(N_have):
+        frames[i, 30 + i:33 + i, 60:63] += 400
+    shm = tmp_path / "shm"
+    _write_stream_dir(str(shm), frames)
+    hdr = json.loads((shm / "start_1").read_text())
+    hdr["nimages"] = N_said
+    (shm / "start_1").write_text(json.dumps(hdr) + "\n")
+    r, w = os.pipe()
+    proc = subprocess.Popen([SPOTFINDER, str(shm), "--cpu-decode", "--threads", "20", "--batch", "2", "--timeout", "120", "--pipe_fd", str(w)],
+                            pass_fds=[w], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    os.close(w)
+    time.sleep(3.0)
+    t0 = time.time()
+    proc.send_signal(signal.SIGINT)
+    out, err = proc.communicate(timeout=60)          # (a hang here is the bug: TimeoutExpired)
+    assert time.time() - t0 < 20
+    with os.fdopen(r) as f:
+        lines = [l for l in f.read().split("\n") if l]
+    assert proc.returncode == 0 and not err, (out[-500:], err)
+    assert "Running interrupted by user request" in out
+    assert [json.loads(l)["file-number"] for l in lines] == list(range(N_have))
+    assert f"{N_have} images in" in strip_ansi(out)
