@@ -421,6 +421,22 @@ extern "C" int ffs_ctx_set_tuning(ffs_ctx* c, const char* key, long long value) 
     else if (k == "device_lists") { if ((ok = in(0, 2))) t.device_lists = (int)value; }
     else if (k == "strong_log") { if ((ok = in(0, 1))) t.strong_log = (int)value; }
     else if (k == "chain_runs") { if ((ok = in(0, 2))) t.chain_runs = (int)value; }
+    else if (k == "sparse_bands") { if ((ok = in(0, 1))) t.sparse_bands = (int)value; }
+    else if (k == "sparse_priority") {
+        // priority of the context's two sparse HIP streams: 0 = highest (default), 1 = lowest, 2 = the dense stream's; before the first stream is created
+        if ((ok = in(0, 2) && c->n_streams_made == 0)) {
+            int lo = 0, hi = 0;
+            HIP_TRY(c, hipSetDevice(c->device));
+            HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+            const int prio = value == 0 ? hi : value == 1 ? lo : (lo + hi) / 2;
+            for (auto& sp : c->sparse_st) {
+                if (sp) (void)hipStreamDestroy(sp);
+                sp = nullptr;
+                HIP_TRY(c, hipStreamCreateWithPriority(&sp, hipStreamNonBlocking, prio));
+            }
+            t.sparse_priority = (int)value;
+        }
+    }
     else if (k == "sched") { if ((ok = (value == 0 || value == 3) && c->n_streams_made == 0)) t.sched = (int)value; }
     else if (k == "chain_first") { if ((ok = in(0, 64))) t.chain_first = (int)value; }
     else if (k == "bright_cap") { if ((ok = in(0, kBrightCap))) t.bright_cap = (int)value; }
@@ -480,7 +496,8 @@ void stream_destroy_internal(ffs_stream* s) {
     // (d_n_comp, d_summary and d_overflow live inside the d_num_strong allocation)
     if (s->h_pack_tab) (void)hipHostFree(s->h_pack_tab);
     // (the stream's device buffers are one slab; what is allocated on first use is freed by itself)
-    void* dev[] = {s->d_slab, s->d_pack_k, s->d_pack_i, s->d_pack_tab, s->d_comp, s->d_tab, s->d_ext_pair[0], s->d_ext_pair[1], s->d_wlog, s->d_wlog_n, s->d_wpix};
+    void* dev[] = {s->d_slab, s->d_pack_k, s->d_pack_i, s->d_pack_tab, s->d_comp, s->d_tab, s->d_ext_pair[0], s->d_ext_pair[1], s->d_wlog, s->d_wlog_n, s->d_wpix,
+                   s->d_band_hdr, s->d_band_acc, s->d_band_seam};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     void* host[] = {s->h_tab, s->h_counts, s->h_recs, s->h_list_k, s->h_list_i, s->h_mask};

@@ -93,6 +93,9 @@ struct Tuning {
                                 //    0 = the bit plane (also what dense frames, tall frames and the other algorithms and paths take)
     int chain_runs = 1;         // sparse_stage 2: frames beyond the LDS forest of pixels stay in the one launch when their RUNS fit
                                 //    (16-bit pixels, rows up to 16383 pixels); 0 = such batches take the four grid-wide kernels; 2 = runs for every frame
+    int sparse_bands = 1;       // standard path with wave logs, lists not asked for: the sparse stage in small workgroups (kernels_band.hpp: a wave per
+                                //    band of a frame + a merge per frame) instead of k_frame_chain's one workgroup per frame; 0 = k_frame_chain
+    int sparse_priority = 0;    // priority of the context's sparse HIP streams: 0 = highest, 1 = lowest, 2 = the dense stream's
 #ifdef FFS_EXPERIMENTS
     struct Exp {
         int k1_debug = 0, chain_skip = 0, chain_stop = 0, dummy_us = 0, dummy_wg = 32, dummy_threads = 1024, dummy_lds = 0;
@@ -195,6 +198,16 @@ struct ffs_stream {
     uint32_t* d_wlog_n = nullptr;
     uint4* d_wpix = nullptr;
     size_t wlog_waves = 0;
+    // the sparse stage in small workgroups (kernels_band.hpp): what the band waves hand to the per-frame merge (allocated on first use)
+    uint4* d_band_hdr = nullptr;
+    uint8_t* d_band_acc = nullptr;
+    uint32_t* d_band_seam = nullptr;
+    uint32_t band_slots = 0;                 // (frame, band) pairs the three buffers hold
+    uint32_t band_backoff = 0;               // batches this stream still sends through k_frame_chain after a band overflowed its plan (flag 128: dense data)
+    bool bands_once_off = false;             // the next enqueue takes k_frame_chain (the batch that raised flag 128 is run again)
+    bool band_mode = false;                  // this batch's sparse stage is k_band_cc + k_frame_merge
+    uint32_t path_bits = 0;                  // which launches the last batch took (ffs_stream_last_path)
+    uint32_t reruns = 0;                     // times ffs_wait ran the last batch again (a plan that did not hold it)
     bool force_grid = false;                 // the next enqueue takes the grid-wide sparse kernels (a frame's runs overflowed the one launch)
     bool runs_overflowed = false;            // ... and dense batches of this stream keep taking them
     uint32_t *d_pack_k = nullptr, *d_pack_i = nullptr;  // a batch's lists packed end to end for another device's 3D stack

@@ -10,6 +10,7 @@
 #include "kernels_stream.hpp"
 #include "kernels_ccl.hpp"
 #include "kernels_chain.hpp"
+#include "kernels_band.hpp"
 #include "kernels_decode.hpp"
 
 bool chain_prepare_device() {   // more than 64 KB of dynamic LDS has to be asked for, per device
@@ -316,6 +317,38 @@ __global__ void k_dummy_spin(uint32_t ticks, uint32_t* sink) {
 }
 #endif
 
+// The sparse stage in small workgroups (kernels_band.hpp, tuning "sparse_bands"): can this launch geometry take it, and are the
+// buffers between its two kernels there (allocated once, for the most bands any batch of this stream can have).
+static int band_split(const ThresholdArgs& a) { return (std::max(a.band_rows, a.band_rows2) + kBandSplitRows - 1) / kBandSplitRows; }
+static bool band_stage_for(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames) {
+    ffs_ctx* c = s->ctx;
+    const uint32_t strips = (uint32_t)a.gpf / (uint32_t)kSOwned + 2u;   // strips a frame's groups can touch
+    const int sub = band_split(a), sub_rows = (std::max(a.band_rows, a.band_rows2) + sub - 1) / sub;
+    if (sub_rows > kBandMaxRows || (uint32_t)sub_rows * std::min(strips, 16u) > (uint32_t)kBandCw || a.n_bands * sub > kMergeMaxBands || c->L.W > 65535)
+        return false;
+    const uint32_t need = n_frames * (uint32_t)(a.n_bands * sub);
+    if (need > s->band_slots) {
+        uint32_t slots = need;
+        for (uint32_t nf = 1; nf <= s->max_batch; ++nf) {   // (sized once: hipFree synchronises the device -- see wave_logs_for)
+            const ThresholdArgs t = make_threshold_args(s, a.image, a.pitch, a.frame_stride, nf);
+            slots = std::max(slots, nf * (uint32_t)(t.n_bands * band_split(t)));
+        }
+        if (s->d_band_hdr) {
+            (void)hipFree(s->d_band_hdr); (void)hipFree(s->d_band_acc); (void)hipFree(s->d_band_seam);
+            s->d_band_hdr = nullptr; s->d_band_acc = nullptr; s->d_band_seam = nullptr;
+        }
+        s->band_slots = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&s->d_band_hdr), (size_t)slots * sizeof(uint4)) != hipSuccess
+            || hipMalloc(reinterpret_cast<void**>(&s->d_band_acc), (size_t)slots * kBandCompStride * sizeof(ChainAcc)) != hipSuccess
+            || hipMalloc(reinterpret_cast<void**>(&s->d_band_seam), (size_t)slots * 2 * kBandSeamCap * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        s->band_slots = slots;
+    }
+    return true;
+}
+
 // ---- one batch ------------------------------------------------------------------------------------------------------
 int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride, uint32_t n, const ffs_params* snapshot) {
     ffs_ctx* c = s->ctx;
@@ -392,7 +425,15 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
     // flight: 0.369-0.377 against 0.353 ms per step; 2 in flight: 0.385 against 0.523).
     const bool aside = streamed && s->st2 != s->st;   // the context has sparse streams: the dense stream holds streaming kernels only
     const int depth = c->inflight.load() + (s->busy ? 0 : 1);
-    const bool chain_first = list_path && aside && will_chain && c->tune.chain_first > 0 && depth <= c->tune.chain_first;
+    // The sparse stage in small workgroups (kernels_band.hpp): wave logs, nobody reads the pixel lists or the byte mask, a geometry
+    // its LDS plan holds, and the stream's recent batches did not overflow that plan.
+    const bool need_lists = p.want_strong_list || c->tune.device_lists == 1 || (c->tune.device_lists == 2 && g_live_stacks.load() > 0);
+    const bool banded = use_log && c->tune.sparse_bands != 0 && !need_lists && !ta.dense_mask && !s->bands_once_off && s->band_backoff == 0
+                        && band_stage_for(s, ta_launch, n);
+    if (use_log && s->band_backoff > 0 && !s->bands_once_off) --s->band_backoff;
+    s->band_mode = banded;
+    // (band waves fit wherever a streaming wave has left: they need no head start)
+    const bool chain_first = list_path && aside && will_chain && !banded && c->tune.chain_first > 0 && depth <= c->tune.chain_first;
     if (chain_first) {
         std::lock_guard<std::mutex> lock(c->stream_mu);   // (the newest start event cannot be re-recorded between the two lines)
         const int slot = c->chain_ev_newest.load();
@@ -476,7 +517,7 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
     ca.summary = s->d_summary;
     // (the byte mask: zero-filled by the streaming kernels only when asked for; the exact stages always produce it)
     ca.dense_bytes = ((list_path || (ext && ext_stream_first(ta))) ? ta.dense_mask : 1) ? 1 : 0;
-    ca.need_lists = (p.want_strong_list || c->tune.device_lists == 1 || (c->tune.device_lists == 2 && g_live_stacks.load() > 0)) ? 1 : 0;
+    ca.need_lists = need_lists ? 1 : 0;
     // (the launch that merges wave logs and the run-based launch of dense frames can do without the lists)
     const bool runs_launch = will_chain && !use_log && c->pixel_bytes == 2 && runs_ok && (dense_batch || c->tune.chain_runs == 2);
     s->lists_valid = !(use_log || runs_launch) || ca.need_lists != 0;
@@ -510,6 +551,8 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
     sa.zero_word = s->d_tile_counts + tile_counts_bytes(s) / 4 - 1;
 
     s->chain_mode = will_chain;
+    s->path_bits = (use_log ? FFS_PATH_WAVE_LOGS : 0u) | (will_chain && !banded ? FFS_PATH_FRAME_CHAIN : 0u) | (banded ? FFS_PATH_BANDS : 0u)
+                   | (runs_launch ? FFS_PATH_RUNS : 0u) | (!will_chain ? FFS_PATH_GRID_KERNELS : 0u) | (ext ? FFS_PATH_EXTENDED : 0u);
     if (s->chain_mode) {
         ChainArgs A{};
         A.c = ca;
@@ -536,7 +579,20 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
             // the launch's start event belongs to the context (ffs_internal.hpp); published under the lock the waiting side takes
             std::lock_guard<std::mutex> lock(c->stream_mu);
             const int slot = (int)(c->chain_ev_next.fetch_add(1) % ffs_ctx::kChainEvents);
-            if (use_log && c->pixel_bytes == 2) hipExtLaunchKernelGGL((k_frame_chain<uint16_t, false, true>), dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
+            if (banded) {
+                BandArgs BA{};
+                BA.A = A;
+                BA.hdr = s->d_band_hdr;
+                BA.acc = reinterpret_cast<ChainAcc*>(s->d_band_acc);
+                BA.seam = s->d_band_seam;
+                BA.sub = band_split(ta_launch);
+                BA.sub_rows = (std::max(ta_launch.band_rows, ta_launch.band_rows2) + BA.sub - 1) / BA.sub;
+                const dim3 gb((unsigned)(ta_launch.n_bands * BA.sub), n);
+                if (c->pixel_bytes == 2) hipExtLaunchKernelGGL(k_band_cc<uint16_t>, gb, dim3(64), 0, s->st2, c->chain_ev[slot], nullptr, 0, BA);
+                else hipExtLaunchKernelGGL(k_band_cc<uint32_t>, gb, dim3(64), 0, s->st2, c->chain_ev[slot], nullptr, 0, BA);
+                hipLaunchKernelGGL(k_frame_merge, dim3(n), dim3(kMergeThreads), 0, s->st2, BA);
+            }
+            else if (use_log && c->pixel_bytes == 2) hipExtLaunchKernelGGL((k_frame_chain<uint16_t, false, true>), dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
             else if (use_log) hipExtLaunchKernelGGL((k_frame_chain<uint32_t, false, true>), dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
             else if (c->pixel_bytes == 2 && runs_ok && (dense_batch || c->tune.chain_runs == 2)) hipExtLaunchKernelGGL((k_frame_chain<uint16_t, true>), dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
             else if (c->pixel_bytes == 2) hipExtLaunchKernelGGL(k_frame_chain<uint16_t>, dim3(n), dim3(kChainThreads), kChainDynBytes, s->st2, c->chain_ev[slot], nullptr, 0, A);
@@ -619,6 +675,7 @@ extern "C" int ffs_submit_device(ffs_stream* s, const void* device_pixels, size_
     s->dev_input = true;
     s->ev1_pending = true;
     s->first_id = first_frame_id;
+    s->reruns = 0;
     return enqueue_batch(s, device_pixels, pitch, fstride, n_frames);
 }
 
@@ -643,6 +700,7 @@ extern "C" int ffs_submit(ffs_stream* s, const void* host_pixels, uint32_t n_fra
                                 hipMemcpyHostToDevice, s->st_up));
     HIP_TRY(c, hipEventRecord(s->ev[1], s->st_up));
     s->first_id = first_frame_id;
+    s->reruns = 0;
     return enqueue_batch(s, s->d_img, L.pitch, L.frame_stride, n_frames);
 }
 
@@ -862,6 +920,7 @@ static int ffs_submit_compressed_impl(ffs_stream* s, const void* const* chunks, 
     // The rest -- block index, table copy, decode kernel and the hot path's launches -- is enqueued by a
     // helper thread, so that the caller gets its thread back while the index is built; ffs_wait joins it.
     s->first_id = first_frame_id;
+    s->reruns = 0;
     s->n_frames = n_frames;
     mark_busy(s);
     s->job_rc = FFS_OK;

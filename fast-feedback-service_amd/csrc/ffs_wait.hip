@@ -72,6 +72,19 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
             int rc = enqueue_batch(s, s->cur_img, s->cur_pitch, s->cur_fstride, s->n_frames, &s->batch_params);
             s->force_path = -1;
             if (rc != FFS_OK) return rc;
+            ++s->reruns;
+            return ffs_wait_impl(s, results, n_results);
+        }
+        if ((overflow & 128u) && !(overflow & 32u)) {
+            // a band of a frame beyond the plan of the small-workgroup sparse stage (kernels_band.hpp: strong pixels, log entries,
+            // components or seam pixels of ONE band): the batch again through the one-workgroup launch, and so the stream's next batches
+            // (data that is dense stays dense)
+            s->bands_once_off = true;
+            s->band_backoff = 32;
+            int rc = enqueue_batch(s, s->cur_img, s->cur_pitch, s->cur_fstride, s->n_frames, &s->batch_params);
+            s->bands_once_off = false;
+            if (rc != FFS_OK) return rc;
+            ++s->reruns;
             return ffs_wait_impl(s, results, n_results);
         }
         if (overflow & (32u | 64u)) {
@@ -84,6 +97,7 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
             int rc = enqueue_batch(s, s->cur_img, s->cur_pitch, s->cur_fstride, s->n_frames, &s->batch_params);
             s->plane_once = false;
             if (rc != FFS_OK) return rc;
+            ++s->reruns;
             return ffs_wait_impl(s, results, n_results);
         }
         if (overflow & 16u) {
@@ -94,6 +108,7 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
             int rc = enqueue_batch(s, s->cur_img, s->cur_pitch, s->cur_fstride, s->n_frames, &s->batch_params);
             s->force_grid = false;
             if (rc != FFS_OK) return rc;
+            ++s->reruns;
             return ffs_wait_impl(s, results, n_results);
         }
         // A frame with more strong pixels than the stream's lists hold (flag 1) or more components than its
@@ -369,6 +384,13 @@ extern "C" int ffs_stream_batch_arrays(ffs_stream* s, const ffs_box** boxes, uin
     if (n_boxes) *n_boxes = (uint32_t)s->boxes.size();
     if (refls) *refls = s->refls.data();
     if (n_refls) *n_refls = (uint32_t)s->refls.size();
+    return FFS_OK;
+}
+
+extern "C" int ffs_stream_last_path(ffs_stream* s, uint32_t* path_bits, uint32_t* reruns) {
+    if (!s) return FFS_ERR_INVALID;
+    if (path_bits) *path_bits = s->path_bits;
+    if (reruns) *reruns = s->reruns;
     return FFS_OK;
 }
 

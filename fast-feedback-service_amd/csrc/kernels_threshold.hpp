@@ -39,6 +39,26 @@ constexpr int kQCap = 64;        // lane-group queue entries per wave of the str
 // K2: exact predicate on candidates
 // ================================================================================================
 
+// The oracle's predicate on a window's exact sums (standalone.cc:165-170), shared by the gathered forms below.
+template <bool DISP_ONLY>
+__device__ __forceinline__ bool exact_decide(const ThresholdArgs& a, uint32_t m, unsigned long long sx, unsigned long long sy, uint32_t pc, bool centre_valid) {
+    // :165  mask[k] && m >= min_count && x >= 0 && src[k] > threshold
+    const double src = (double)pc;
+    if (!(centre_valid && (int)m >= a.min_count && (DISP_ONLY || src > a.threshold))) return false;
+    if (a.max_valid >= 0 && (long long)pc > a.max_valid) return false;  // GPU reference only, thresholding.cu:208-215
+    const double md = (double)m, xd = (double)sx, yd = (double)sy;
+    // :166-170, each operation rounded separately (contraction is off for this library)
+    const double t0 = md * yd;
+    const double t1 = xd * xd;
+    const double t2 = xd * (md - 1.0);
+    const double av = (t0 - t1) - t2;
+    const double bv = md * src - xd;
+    const double cv = (xd * a.nsig_b) * __builtin_sqrt(2.0 * (md - 1.0));
+    const double dv = a.nsig_s * __builtin_sqrt(xd * md);
+    if constexpr (DISP_ONLY) return av > cv;
+    return av > cv && bv > dv;
+}
+
 // Exact integer window sums + the oracle predicate, standalone.cc:113-174 operation for operation.
 // All seven window rows (pixels and mask bits) are requested before any is used, so a candidate
 // costs one memory round trip, not seven.
@@ -101,21 +121,69 @@ __device__ bool exact_strong(const ThresholdArgs& a, const uint8_t* img, int x, 
         }
     }
 
-    // :165  mask[k] && m >= min_count && x >= 0 && src[k] > threshold
-    const double src = (double)pc;
-    if (!(centre_valid && (int)m >= a.min_count && (DISP_ONLY || src > a.threshold))) return false;
-    if (a.max_valid >= 0 && (long long)pc > a.max_valid) return false;  // GPU reference only, thresholding.cu:208-215
-    const double md = (double)m, xd = (double)sx, yd = (double)sy;
-    // :166-170, each operation rounded separately (contraction is off for this library)
-    const double t0 = md * yd;
-    const double t1 = xd * xd;
-    const double t2 = xd * (md - 1.0);
-    const double av = (t0 - t1) - t2;
-    const double bv = md * src - xd;
-    const double cv = (xd * a.nsig_b) * __builtin_sqrt(2.0 * (md - 1.0));
-    const double dv = a.nsig_s * __builtin_sqrt(xd * md);
-    if constexpr (DISP_ONLY) return av > cv;
-    return av > cv && bv > dv;
+    return exact_decide<DISP_ONLY>(a, m, sx, sy, pc, centre_valid);
+}
+
+// The same decision from the same sums with HALF the registers: the window's rows come in two batches (four, then three) -- two
+// memory round trips instead of one, 16 + 4 registers of pixels and mask bits in flight instead of 28 + 7.  For callers that must
+// stay small (kernels_band.hpp: a one-wave workgroup that has to fit where a streaming wave has left).
+template <typename PixelT>
+__device__ __forceinline__ bool exact_strong_lite(const ThresholdArgs& a, const uint8_t* img, int x, int y) {
+    const int W = a.W, H = a.H;
+    const int xs = max(x - 3, 0), xe = min(x + 3, W - 1);
+    const int bx = min(xs & ~1, a.pitch_px - 8);
+    const uint32_t rm = ((1u << (xe - bx + 1)) - 1u) & ~((1u << (xs - bx)) - 1u);
+    const int sh = bx & 7;
+    uint32_t m = 0, pc = 0;
+    unsigned long long sx = 0, sy = 0;
+    bool centre_valid = false;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int r_lo = half * 4, nr = half ? 3 : 4;
+        uint4 r0[4], r1[4];
+        uint32_t mb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int yy = y - 3 + r_lo + q;
+            const bool ok = q < nr && yy >= 0 && yy < H;
+            const int yc = ok ? yy : y;
+            const uint8_t* mp = a.maskbits + (uint64_t)yc * a.mpitch + (bx >> 3);
+            uint32_t b = mp[0];
+            if (sh) b |= (uint32_t)mp[1] << 8;
+            mb[q] = ok ? b : 0u;
+            const uint8_t* rp = img + (uint64_t)yc * a.pitch + (uint64_t)bx * sizeof(PixelT);
+            r0[q] = *reinterpret_cast<const uint4*>(rp);
+            if constexpr (sizeof(PixelT) == 4) r1[q] = *reinterpret_cast<const uint4*>(rp + 16);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t p[8];
+            if constexpr (sizeof(PixelT) == 2) {
+                p[0] = r0[q].x & 0xFFFFu; p[1] = r0[q].x >> 16; p[2] = r0[q].y & 0xFFFFu; p[3] = r0[q].y >> 16;
+                p[4] = r0[q].z & 0xFFFFu; p[5] = r0[q].z >> 16; p[6] = r0[q].w & 0xFFFFu; p[7] = r0[q].w >> 16;
+            } else {
+                p[0] = r0[q].x; p[1] = r0[q].y; p[2] = r0[q].z; p[3] = r0[q].w;
+                p[4] = r1[q].x; p[5] = r1[q].y; p[6] = r1[q].z; p[7] = r1[q].w;
+            }
+            const uint32_t bits = (mb[q] >> sh) & rm;
+            if (r_lo + q == 3) {  // the candidate itself
+                const int c = x - bx;
+                centre_valid = (mb[q] >> (sh + c)) & 1u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j == c) pc = p[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool inc = ((bits >> j) & 1u) && (sizeof(PixelT) == 2 || p[j] < (1u << 24));
+                const uint32_t pv = inc ? p[j] : 0u;
+                m += inc ? 1u : 0u;
+                sx += pv;
+                sy += (unsigned long long)pv * pv;
+            }
+        }
+    }
+    return exact_decide<false>(a, m, sx, sy, pc, centre_valid);
 }
 
 // extended algorithm's final test (kernels_extended.hpp)

@@ -82,7 +82,7 @@ EXPORTS = [
     "ffs_submit_device", "ffs_ctx_device_layout", "ffs_wait", "ffs_stream_batch_arrays", "ffs_stream_timings",
     "ffs_submit_compressed", "ffs_decode_only", "ffs_stream_spot_centres", "ffs_bench_threshold", "ffs_bench_hbm", "ffs_stream_debug_planes", "ffs_stream_debug_bitplane", "ffs_selftest_sqrt", "ffs_stack3d_create",
     "ffs_stack3d_destroy", "ffs_stack3d_add_batch", "ffs_stack3d_add_slice", "ffs_stack3d_finish", "ffs_stack3d_signals", "ffs_stack3d_last_finish_ms", "ffs_multi_init", "ffs_multi_transport",
-    "ffs_ctx_set_tuning", "ffs_bench_pipeline", "ffs_device_numa_node", "ffs_stream_reserve_host",
+    "ffs_ctx_set_tuning", "ffs_bench_pipeline", "ffs_device_numa_node", "ffs_stream_reserve_host", "ffs_stream_last_path",
 ]
 
 _lib = None
@@ -119,6 +119,7 @@ def load_library():
         L.ffs_submit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_int64]
         L.ffs_wait.argtypes = [C.c_void_p, C.POINTER(C.POINTER(_FrameResult)), C.POINTER(C.c_uint32)]
         L.ffs_stream_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.ffs_stream_last_path.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.ffs_stream_batch_arrays.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
                                               C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
         L.ffs_bench_threshold.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32,
@@ -403,6 +404,14 @@ class Stream:
         t = (C.c_float * 5)()
         self.ctx._check(self._lib.ffs_stream_timings(self._h, t))
         return dict(zip(("h2d", "threshold", "ccl", "d2h", "total"), list(t)))
+
+    PATH_BITS = {"wave_logs": 1, "frame_chain": 2, "bands": 4, "runs": 8, "grid_kernels": 16, "extended": 32}
+
+    def last_path(self):
+        """ffs_stream_last_path: (set of the launches the last batch took, times ffs_wait ran it again)."""
+        bits, reruns = C.c_uint32(), C.c_uint32()
+        self.ctx._check(self._lib.ffs_stream_last_path(self._h, C.byref(bits), C.byref(reruns)))
+        return {k for k, v in self.PATH_BITS.items() if bits.value & v}, reruns.value
 
     def bench_threshold(self, dev_ptr: int, pitch_bytes: int, frame_stride_bytes: int, n_frames: int,
                         iters: int):

@@ -264,6 +264,18 @@ int ffs_stream_batch_arrays(ffs_stream *s, const ffs_box **boxes, uint32_t *n_bo
  * [3] D2H, [4] total.  (The reference prints Copy/Kernel/Post Copy/Post, spotfinder.cc:1056-1076.) */
 int ffs_stream_timings(ffs_stream *s, float ms[5]);
 
+/* Which launches the stream's last batch took -- for tests and tools that must know that the path they mean to exercise ran
+ * (results never depend on it): a mask of the bits below; *reruns = how many times ffs_wait ran the batch again because a plan
+ * did not hold it (list / component capacity, LDS forests, wave logs, band plan).  Either pointer may be NULL.
+ * (The reference has one path: spotfinder/spotfinder.cu:148-189 + the host's ConnectedComponents.) */
+#define FFS_PATH_WAVE_LOGS 1u      /* the streaming kernel's strong groups travelled in per-wave logs, not the bit plane */
+#define FFS_PATH_FRAME_CHAIN 2u    /* sparse stage: one launch, a workgroup per frame */
+#define FFS_PATH_BANDS 4u          /* sparse stage: a wave per band of a frame + a merge per frame */
+#define FFS_PATH_RUNS 8u           /* ... the one launch's forest over runs of strong pixels (dense frames) */
+#define FFS_PATH_GRID_KERNELS 16u  /* sparse stage: four grid-wide kernels */
+#define FFS_PATH_EXTENDED 32u      /* extended dispersion */
+int ffs_stream_last_path(ffs_stream *s, uint32_t *path_bits, uint32_t *reruns);
+
 /* Centres of mass of the last batch's reflections as rows (frame_id, x, y, z) of float32 -- the
  * payload of `--output-for-index` (spot_centers, spotfinder.cc:919-933,1004-1006), in frame order;
  * used to feed a multi-GPU gather without a per-frame loop on the caller's side.  Lane 0 carries the
