@@ -461,36 +461,57 @@ def bench_sweep(args, dev, local_rank):
     del host
     streams = [ctx.stream() for _ in range(4)]   # the whole sweep in flight: a batch's sparse stage runs beside the next batches' threshold kernels
     n_refl, finish_ms = 0, []
+    # self-check: every sweep's 3D reflection table (counts and digest) and every frame's strong pixels and boxes against the
+    # committed oracle results for this sweep (tests/golden/bench_workloads.npz, make_golden_bench.py --only sweep16m)
+    from ffs_amd import fixtures
+    expected = fixtures.load_expected_sweep("sweep16m")
+    check = {"sweeps": 0, "bad_sweeps": 0, "first_bad": None}
 
     def sweep():
         nonlocal n_refl
         stack = ffs_amd.Stack3D(ctx)
         inflight = []
+        ok = True
         for b in range(NZ // B + len(streams)):
             if len(inflight) == len(streams) or (b >= NZ // B and inflight):
-                s = inflight.pop(0)
-                s.wait(copy=False)
+                b0, s = inflight.pop(0)
+                s.wait_counts()
+                raw = s.last_frame_counts
+                if expected is not None:
+                    sl = slice(b0 * B, b0 * B + B)
+                    ok = ok and np.array_equal(raw["num_strong_pixels"], expected["num_strong_pixels"][sl]) and np.array_equal(raw["n_boxes"], expected["n_boxes"][sl])
                 stack.add_batch(s)
             if b < NZ // B:
                 s = streams[b % len(streams)]
                 s.submit_device(d_frames.data_ptr() + b * B * fstride, pitch, fstride, B, first_frame_id=b * B)
-                inflight.append(s)
+                inflight.append((b, s))
         refl, n_calc, fs, fp = stack.finish()
         finish_ms.append(stack.last_finish_ms())
         n_refl = len(refl)
+        if expected is not None:
+            got = (len(refl), n_calc, fs, fp)
+            want = (expected["n_reflections"], expected["n_calculated"], expected["n_filtered_size"], expected["n_filtered_sep"])
+            ok = ok and got == want and fixtures.reflections_digest(refl) == expected["digest"]
+            check["sweeps"] += 1
+            if not ok:
+                check["bad_sweeps"] += 1
+                if check["first_bad"] is None:
+                    check["first_bad"] = {"got": [int(v) for v in got], "want": [int(v) for v in want]}
         stack.close()
 
     for _ in range(max(1, args.warmup // 2)):
         sweep()
     torch.cuda.synchronize(dev)
     finish_ms.clear()
+    check.update(sweeps=0, bad_sweeps=0, first_bad=None)
     steps = max(1, args.steps // 10)
     t0 = time.perf_counter()
     for _ in range(steps):
         sweep()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    print(json.dumps({
+    results_checked = None if expected is None else bool(check["sweeps"] > 0 and check["bad_sweeps"] == 0)
+    out = {
         "metric": "detector frames/s (Eiger-16M 100-frame sweep, 2D + 3D connected components)", "value": round(steps * NZ / elapsed, 1),
         "unit": "frames/s", "n_gpus": 1, "steps": steps, "warmup": max(1, args.warmup // 2), "ms_per_step": round(elapsed / steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
@@ -498,7 +519,56 @@ def bench_sweep(args, dev, local_rank):
                                "min_spot_size 3, min_spot_size_3d 15; one step = whole sweep incl. ffs_stack3d_finish",
                    "frames_per_batch": B, "streams": len(streams), "reflections_3d": n_refl,
                    "stack3d_finish_device_ms": round(float(np.mean(finish_ms)), 3)},
-    }), flush=True)
+        "results_checked": results_checked,
+        "results_check": ({"sweeps_compared_in_the_timed_region": check["sweeps"], "bad_sweeps": check["bad_sweeps"], "first_bad": check["first_bad"],
+                           "what": "every frame's strong pixels and boxes, the 3D reflection table's counts (found, calculated, filtered by size / "
+                                   "separation) and its digest over every field",
+                           "against": "tests/golden/bench_workloads.npz (sweep16m: reference standalone.cc threshold + restated 2D / 3D connected "
+                                      "components; tests/golden/make_golden_bench.py --only sweep16m)"}
+                          if expected is not None else {"skipped": "no committed oracle results for this sweep"}),
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_sweep(p, mask, NZ)
+    print(json.dumps(out), flush=True)
+    return 0 if results_checked is not False else 6
+
+
+def cpu_baseline_sweep(p, mask, NZ, n_sample=32):
+    """The sweep's CPU path on this box's host cores, on a bounded sample: the first `n_sample` frames of the sweep through the
+    reference's standalone.cc threshold (oracle/_ref; else the restatement) + the oracle's 2D components, one frame per thread on
+    16 threads (the reference's threading model, spotfinder/spotfinder.cc:725-752), then the oracle's 3D labelling of those slices
+    on one thread (the reference labels after all frames, serially: connected_components.cc:270-470)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from ffs_amd import synth
+    from oracle import oracle as O
+    H, W = mask.shape
+    hi = host_info()
+    cores = max(1, min(hi["affinity_cores"], int(os.environ.get("FFS_BENCH_CPU_THREADS", "16"))))
+    frames = synth.frames(p, range(n_sample), threads=cores)
+    kind = "reference" if O.have_ref() else "port"
+
+    def worker(idx_list):   # (one spot-finder object per thread, as cpu_baseline's: its tables are allocated once)
+        sf = O.RefSpotfinder(W, H) if kind == "reference" else O.PortSpotfinder(W, H)
+        dst = np.empty((H, W), np.uint8)
+        out = []
+        for i in idx_list:
+            sf.run_f64(frames[i].astype(np.float64), mask, dst)      # the reference converts too (spotfinder.cc:1024)
+            cc = O.cc2d(dst, frames[i], 3)
+            out.append((i, cc.k, cc.intensity))
+        return out
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        parts = list(ex.map(worker, [list(range(c, n_sample, cores)) for c in range(cores)]))
+    slices = [(k, it) for _, k, it in sorted((r for part in parts for r in part), key=lambda r: r[0])]
+    t1 = time.perf_counter()
+    want = O.cc3d(slices, W, H, 15, 2.0)
+    t2 = time.perf_counter()
+    return {"value": round(n_sample / (t2 - t0), 3), "unit": "frames/s", "cores": cores, "kind": kind, "nproc": hi["affinity_cores"],
+            "cpu_model": hi["cpu_model"], "host_cores": hi["nproc"],
+            "frames_2d_s": round(t1 - t0, 3), "labelling_3d_s": round(t2 - t1, 3), "reflections_3d_in_sample": int(len(want.reflections)),
+            "sample": f"the first {n_sample} of the sweep's {NZ} frames: threshold = " + ("reference baseline/spotfinder/standalone.cc (oracle/_ref)" if kind == "reference" else "oracle port")
+                      + f" + oracle 2D components, one frame per thread on {cores} threads, then the oracle's 3D labelling of the {n_sample} slices on one thread; "
+                      + f"{t2 - t0:.1f} s wall (the host shows {hi['nproc']} cores)"}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -895,31 +965,33 @@ def main():
             flush_gather()
 
     strong_px = 0
+    # Duration of every batch's threshold stage inside the timed regions, from the HIP events that ride on ITS dispatch (the stream's
+    # own start / stop events of the streaming kernel: ffs_stream_timings): the kernel as it runs in the pipeline, beside the other
+    # batches' sparse launches -- what `rocprofv3 --kernel-trace --stats` of this command averages too.
+    thr_ms = []
+
+    def reap(done):
+        nonlocal strong_px
+        _, nbx, nst = done.wait_counts()      # (every frame's boxes and centroids are in the library's host arrays)
+        check_counts(done)
+        thr_ms.append(done.timings()["threshold"])
+        gather(None, done)
+        strong_px += nst
+        return nbx
 
     def run_steps(k):
         """k steps, `streams` batches in flight"""
         inflight = []
         spots = 0
-        nonlocal strong_px
         for step in range(k + len(streams)):
             if step < k:
                 s = streams[step % len(streams)]
                 if len(inflight) == len(streams):
-                    done = inflight.pop(0)
-                    _, nbx, nst = done.wait_counts()      # (every frame's boxes and centroids are in the library's host arrays)
-                    check_counts(done)
-                    gather(None, done)
-                    spots += nbx
-                    strong_px += nst
+                    spots += reap(inflight.pop(0))
                 s.submit_device(ptr, pitch, fstride, B, first_frame_id=(rank * k + step) * B)
                 inflight.append(s)
             elif inflight:
-                done = inflight.pop(0)
-                _, nbx, nst = done.wait_counts()
-                check_counts(done)
-                gather(None, done)
-                spots += nbx
-                strong_px += nst
+                spots += reap(inflight.pop(0))
         flush_gather(last=True)          # every frame's spots are gathered before the clock stops
         return spots
 
@@ -942,6 +1014,7 @@ def main():
         return el, sp
 
     run_steps(args.warmup)
+    thr_ms.clear()
     # `reps` repetitions of the same `steps`-step region: the timed region is a few ms, one slow dispatch moves a single
     # repetition by several per cent -- `value` is the median repetition
     times = []
@@ -954,6 +1027,7 @@ def main():
     elapsed = statistics.median(times)
     # the fixed tail of a run (the last batches' sparse launches drain after the last streaming kernel), made visible:
     # steady = (T(2K) - T(K)) / K, drain = T(K) - K steady
+    thr_timed = list(thr_ms)          # (the batches of the `reps` timed regions)
     el2, _ = timed(2 * args.steps)
     steady = max(0.0, (el2 - elapsed) / args.steps)
     drain = max(0.0, elapsed - steady * args.steps)
@@ -990,6 +1064,13 @@ def main():
         ms_dense, _ = streams[0].bench_threshold(ptr, pitch, fstride, B, iters=10)
         ctx.set_params(want_reflections=1, algorithm=0, want_strong_mask=0)
     alg_bytes = float(W) * H * bytes_per_px * B
+    # The kernel's duration for the roofline: standard algorithm = the average over every batch of the timed regions, each from the
+    # events on its own dispatch (the contract: "average launch duration, measured live with HIP events over the timed region");
+    # `ms_alone` = the same kernel launched alone in a loop (ffs_bench_threshold: each launch behind the fills that reset the
+    # stream's planes, i.e. on cold mask tables).  Extended algorithm: its first pass alone (the stage's events span three kernels).
+    ms_alone = ms_cand
+    if not ext and thr_timed:
+        ms_cand = float(sum(thr_timed) / len(thr_timed))
     achieved = alg_bytes / (ms_cand * 1e-3) / 1e9
     tm = streams[0].timings()
     traffic, traffic_src = pmc_traffic(args.workload + ("_extended" if ext else ""), B)
@@ -1120,6 +1201,10 @@ def main():
                          "kernel": ("k_stream_u16<2,true> (extended first pass)" if ext else
                                     "k_stream_u16 (whole threshold stage)" if dt == np.uint16 else "k_stream_u32 (whole threshold stage)"),
                          "ms_per_launch": round(ms_cand, 4),
+                         "ms_per_launch_from": (f"mean over the {len(thr_timed)} batches of the timed regions, each from the HIP events on its own dispatch "
+                                                "(in the pipeline, beside the other batches' sparse launches)" if (not ext and thr_timed) else
+                                                "ffs_bench_threshold: the kernel launched alone, 10 launches"),
+                         "ms_per_launch_alone": round(ms_alone, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "exact_kernel_ms_per_launch": round(ms_exact, 4),
                          "dense_mask": False,

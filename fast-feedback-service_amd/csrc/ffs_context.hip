@@ -48,6 +48,7 @@ static void on_process_exit() {
             if (s->job.joinable()) s->job.join();
         if (hipSetDevice(c->device) == hipSuccess) (void)hipDeviceSynchronize();
         (void)hipGetLastError();
+        ahead_stop(c, false);   // (behind the drain: the thread may be waiting for a batch's last event)
         if (AssemblyPool* pool = c->assembly.load(std::memory_order_acquire)) pool->stop_and_join();
     }
 }
@@ -305,6 +306,7 @@ extern "C" void ffs_ctx_destroy(ffs_ctx* c) {
 
 static void ctx_destroy_internal(ffs_ctx* c) {
     (void)hipSetDevice(c->device);
+    ahead_stop(c, true);
     for (auto* st : c->stack_pool) stack3d_free(st);
     c->stack_pool.clear();
     if (AssemblyPool* pool = c->assembly.exchange(nullptr)) {
@@ -421,6 +423,7 @@ extern "C" int ffs_ctx_set_tuning(ffs_ctx* c, const char* key, long long value) 
     else if (k == "device_lists") { if ((ok = in(0, 2))) t.device_lists = (int)value; }
     else if (k == "strong_log") { if ((ok = in(0, 1))) t.strong_log = (int)value; }
     else if (k == "chain_runs") { if ((ok = in(0, 2))) t.chain_runs = (int)value; }
+    else if (k == "wait_ahead") { if ((ok = in(0, 1))) t.wait_ahead = (int)value; }
     else if (k == "sparse_bands") { if ((ok = in(0, 1))) t.sparse_bands = (int)value; }
     else if (k == "sparse_priority") {
         // priority of the context's two sparse HIP streams: 0 = highest (default), 1 = lowest, 2 = the dense stream's; before the first stream is created
@@ -480,6 +483,7 @@ extern "C" void ffs_stream_destroy(ffs_stream* s) {
 void stream_destroy_internal(ffs_stream* s) {
     (void)hipSetDevice(s->ctx->device);
     if (s->job.joinable()) s->job.join();
+    (void)ahead_take(s);   // (a batch in flight that the context's own thread is assembling: let it finish with the stream)
     mark_idle(s);   // (a stream may be closed with its batch still in flight)
 #ifdef FFS_EXPERIMENTS
     if (s->phase_n) {

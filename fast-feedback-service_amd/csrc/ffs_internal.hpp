@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <new>
@@ -95,6 +96,7 @@ struct Tuning {
                                 //    (16-bit pixels, rows up to 16383 pixels); 0 = such batches take the four grid-wide kernels; 2 = runs for every frame
     int sparse_bands = 1;       // standard path with wave logs, lists not asked for: the sparse stage in small workgroups (kernels_band.hpp: a wave per
                                 //    band of a frame + a merge per frame) instead of k_frame_chain's one workgroup per frame; 0 = k_frame_chain
+    int wait_ahead = 1;         // a thread of the context assembles each batch's result arrays as soon as the GPU has finished it (0: ffs_wait does)
     int sparse_priority = 0;    // priority of the context's sparse HIP streams: 0 = highest, 1 = lowest, 2 = the dense stream's
 #ifdef FFS_EXPERIMENTS
     struct Exp {
@@ -139,6 +141,18 @@ struct PinnedBuf {
 PinnedBuf pinned_alloc(size_t bytes);   // p == nullptr on failure
 void pinned_free(PinnedBuf& b);
 
+// One thread per context that assembles the results of the context's batches as the GPU finishes them (ffs_wait.hip): ffs_wait then
+// finds a batch's arrays ready instead of spending 0.1-0.2 ms on them -- which the waits at the END of a run, one behind the other
+// with nothing left to hide them, paid on the clock.  Only batches that need nothing else from the host (no overflow, no list or
+// mask copies); everything else is left to the caller's ffs_wait as before.
+struct AheadThread {
+    std::thread th;
+    std::mutex mu;                 // guards q, stop and every stream's ahead_state
+    std::condition_variable cv_work, cv_done;
+    std::deque<ffs_stream*> q;     // registered batches, in submit order
+    bool stop = false;
+};
+
 struct ffs_ctx {
     int device = 0;
     Tuning tune;
@@ -176,6 +190,7 @@ struct ffs_ctx {
     std::atomic<int> chain_ev_newest{-1};       // slot of the newest recorded start, -1: none yet
     bool chain_ok = false;           // k_frame_chain may use its dynamic LDS on this device
     std::atomic<AssemblyPool*> assembly{nullptr};   // helper threads of ffs_wait (created on first use under stream_mu; read without it)
+    std::atomic<AheadThread*> ahead{nullptr};       // assembles results as batches complete (created on first use under stream_mu)
     ThreadError err;  // the calling thread's most recent error on any context
 };
 
@@ -299,6 +314,13 @@ struct ffs_stream {
     unsigned long long phase_n = 0;
 #endif
     std::vector<float> centres;   // (frame id bits, com_x, com_y, com_z) per reflection of the last batch, filled with `refls` (ffs_stream_spot_centres)
+    // the same four for the batch in flight, filled by the context's AheadThread and swapped in by ffs_wait (what the last ffs_wait
+    // returned stays valid until the next one)
+    std::vector<ffs_frame_result> results_n;
+    std::vector<ffs_box> boxes_n;
+    std::vector<ffs_reflection> refls_n;
+    std::vector<float> centres_n;
+    int ahead_state = 0;          // 0: not registered, 1: queued / being assembled, 2: assembled into the *_n arrays, 3: left to the caller (AheadThread::mu)
 };
 
 // Results of a frame that did not fit the stream's lists, from its re-run on the one-frame stream
@@ -397,5 +419,8 @@ void bench_launch_dense(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames
 void bench_launch_rest(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames);
 // ffs_wait.hip
 int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_results);
+void ahead_register(ffs_stream* s);   // the batch just enqueued may be assembled ahead of its ffs_wait
+int ahead_take(ffs_stream* s);        // waits for the AheadThread to be done with the stream's batch; its verdict (0, 2 or 3), state reset
+void ahead_stop(ffs_ctx* c, bool destroy);   // the thread leaves and is joined (context destroy, process exit)
 // ffs_stack3d.hip
 void stack3d_free(ffs_stack3d* st);

@@ -676,7 +676,9 @@ extern "C" int ffs_submit_device(ffs_stream* s, const void* device_pixels, size_
     s->ev1_pending = true;
     s->first_id = first_frame_id;
     s->reruns = 0;
-    return enqueue_batch(s, device_pixels, pitch, fstride, n_frames);
+    rc = enqueue_batch(s, device_pixels, pitch, fstride, n_frames);
+    if (rc == FFS_OK) ahead_register(s);
+    return rc;
 }
 
 extern "C" int ffs_submit(ffs_stream* s, const void* host_pixels, uint32_t n_frames, int64_t first_frame_id) {
@@ -701,7 +703,9 @@ extern "C" int ffs_submit(ffs_stream* s, const void* host_pixels, uint32_t n_fra
     HIP_TRY(c, hipEventRecord(s->ev[1], s->st_up));
     s->first_id = first_frame_id;
     s->reruns = 0;
-    return enqueue_batch(s, s->d_img, L.pitch, L.frame_stride, n_frames);
+    const int rc = enqueue_batch(s, s->d_img, L.pitch, L.frame_stride, n_frames);
+    if (rc == FFS_OK) ahead_register(s);
+    return rc;
 }
 
 
@@ -953,6 +957,7 @@ static int ffs_submit_compressed_impl(ffs_stream* s, const void* const* chunks, 
             if (r != FFS_OK) s->job_err = c->err;
         }
         s->job_rc = r;
+        if (r == FFS_OK) ahead_register(s);
     });
     return FFS_OK;
 }

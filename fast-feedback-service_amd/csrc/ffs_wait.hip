@@ -13,6 +13,279 @@ static int ensure_list_host(ffs_stream* s) {
     return FFS_OK;
 }
 
+// Turns the batch's wire records and summaries (pinned host memory, complete) into the arrays ffs_wait hands out.  Runs on the
+// caller's thread inside ffs_wait, or ahead of it on the context's AheadThread (then into the stream's *_n arrays).
+// `ovf`: the frames of this batch that were run again on the one-frame stream (only ffs_wait's own path has any).
+static int assemble_batch(ffs_stream* s, uint64_t total_recs, const std::vector<OverflowFrame>* ovf, std::vector<ffs_frame_result>& out_results,
+                          std::vector<ffs_box>& out_boxes, std::vector<ffs_reflection>& out_refls, std::vector<float>& out_centres) {
+    ffs_ctx* c = s->ctx;
+    const uint32_t n = s->n_frames;
+    const size_t B = s->max_batch;
+    const Layout& L = c->L;
+    const ffs_params& p = s->batch_params;
+    const uint32_t* h_ns = s->h_counts;
+    const uint32_t* h_nc = s->h_counts + B;
+    const uint32_t* h_sm = s->h_counts + 2 * B;
+    auto overflow_frame = [&](uint32_t f) -> const OverflowFrame* {
+        if (ovf)
+            for (const OverflowFrame& o : *ovf)
+                if (o.frame == f) return &o;
+        return nullptr;
+    };
+    // assemble: boxes = components surviving the min-size filter (connected_components.cc:122-135),
+    // reflections = components surviving filter_reflections (:207-236); both keep label order.
+    // (written through raw pointers into arrays sized for the worst case: 45 000 records per batch of the bench frames, and the
+    // last wait of a run does this on the clock -- push_back's capacity check per record was a third of it)
+    out_results.assign(n, ffs_frame_result{});
+    const uint32_t min_size = p.min_spot_size;
+    const bool want_refl = p.want_reflections != 0;
+    // Where each frame's boxes / reflections / records lie follows from the per-frame summaries the sparse stage wrote (boxes =
+    // summary[0], reflections = summary[2]; a frame that was re-run on the one-frame stream: what that run returned), so the
+    // frames can be assembled independently -- by the caller and the context's helper threads (AssemblyPool) when the batch is large.
+    std::vector<size_t> box_at(n + 1), refl_at(n + 1), rec_at(n);
+    {
+        size_t nb = 0, nr = 0, at = 0;
+        for (uint32_t f = 0; f < n; ++f) {
+            box_at[f] = nb;
+            refl_at[f] = nr;
+            const uint32_t nc = std::min<uint32_t>(h_nc[f], s->max_comp);
+            rec_at[f] = s->chain_mode ? (size_t)f * s->max_comp : at;   // k_frame_chain: every frame has its own record area
+            at += nc;
+            if (const OverflowFrame* o = overflow_frame(f)) {
+                nb += o->boxes.size();
+                nr += want_refl ? o->refls.size() : 0;
+            } else {
+                nb += h_sm[(size_t)f * 8 + 0];
+                nr += want_refl ? h_sm[(size_t)f * 8 + 2] : 0;
+            }
+        }
+        box_at[n] = nb;
+        refl_at[n] = nr;
+    }
+    out_boxes.resize(box_at[n]);
+    out_refls.resize(refl_at[n]);
+    // the centres as (frame id, x, y, z) rows, written while each record is in hand: ffs_stream_spot_centres hands them out with one
+    // memcpy (walking the 72-byte reflections again cost a caller 0.3 ms per batch of 45 000 -- as long as the GPU takes for the batch)
+    out_centres.resize(refl_at[n] * 4);
+    ffs_box* const bo = out_boxes.data();
+    ffs_reflection* const ro = out_refls.data();
+    float* const co = out_centres.data();
+    const WireRec2* const recs0 = reinterpret_cast<const WireRec2*>(s->h_recs);
+    std::atomic<bool> consistent{true};
+    const std::function<void(uint32_t)> assemble = [&](uint32_t f) {
+        size_t nbx = box_at[f], nrf = refl_at[f];
+        const uint32_t id_bits = (uint32_t)((uint64_t)(s->first_id + f) & 0xFFFFFFFFull);   // (a bit pattern: as a float VALUE ids collide from 2^24 on)
+        float id_lane;
+        std::memcpy(&id_lane, &id_bits, 4);
+        if (const OverflowFrame* o = overflow_frame(f)) {  // re-run on the one-frame stream: its cut records are skipped
+            for (const ffs_box& b : o->boxes) bo[nbx++] = b;
+            if (want_refl)
+                for (const ffs_reflection& r : o->refls) {
+                    co[4 * nrf] = id_lane; co[4 * nrf + 1] = r.com_x; co[4 * nrf + 2] = r.com_y; co[4 * nrf + 3] = r.com_z;
+                    ro[nrf++] = r;
+                }
+            return;
+        }
+        const uint32_t nc = std::min<uint32_t>(h_nc[f], s->max_comp);
+        const WireRec2* wrec = recs0 + rec_at[f];
+        const size_t box_end = box_at[f + 1], refl_end = refl_at[f + 1];
+        for (uint32_t q = 0; q < nc; ++q, ++wrec) {
+            const uint32_t npx = wrec->npx_flags & 0x3FFFFFFFu, flags = wrec->npx_flags >> 30;
+            if (min_size == 0 || npx >= min_size) {
+                if (nbx >= box_end) { consistent = false; return; }   // (never: the summary counts what this loop counts)
+                bo[nbx++] = ffs_box{wrec->x_min, wrec->y_min, wrec->x_max, wrec->y_max, (int32_t)npx};
+            }
+            if (want_refl && flags == 0) {
+                if (nrf >= refl_end) { consistent = false; return; }
+                ffs_reflection r{};
+                r.x_min = wrec->x_min; r.x_max = wrec->x_max; r.y_min = wrec->y_min; r.y_max = wrec->y_max;
+                r.z_min = 0; r.z_max = 0;
+                r.num_pixels = (int32_t)npx;
+                r.com_x = wrec->com_x; r.com_y = wrec->com_y; r.com_z = 0.5f;  // z = 0 for a single frame
+                r.peak_x = wrec->peak_x; r.peak_y = wrec->peak_y; r.peak_z = 0;
+                r.peak_intensity = wrec->peak_intensity;
+                r.peak_centroid_distance = wrec->peak_centroid_distance;
+                r.flags = 0;
+                r.sum_intensity = wrec->sum_intensity;
+                co[4 * nrf] = id_lane; co[4 * nrf + 1] = r.com_x; co[4 * nrf + 2] = r.com_y; co[4 * nrf + 3] = 0.5f;
+                ro[nrf++] = r;
+            }
+        }
+        if (nbx != box_end || nrf != refl_end) consistent = false;
+    };
+    // assemble: boxes = components surviving the min-size filter (connected_components.cc:122-135),
+    // reflections = components surviving filter_reflections (:207-236); both keep label order.
+    bool pooled = false;
+    if (total_recs >= 8192 && n >= 4) {
+        AssemblyPool* pool = c->assembly.load(std::memory_order_acquire);
+        if (!pool && !process_exiting()) {
+            std::lock_guard<std::mutex> lock(c->stream_mu);
+            pool = c->assembly.load(std::memory_order_acquire);
+            if (!pool) {
+                pool = new (std::nothrow) AssemblyPool();
+                if (pool) {
+                    try {
+                        pool->start(3);
+                    } catch (...) {   // (no more threads to be had: whatever did start is joined, and this wait assembles on its own)
+                        delete pool;
+                        pool = nullptr;
+                    }
+                }
+                if (pool) c->assembly.store(pool, std::memory_order_release);   // (published with its members built and its threads started)
+            }
+        }
+        if (pool && pool->owner.try_lock()) {   // (another stream's wait has the helpers: assemble here)
+            pool->run(n, assemble);
+            pool->owner.unlock();
+            pooled = true;
+        }
+    }
+    if (!pooled)
+        for (uint32_t f = 0; f < n; ++f) assemble(f);
+    if (!consistent.load()) return FFS_ERR_DEVICE;   // (the caller words the error: this may run on the context's own thread)
+    for (uint32_t f = 0; f < n; ++f) {
+        ffs_frame_result& r = out_results[f];
+        const uint32_t* sm = h_sm + (size_t)f * 8;
+        r.frame_id = s->first_id + f;
+        r.num_strong_pixels = h_ns[f];
+        r.num_strong_pixels_filtered = sm[1];
+        r.n_components = h_nc[f];
+        r.n_boxes = sm[0];
+        r.boxes = out_boxes.data() + box_at[f];
+        r.n_reflections = p.want_reflections ? sm[2] : 0;
+        r.reflections = p.want_reflections ? out_refls.data() + refl_at[f] : nullptr;
+        r.n_filtered_size = sm[3];
+        r.n_filtered_sep = sm[4];
+        if (p.want_strong_list) {
+            r.strong_k = s->h_list_k ? s->h_list_k + (size_t)f * s->cap : nullptr;
+            r.strong_intensity = s->h_list_i ? s->h_list_i + (size_t)f * s->cap : nullptr;
+        }
+        if (p.want_strong_mask) r.strong_mask = s->h_mask + (size_t)f * L.W * L.H;
+        if (const OverflowFrame* o = overflow_frame(f)) {
+            const ffs_frame_result& b = o->res;
+            r.num_strong_pixels = b.num_strong_pixels;
+            r.num_strong_pixels_filtered = b.num_strong_pixels_filtered;
+            r.n_components = b.n_components;
+            r.n_boxes = b.n_boxes;
+            r.n_reflections = p.want_reflections ? b.n_reflections : 0;
+            r.n_filtered_size = b.n_filtered_size;
+            r.n_filtered_sep = b.n_filtered_sep;
+            if (p.want_strong_list) {
+                r.strong_k = o->k.data();
+                r.strong_intensity = o->inten.data();
+            }
+        }
+    }
+    return FFS_OK;
+}
+
+// ---- assembly ahead of ffs_wait (ffs_internal.hpp: AheadThread) ------------------------------------------------------------------
+static void ahead_main(ffs_ctx* c) {
+    AheadThread* A = c->ahead.load(std::memory_order_acquire);
+    (void)hipSetDevice(c->device);
+    for (;;) {
+        ffs_stream* s = nullptr;
+        {
+            std::unique_lock<std::mutex> lock(A->mu);
+            A->cv_work.wait(lock, [&] { return A->stop || !A->q.empty(); });
+            if (A->q.empty()) return;   // (stop: what is still queued is left to its ffs_wait, below)
+            s = A->q.front();
+            A->q.pop_front();
+        }
+        int verdict = 3;
+        try {
+            const ffs_params& p = s->batch_params;
+            if (hipEventSynchronize(s->ev[4]) == hipSuccess && !p.want_strong_list && !p.want_strong_mask && s->direct_recs) {
+                const uint32_t n = s->n_frames;
+                const size_t B = s->max_batch;
+                uint32_t overflow = s->h_counts[10 * B];
+                if (s->chain_mode) {
+                    overflow = 0;
+                    for (uint32_t f = 0; f < n; ++f) overflow |= s->h_counts[10 * B + 1 + f];
+                }
+                if (overflow == 0) {
+                    uint64_t total_recs = 0;
+                    for (uint32_t f = 0; f < n; ++f) total_recs += std::min<uint32_t>(s->h_counts[B + f], s->max_comp);
+                    if (assemble_batch(s, total_recs, nullptr, s->results_n, s->boxes_n, s->refls_n, s->centres_n) == FFS_OK) verdict = 2;
+                }
+            } else {
+                (void)hipGetLastError();
+            }
+        } catch (...) {
+            verdict = 3;   // (out of memory while the arrays grew: the caller's ffs_wait tries again and reports it)
+        }
+        {
+            std::lock_guard<std::mutex> lock(A->mu);
+            s->ahead_state = verdict;
+        }
+        A->cv_done.notify_all();
+    }
+}
+
+void ahead_register(ffs_stream* s) {
+    ffs_ctx* c = s->ctx;
+    if (!c->tune.wait_ahead || process_exiting()) return;
+#ifdef FFS_EXPERIMENTS
+    if (s->h_phase_ts) return;   // (the phase times of the sparse launch are summed up by ffs_wait's own path)
+#endif
+    AheadThread* A = c->ahead.load(std::memory_order_acquire);
+    if (!A) {
+        std::lock_guard<std::mutex> lock(c->stream_mu);
+        A = c->ahead.load(std::memory_order_acquire);
+        if (!A) {
+            A = new (std::nothrow) AheadThread();
+            if (!A) return;
+            c->ahead.store(A, std::memory_order_release);
+            try {
+                A->th = std::thread(ahead_main, c);
+            } catch (...) {   // (no thread to be had: ffs_wait assembles, as before)
+                c->ahead.store(nullptr, std::memory_order_release);
+                delete A;
+                return;
+            }
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lock(A->mu);
+        if (A->stop) return;
+        s->ahead_state = 1;
+        A->q.push_back(s);
+    }
+    A->cv_work.notify_one();
+}
+
+int ahead_take(ffs_stream* s) {
+    AheadThread* A = s->ctx->ahead.load(std::memory_order_acquire);
+    if (!A) return 0;
+    std::unique_lock<std::mutex> lock(A->mu);
+    if (s->ahead_state == 1 && A->stop) {   // the thread has left (process exit): take the batch back if it is still queued
+        for (auto it = A->q.begin(); it != A->q.end(); ++it)
+            if (*it == s) { A->q.erase(it); s->ahead_state = 3; break; }
+    }
+    A->cv_done.wait(lock, [&] { return s->ahead_state != 1; });
+    const int v = s->ahead_state;
+    s->ahead_state = 0;
+    return v;
+}
+
+void ahead_stop(ffs_ctx* c, bool destroy) {
+    AheadThread* A = c->ahead.load(std::memory_order_acquire);
+    if (!A) return;
+    {
+        std::lock_guard<std::mutex> lock(A->mu);
+        A->stop = true;
+        for (ffs_stream* s : A->q) s->ahead_state = 3;   // (still queued: their ffs_wait does the work)
+        A->q.clear();
+    }
+    A->cv_work.notify_all();
+    A->cv_done.notify_all();
+    if (A->th.joinable()) A->th.join();
+    if (destroy) {
+        c->ahead.store(nullptr, std::memory_order_release);
+        delete A;
+    }
+}
+
 int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_results) {
     if (!s) return FFS_ERR_INVALID;
     ffs_ctx* c = s->ctx;
@@ -30,6 +303,20 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
             return s->job_rc;
         }
     }
+    if (ahead_take(s) == 2) {
+        // the context's own thread has assembled this batch behind its last event: its arrays become the stream's
+        s->results.swap(s->results_n);
+        s->boxes.swap(s->boxes_n);
+        s->refls.swap(s->refls_n);
+        s->centres.swap(s->centres_n);
+        s->ovf.clear();
+        mark_idle(s);
+        s->timing_last = s->ev[4];
+        s->timings_stale = true;
+        if (results) *results = s->results.data();
+        if (n_results) *n_results = s->n_frames;
+        return FFS_OK;
+    }
     HIP_TRY(c, hipEventSynchronize(s->ev[4]));
     const uint32_t n = s->n_frames;
     const size_t B = s->max_batch;
@@ -37,7 +324,6 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
     const ffs_params& p = s->batch_params;
     const uint32_t* h_ns = s->h_counts;
     const uint32_t* h_nc = s->h_counts + B;
-    const uint32_t* h_sm = s->h_counts + 2 * B;
     uint32_t overflow = s->h_counts[10 * B];
     if (s->chain_mode) {  // k_frame_chain: one flag word per frame
         overflow = 0;
@@ -176,11 +462,6 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
             }
         }
     }
-    auto overflow_frame = [&](uint32_t f) -> const OverflowFrame* {
-        for (const OverflowFrame& o : s->ovf)
-            if (o.frame == f) return &o;
-        return nullptr;
-    };
     uint64_t total_recs = 0;
     uint32_t max_ns = 0;
     for (uint32_t f = 0; f < n; ++f) {
@@ -225,151 +506,11 @@ int ffs_wait_impl(ffs_stream* s, const ffs_frame_result** results, uint32_t* n_r
     s->timing_last = last;
     s->timings_stale = true;
 
-    // assemble: boxes = components surviving the min-size filter (connected_components.cc:122-135),
-    // reflections = components surviving filter_reflections (:207-236); both keep label order.
-    // (written through raw pointers into arrays sized for the worst case: 45 000 records per batch of the bench frames, and the
-    // last wait of a run does this on the clock -- push_back's capacity check per record was a third of it)
-    s->results.assign(n, ffs_frame_result{});
-    const uint32_t min_size = p.min_spot_size;
-    const bool want_refl = p.want_reflections != 0;
-    // Where each frame's boxes / reflections / records lie follows from the per-frame summaries the sparse stage wrote (boxes =
-    // summary[0], reflections = summary[2]; a frame that was re-run on the one-frame stream: what that run returned), so the
-    // frames can be assembled independently -- by the caller and the context's helper threads (AssemblyPool) when the batch is large.
-    std::vector<size_t> box_at(n + 1), refl_at(n + 1), rec_at(n);
     {
-        size_t nb = 0, nr = 0, at = 0;
-        for (uint32_t f = 0; f < n; ++f) {
-            box_at[f] = nb;
-            refl_at[f] = nr;
-            const uint32_t nc = std::min<uint32_t>(h_nc[f], s->max_comp);
-            rec_at[f] = s->chain_mode ? (size_t)f * s->max_comp : at;   // k_frame_chain: every frame has its own record area
-            at += nc;
-            if (const OverflowFrame* o = overflow_frame(f)) {
-                nb += o->boxes.size();
-                nr += want_refl ? o->refls.size() : 0;
-            } else {
-                nb += h_sm[(size_t)f * 8 + 0];
-                nr += want_refl ? h_sm[(size_t)f * 8 + 2] : 0;
-            }
-        }
-        box_at[n] = nb;
-        refl_at[n] = nr;
-    }
-    s->boxes.resize(box_at[n]);
-    s->refls.resize(refl_at[n]);
-    // the centres as (frame id, x, y, z) rows, written while each record is in hand: ffs_stream_spot_centres hands them out with one
-    // memcpy (walking the 72-byte reflections again cost a caller 0.3 ms per batch of 45 000 -- as long as the GPU takes for the batch)
-    s->centres.resize(refl_at[n] * 4);
-    ffs_box* const bo = s->boxes.data();
-    ffs_reflection* const ro = s->refls.data();
-    float* const co = s->centres.data();
-    const WireRec2* const recs0 = reinterpret_cast<const WireRec2*>(s->h_recs);
-    std::atomic<bool> consistent{true};
-    const std::function<void(uint32_t)> assemble = [&](uint32_t f) {
-        size_t nbx = box_at[f], nrf = refl_at[f];
-        const uint32_t id_bits = (uint32_t)((uint64_t)(s->first_id + f) & 0xFFFFFFFFull);   // (a bit pattern: as a float VALUE ids collide from 2^24 on)
-        float id_lane;
-        std::memcpy(&id_lane, &id_bits, 4);
-        if (const OverflowFrame* o = overflow_frame(f)) {  // re-run on the one-frame stream: its cut records are skipped
-            for (const ffs_box& b : o->boxes) bo[nbx++] = b;
-            if (want_refl)
-                for (const ffs_reflection& r : o->refls) {
-                    co[4 * nrf] = id_lane; co[4 * nrf + 1] = r.com_x; co[4 * nrf + 2] = r.com_y; co[4 * nrf + 3] = r.com_z;
-                    ro[nrf++] = r;
-                }
-            return;
-        }
-        const uint32_t nc = std::min<uint32_t>(h_nc[f], s->max_comp);
-        const WireRec2* wrec = recs0 + rec_at[f];
-        const size_t box_end = box_at[f + 1], refl_end = refl_at[f + 1];
-        for (uint32_t q = 0; q < nc; ++q, ++wrec) {
-            const uint32_t npx = wrec->npx_flags & 0x3FFFFFFFu, flags = wrec->npx_flags >> 30;
-            if (min_size == 0 || npx >= min_size) {
-                if (nbx >= box_end) { consistent = false; return; }   // (never: the summary counts what this loop counts)
-                bo[nbx++] = ffs_box{wrec->x_min, wrec->y_min, wrec->x_max, wrec->y_max, (int32_t)npx};
-            }
-            if (want_refl && flags == 0) {
-                if (nrf >= refl_end) { consistent = false; return; }
-                ffs_reflection r{};
-                r.x_min = wrec->x_min; r.x_max = wrec->x_max; r.y_min = wrec->y_min; r.y_max = wrec->y_max;
-                r.z_min = 0; r.z_max = 0;
-                r.num_pixels = (int32_t)npx;
-                r.com_x = wrec->com_x; r.com_y = wrec->com_y; r.com_z = 0.5f;  // z = 0 for a single frame
-                r.peak_x = wrec->peak_x; r.peak_y = wrec->peak_y; r.peak_z = 0;
-                r.peak_intensity = wrec->peak_intensity;
-                r.peak_centroid_distance = wrec->peak_centroid_distance;
-                r.flags = 0;
-                r.sum_intensity = wrec->sum_intensity;
-                co[4 * nrf] = id_lane; co[4 * nrf + 1] = r.com_x; co[4 * nrf + 2] = r.com_y; co[4 * nrf + 3] = 0.5f;
-                ro[nrf++] = r;
-            }
-        }
-        if (nbx != box_end || nrf != refl_end) consistent = false;
-    };
-    // assemble: boxes = components surviving the min-size filter (connected_components.cc:122-135),
-    // reflections = components surviving filter_reflections (:207-236); both keep label order.
-    bool pooled = false;
-    if (total_recs >= 8192 && n >= 4) {
-        AssemblyPool* pool = c->assembly.load(std::memory_order_acquire);
-        if (!pool && !process_exiting()) {
-            std::lock_guard<std::mutex> lock(c->stream_mu);
-            pool = c->assembly.load(std::memory_order_acquire);
-            if (!pool) {
-                pool = new (std::nothrow) AssemblyPool();
-                if (pool) {
-                    try {
-                        pool->start(3);
-                    } catch (...) {   // (no more threads to be had: whatever did start is joined, and this wait assembles on its own)
-                        delete pool;
-                        pool = nullptr;
-                    }
-                }
-                if (pool) c->assembly.store(pool, std::memory_order_release);   // (published with its members built and its threads started)
-            }
-        }
-        if (pool && pool->owner.try_lock()) {   // (another stream's wait has the helpers: assemble here)
-            pool->run(n, assemble);
-            pool->owner.unlock();
-            pooled = true;
-        }
-    }
-    if (!pooled)
-        for (uint32_t f = 0; f < n; ++f) assemble(f);
-    if (!consistent.load()) {
-        c->err = "ffs_wait: the records of a frame do not match its summary counts";
-        return FFS_ERR_DEVICE;
-    }
-    for (uint32_t f = 0; f < n; ++f) {
-        ffs_frame_result& r = s->results[f];
-        const uint32_t* sm = h_sm + (size_t)f * 8;
-        r.frame_id = s->first_id + f;
-        r.num_strong_pixels = h_ns[f];
-        r.num_strong_pixels_filtered = sm[1];
-        r.n_components = h_nc[f];
-        r.n_boxes = sm[0];
-        r.boxes = s->boxes.data() + box_at[f];
-        r.n_reflections = p.want_reflections ? sm[2] : 0;
-        r.reflections = p.want_reflections ? s->refls.data() + refl_at[f] : nullptr;
-        r.n_filtered_size = sm[3];
-        r.n_filtered_sep = sm[4];
-        if (p.want_strong_list) {
-            r.strong_k = s->h_list_k ? s->h_list_k + (size_t)f * s->cap : nullptr;
-            r.strong_intensity = s->h_list_i ? s->h_list_i + (size_t)f * s->cap : nullptr;
-        }
-        if (p.want_strong_mask) r.strong_mask = s->h_mask + (size_t)f * L.W * L.H;
-        if (const OverflowFrame* o = overflow_frame(f)) {
-            const ffs_frame_result& b = o->res;
-            r.num_strong_pixels = b.num_strong_pixels;
-            r.num_strong_pixels_filtered = b.num_strong_pixels_filtered;
-            r.n_components = b.n_components;
-            r.n_boxes = b.n_boxes;
-            r.n_reflections = p.want_reflections ? b.n_reflections : 0;
-            r.n_filtered_size = b.n_filtered_size;
-            r.n_filtered_sep = b.n_filtered_sep;
-            if (p.want_strong_list) {
-                r.strong_k = o->k.data();
-                r.strong_intensity = o->inten.data();
-            }
+        const int rc = assemble_batch(s, total_recs, &s->ovf, s->results, s->boxes, s->refls, s->centres);
+        if (rc != FFS_OK) {
+            c->err = "ffs_wait: the records of a frame do not match its summary counts";
+            return rc;
         }
     }
     if (results) *results = s->results.data();

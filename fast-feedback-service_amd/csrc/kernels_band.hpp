@@ -38,8 +38,10 @@ constexpr int kBandCompStride = 256;    // components of a band handed to the me
 constexpr int kBandSeamCap = 256;       // strong pixels of a band's first / last row handed to the merge
 constexpr int kBandItems = (kBandPx - kBandEntries) / 2;   // undecided pixels of a band: two words each behind the per-entry results, in the forest's LDS (free then)
 constexpr int kMergeThreads = 256;
-constexpr int kMergeMaxBands = 256;
-constexpr int kMergeCap = 6144;         // band components of a frame whose forest fits the merge's LDS
+constexpr int kMergeMaxBands = 128;
+constexpr int kMergeCap = 4096;         // band components of a frame whose forest fits the merge's LDS
+constexpr int kMergeSeamLds = 8;        // strong pixels of a seam row the merge stages in LDS (longer rows: walked in global memory)
+constexpr int kMergeLabels = 2;         // labels per thread and round of the record phase
 constexpr int kMergePer = kMergeCap / kMergeThreads;
 static_assert(sizeof(ChainAcc) == 56 && kBandSlots * (int)sizeof(ChainAcc) <= kBandCw * 4, "the accumulators take the counters' LDS");
 static_assert(kBandEntries + 2 * kBandItems <= kBandPx && kBandMaxRows % 2 == 0, "LDS plan");
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(64) void k_band_cc(const BandArgs B) {
     const uint8_t* img = (const uint8_t*)a.image + (uint64_t)frame * a.frame_stride;
     const size_t slot = (size_t)frame * (size_t)gridDim.x + (size_t)blockIdx.x;
 
+    FFS_STOP_AFTER(B.A, 10);   // (timing experiments: 10 = both kernels return at once, 11 = the merge does, 12 / 13 = the band wave after its entries / the placement)
     if (lane == 0) s_flag = (rows > (uint32_t)kBandMaxRows || rows * l_ns > (uint32_t)kBandCw) ? 128u : 0u;   // (the host checks the geometry too)
     for (uint32_t i = lane; i < min(rows * l_ns, (uint32_t)kBandCw); i += 64) s_cw[i] = 0;
     for (uint32_t i = lane; i < kBandEntries; i += 64) s_par[i] = 0;   // (phase M's per-entry results)
@@ -122,8 +125,21 @@ __global__ __launch_bounds__(64) void k_band_cc(const BandArgs B) {
                 if ((uint32_t)(c * 64) < nb) s_ent[c * 64 + lane] = ent[c];
         }
         __syncthreads();
+        FFS_STOP_AFTER(B.A, 12);
         const uint32_t nchunks = (nb + 63u) / 64u;
         auto mine_of = [](uint2 v) -> bool { return (v.y >> 16) != 0xFFFFu; };
+        // the logged pixels of an entry that holds a strong or undecided pixel (phase L places them); the first two chunks' are asked
+        // for here, ahead of the gathers of phase M, the others one chunk ahead of their use
+        auto load_px = [&](uint32_t c) -> uint4 {
+            uint4 px = make_uint4(0u, 0u, 0u, 0u);
+            if (c < nchunks) {
+                const uint32_t f = c * 64u + (uint32_t)lane;
+                const uint2 v = s_ent[f];
+                if (f < nb && mine_of(v) && (v.y & 0xFFFFu)) px = T.wpix[(uint64_t)(wave0 + 8u * (v.y >> 16)) * kWlogCap + (f - s_lst[v.y >> 16])];
+            }
+            return px;
+        };
+        const uint4 px0 = load_px(0), px1 = load_px(1);
 
         // ---- M: undecided pixels (windows with sum p >= 65536: the cores of bright spots) take the gathered predicate, one per lane --
         {
@@ -192,19 +208,10 @@ __global__ __launch_bounds__(64) void k_band_cc(const BandArgs B) {
 
         if (s_flag == 0 && n != 0) {
             // ---- L: every entry's pixels placed in raster order (k_frame_chain's phase L2, one band) ------------------------------
-            auto load_px = [&](uint32_t c) -> uint4 {
-                uint4 px = make_uint4(0u, 0u, 0u, 0u);
-                if (c < nchunks) {
-                    const uint32_t f = c * 64u + (uint32_t)lane;
-                    const uint2 v = s_ent[f];
-                    if (f < nb && mine_of(v) && (v.y & 0xFFu)) px = T.wpix[(uint64_t)(wave0 + 8u * (v.y >> 16)) * kWlogCap + (f - s_lst[v.y >> 16])];
-                }
-                return px;
-            };
-            uint4 px_next = load_px(0);
+            uint4 px_next = px0;
             for (uint32_t c = 0; c < nchunks; ++c) {
                 const uint4 px = px_next;
-                px_next = load_px(c + 1);   // (on its way while this chunk is placed)
+                px_next = c == 0 ? px1 : load_px(c + 1);   // (on its way while this chunk is placed)
                 const uint2 v = s_ent[c * 64 + lane];
                 const bool mine = mine_of(v);
                 const uint32_t row = (v.x >> 16) - (uint32_t)yb0, k = v.y >> 16;
@@ -245,6 +252,7 @@ __global__ __launch_bounds__(64) void k_band_cc(const BandArgs B) {
                 __syncthreads();
             }
 
+            FFS_STOP_AFTER(B.A, 13);
             // ---- X / U: the forest (k_frame_chain's phases, band-local rows; edges across the band's ends are the merge's) --------
             const uint32_t per = (n + 63u) / 64u;
             const uint32_t i0 = min((uint32_t)lane * per, n), i1 = min(i0 + per, n);
@@ -388,7 +396,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_frame_merge(const BandArgs B)
     __shared__ uint32_t s_wave[kMergeThreads / 64];
     __shared__ uint32_t s_sm[8];
     __shared__ uint32_t s_tot[2];   // strong pixels, flags
-    __shared__ __align__(16) uint32_t s_out[kMergeThreads * (sizeof(WireRec2) / 4)];
+    __shared__ __align__(16) uint32_t s_out[kMergeLabels * kMergeThreads * (sizeof(WireRec2) / 4)];
+    __shared__ __align__(16) uint32_t s_seam[kMergeMaxBands * 2 * kMergeSeamLds];   // the first pixels of every seam row (first row, last row per band)
     const int frame = blockIdx.x, tid = threadIdx.x;
     const uint32_t W = (uint32_t)a.W;
     const uint32_t nbands = (uint32_t)(T.n_bands * B.sub);
@@ -396,12 +405,22 @@ __global__ __launch_bounds__(kMergeThreads) void k_frame_merge(const BandArgs B)
     ChainAcc* acc = B.acc + (size_t)frame * nbands * kBandCompStride;
     const uint32_t* seam = B.seam + (size_t)frame * nbands * 2 * kBandSeamCap;
 
+    FFS_PHASE_TS(A, 0);
+    FFS_STOP_AFTER(A, 10);
+    FFS_STOP_AFTER(A, 11);
+    FFS_STOP_AFTER(A, 12);
+    FFS_STOP_AFTER(A, 13);
     if (tid < 8) s_sm[tid] = 0;
     if (tid < 2) s_tot[tid] = 0;
     for (int i = tid; i < kMergeCap / 32; i += kMergeThreads) s_touched[i] = 0;
     __syncthreads();
     uint4 h = make_uint4(0u, 0u, 0u, 0u);
     if ((uint32_t)tid < nbands) h = hdr[tid];
+    // the seam rows' first pixels into LDS, all loads in one round trip (the walk below then costs no memory access per step)
+    for (uint32_t j = (uint32_t)tid; j < nbands * 2u * (kMergeSeamLds / 4); j += kMergeThreads) {
+        const uint32_t list = j / (kMergeSeamLds / 4), q = j % (kMergeSeamLds / 4);
+        reinterpret_cast<uint4*>(s_seam)[j] = reinterpret_cast<const uint4*>(seam + (size_t)list * kBandSeamCap)[q];
+    }
     if (h.x) atomicAdd(&s_tot[0], h.x);
     if (h.w & 0xFFFFu) atomicOr(&s_tot[1], h.w & 0xFFFFu);
     uint32_t NB;
@@ -412,6 +431,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_frame_merge(const BandArgs B)
     const uint32_t total = s_tot[0];
     uint32_t flags = s_tot[1];
     if (NB > (uint32_t)kMergeCap) flags |= 128u;
+    FFS_PHASE_TS(A, 1);
     uint32_t before = 0;
 
     if (flags == 0) {
@@ -429,22 +449,27 @@ __global__ __launch_bounds__(kMergeThreads) void k_frame_merge(const BandArgs B)
             if (nbot && ntop) {
                 const uint32_t* bot = seam + ((size_t)b * 2 + 1) * kBandSeamCap;
                 const uint32_t* top = seam + ((size_t)t * 2) * kBandSeamCap;
+                const uint32_t* lbot = s_seam + (b * 2u + 1u) * kMergeSeamLds;
+                const uint32_t* ltop = s_seam + (t * 2u) * kMergeSeamLds;
+                auto bot_at = [&](uint32_t i) -> uint32_t { return i < (uint32_t)kMergeSeamLds ? lbot[i] : bot[i]; };
+                auto top_at = [&](uint32_t i) -> uint32_t { return i < (uint32_t)kMergeSeamLds ? ltop[i] : top[i]; };
                 const uint32_t ob = s_off[b], ot = s_off[t];
                 // the reference's k + 1 edge has no row-end check (connected_components.cc:62-70): the last pixel of a row and the
                 // first of the next are joined when both are strong
-                const uint32_t last = bot[nbot - 1], first = top[0];
+                const uint32_t last = bot_at(nbot - 1), first = top_at(0);
                 if ((last & 0xFFFFu) == W - 1 && (first & 0xFFFFu) == 0u) uf_union(s_par, ob + (last >> 16), ot + (first >> 16));
                 uint32_t p = 0, q = 0;   // the k + W edges: equal x (both lists ascend)
-                uint32_t vb = bot[0], vt = first;
+                uint32_t vb = bot_at(0), vt = first;
                 for (;;) {
                     const uint32_t xb = vb & 0xFFFFu, xt = vt & 0xFFFFu;
                     if (xb == xt) uf_union(s_par, ob + (vb >> 16), ot + (vt >> 16));
-                    if (xb <= xt) { if (++p >= nbot) break; vb = bot[p]; }
-                    else { if (++q >= ntop) break; vt = top[q]; }
+                    if (xb <= xt) { if (++p >= nbot) break; vb = bot_at(p); }
+                    else { if (++q >= ntop) break; vt = top_at(q); }
                 }
             }
         }
         __syncthreads();
+        FFS_PHASE_TS(A, 2);
         // ---- roots, numbered in order (band after band, inside a band by first pixel: the order of the components' first pixels) ----
         // a band component's accumulator: the band of id i by search in s_off (ids ascend band after band)
         auto acc_of = [&](uint32_t id) -> ChainAcc* {
@@ -475,6 +500,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_frame_merge(const BandArgs B)
             }
         }
         __syncthreads();   // every find is done (the forest is not changed any more; also waits for this block's atomics to have been performed)
+        FFS_PHASE_TS(A, 3);
         {
             uint32_t sl = block_exclusive_scan<kMergeThreads>(mine, s_wave, before);
             for (uint32_t i = i0; i < i1; ++i)
@@ -484,31 +510,42 @@ __global__ __launch_bounds__(kMergeThreads) void k_frame_merge(const BandArgs B)
                 }
         }
         __syncthreads();
+        FFS_PHASE_TS(A, 4);
         // ---- records, kMergeThreads labels at a time, a thread per label: staged in LDS, out as consecutive dwords ------------------
         WireRec2* recs = reinterpret_cast<WireRec2*>(sa.recs) + (uint64_t)frame * A.rec_stride;
         const uint32_t ncomp = min(before, sa.max_comp);
-        for (uint32_t L0 = 0; L0 < ncomp; L0 += kMergeThreads) {
-            const uint32_t lab = L0 + (uint32_t)tid;
-            if (lab < ncomp) {
-                const uint32_t id = s_l2id[lab];
-                const unsigned long long* p = reinterpret_cast<const unsigned long long*>(acc_of(id));
-                unsigned long long v[7];   // sum I, sum (2x+1) I, sum (2y+1) I, peak | x_min, x_max | y_min, y_max | pixels, -
-                if ((s_touched[id >> 5] >> (id & 31u)) & 1u) {
-                    // agent-scope loads: members were folded in by atomics at the L2
+        constexpr uint32_t kRound = (uint32_t)(kMergeLabels * kMergeThreads);
+        for (uint32_t L0 = 0; L0 < ncomp; L0 += kRound) {
+            unsigned long long v[kMergeLabels][7];   // sum I, sum (2x+1) I, sum (2y+1) I, peak | x_min, x_max | y_min, y_max | pixels, -
 #pragma unroll
-                    for (int w = 0; w < 7; ++w) v[w] = __hip_atomic_load(p + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
+            for (int u = 0; u < kMergeLabels; ++u) {   // (both labels' loads are asked for before either record is computed)
+                const uint32_t lab = L0 + (uint32_t)(u * kMergeThreads + tid);
+                if (lab < ncomp) {
+                    const uint32_t id = s_l2id[lab];
+                    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(acc_of(id));
+                    if ((s_touched[id >> 5] >> (id & 31u)) & 1u) {
+                        // agent-scope loads: members were folded in by atomics at the L2
 #pragma unroll
-                    for (int w = 0; w < 7; ++w) v[w] = p[w];
+                        for (int w = 0; w < 7; ++w) v[u][w] = __hip_atomic_load(p + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+#pragma unroll
+                        for (int w = 0; w < 7; ++w) v[u][w] = p[w];
+                    }
                 }
-                WireRec2 o;
-                chain_record(sa, W, (uint32_t)v[6], v[0], v[1], v[2], (uint32_t)v[4], (uint32_t)(v[4] >> 32), (uint32_t)v[5], (uint32_t)(v[5] >> 32),
-                             0xFFFFFFFFu - (uint32_t)(v[3] & 0xFFFFFFFFull), (uint32_t)(v[3] >> 32), s_sm, o);
-                *reinterpret_cast<WireRec2*>(&s_out[tid * (sizeof(WireRec2) / 4)]) = o;
+            }
+#pragma unroll
+            for (int u = 0; u < kMergeLabels; ++u) {
+                const uint32_t slot = (uint32_t)(u * kMergeThreads + tid);
+                if (L0 + slot < ncomp) {
+                    WireRec2 o;
+                    chain_record(sa, W, (uint32_t)v[u][6], v[u][0], v[u][1], v[u][2], (uint32_t)v[u][4], (uint32_t)(v[u][4] >> 32), (uint32_t)v[u][5],
+                                 (uint32_t)(v[u][5] >> 32), 0xFFFFFFFFu - (uint32_t)(v[u][3] & 0xFFFFFFFFull), (uint32_t)(v[u][3] >> 32), s_sm, o);
+                    *reinterpret_cast<WireRec2*>(&s_out[slot * (sizeof(WireRec2) / 4)]) = o;
+                }
             }
             __syncthreads();
             {
-                const uint32_t here = min((uint32_t)kMergeThreads, ncomp - L0);
+                const uint32_t here = min(kRound, ncomp - L0);
                 uint32_t* dst = reinterpret_cast<uint32_t*>(recs + L0);
                 const uint32_t ndw = here * (uint32_t)(sizeof(WireRec2) / 4);
                 for (uint32_t w = tid; w < ndw; w += kMergeThreads) dst[w] = s_out[w];
@@ -518,6 +555,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_frame_merge(const BandArgs B)
     }
     // ---- counters: as k_frame_chain ---------------------------------------------------------------------------------------------
     __syncthreads();
+    FFS_PHASE_TS(A, 5);
+    FFS_PHASE_TS(A, 6);
     if (tid == 0) {
         uint32_t fl = *a.overflow | flags;
         if (total > a.cap) fl |= 1u;

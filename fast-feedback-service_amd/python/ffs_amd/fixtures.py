@@ -48,3 +48,28 @@ def load_expected(workload: str, algorithm: str, rank: int, n_frames: int):
     if len(out["n_boxes"]) < n_frames:
         return None
     return {f: v[:n_frames] for f, v in out.items()}
+
+
+def reflections_digest(reflections: np.ndarray) -> bytes:
+    """One 32-byte value for a whole reflection table (a rotation sweep's 3D reflections, in label order)."""
+    h = hashlib.sha256()
+    h.update(np.uint32(len(reflections)).tobytes())
+    for f in REFL_FIELDS:
+        h.update(np.ascontiguousarray(reflections[f]).tobytes())
+    return h.digest()
+
+
+def load_expected_sweep(name: str = "sweep16m"):
+    """BASELINE.json configs[4], bench.py --workload sweep16m: -> dict(n_reflections, n_calculated, n_filtered_size, n_filtered_sep: int;
+    digest: bytes (reflections_digest of the 3D table); num_strong_pixels, n_boxes: uint32[frames]) or None."""
+    path = os.path.normpath(GOLDEN)
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    if f"{name}/digest" not in z.files:
+        return None
+    out = {f: int(z[f"{name}/{f}"]) for f in ("n_reflections", "n_calculated", "n_filtered_size", "n_filtered_sep")}
+    out["digest"] = z[f"{name}/digest"].tobytes()
+    out["num_strong_pixels"] = z[f"{name}/num_strong_pixels"]
+    out["n_boxes"] = z[f"{name}/n_boxes"]
+    return out

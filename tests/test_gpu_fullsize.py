@@ -102,11 +102,13 @@ def test_sweep_3d_eiger_100_frames(ffs):
     """configs[4] at its stated size: a 100-frame Eiger-16M fine-phi sweep, 800 reflections with a rocking
     curve, `--min-spot-size 3 --min-spot-size-3d 15` (the shape of the reference's
     tests/3d_connected_components.sh:27-37), through the batch path, the device-resident 3D stack and its
-    finish; checked against the oracle's 3D labelling, three frames' strong lists against the oracle's
-    dispersion + 2D labelling."""
+    finish.  EVERY frame's counts, boxes, reflections and strong-pixel list are held to the oracle's dispersion + 2D labelling
+    (16 oracle threads), and the slices the oracle's 3D labelling gets are the ORACLE's own lists, not the HIP path's: a wrong
+    list on any frame fails here, whatever the 3D stage makes of it."""
+    from concurrent.futures import ThreadPoolExecutor
     from ffs_amd import synth
     from oracle import oracle as O
-    from util import assert_reflections_equal, assert_frame_matches_oracle
+    from util import assert_reflections_equal, assert_frame_matches_oracle, oracle_frame
     NZ, B = 100, 25
     p = synth.sweep_params(seed=5000, n_frames=NZ, n_spots=800)
     mask = synth.mask_eiger16m()
@@ -120,11 +122,12 @@ def test_sweep_3d_eiger_100_frames(ffs):
         frames = synth.frames(p, range(z0, z0 + B), threads=16)
         res = st.process(frames, first_frame_id=z0)
         stack.add_batch(st)
-        slices += [(r.strong_k.copy(), r.strong_intensity.copy()) for r in res]
-        if z0 == 50:
-            for j in (0, 11, 24):
-                assert_frame_matches_oracle(res[j], frames[j], mask)
-        del frames
+        with ThreadPoolExecutor(16) as ex:                       # (the C oracle runs without the interpreter lock)
+            want = list(ex.map(lambda img: oracle_frame(img, mask), frames))
+        for j in range(B):
+            assert_frame_matches_oracle(res[j], frames[j], mask, precomputed=want[j])
+            slices.append((want[j][1].k.astype(np.uint32), want[j][1].intensity.astype(np.uint32)))
+        del frames, want
     refl, n_calc, fs, fp = stack.finish()
     assert stack.last_finish_ms() > 0
     want = O.cc3d(slices, 4148, 4362, 15, 2.0)
