@@ -403,7 +403,8 @@ def cli_e2e(n_images=1000, threads=None, batch=None, cpu_decode_images=256, keep
                     pass
             return {"frames_per_s": float(m.group(3)), "images": int(m.group(1)), "binary_s": float(m.group(2)),
                     "chunks_read_GBps": round(int(m.group(1)) * chunk / 1e9 / max(float(m.group(2)), 1e-9), 1),
-                    "wall_s": round(wall, 2), "json_lines": ok, "stderr_bytes": len(p.stderr)}
+                    "wall_s": round(wall, 3), "wall_frames_per_s": round(int(m.group(1)) / max(wall, 1e-9), 1),
+                    "start_up_and_tear_down_s": round(wall - float(m.group(2)), 3), "json_lines": ok, "stderr_bytes": len(p.stderr)}
 
         run([], 32)          # untimed warm-up of the binary (first GPU context of the process tree, page cache of the libraries)
         # first pass over files nobody has read yet (what a live data set is): bounded by the kernel -- the first read() after the
@@ -425,7 +426,9 @@ def cli_e2e(n_images=1000, threads=None, batch=None, cpu_decode_images=256, keep
         # all GPUs of a host, PCIe is not (here both contexts share one link, so the frame rate stays at one GPU's)
         out["two_contexts_one_gpu"] = run(["--devices", "0,0"], max(n_images, long_images))
         out["note"] = ("frames/s = the binary's own last line (timer from just before its workers start to after the last result, "
-                       "stream set-up and pinned staging included); at most 8 of the threads feed the GPU when it decodes the chunks; "
+                       "stream set-up and pinned staging included), as the reference prints it; `wall_frames_per_s` = images / the wall time of "
+                       "the whole process as its caller sees it (the service starts one process per request: HIP runtime, code object, context, "
+                       "mask upload before the timer, exit after it: `start_up_and_tear_down_s`; tools/cli_startup.sh breaks it down); at most 8 of the threads feed the GPU when it decodes the chunks; "
                        "PCIe floor for 7.5 MB chunks at the 55 GB/s measured on this pool: ~7.3 k frames/s; every frame is a file of its own "
                        "(7.5 GB per 1000), `first_pass_over_fresh_files` = the same run the first time those files are read")
     except Exception as e:  # the bench line must still come out
@@ -645,6 +648,35 @@ def bench_single_process(args):
             results_checked = False
     med = statistics.median(times)
     steady = max(0.0, (el2 - med) / args.steps)
+    # The gather of one step's spot rows (every context's last batch), two ways: read where ffs_wait left them (host memory, one
+    # memcpy per context: what `spotfinder --gpus N` does) against the north star's collective on the library's own communicators
+    # (ffs_multi_gather_rows: counts by ncclAllGather, rows by ncclSend / ncclRecv to the root device, one D2H).  Untimed A/B.
+    gather_ab = None
+    try:
+        last_streams = [g["streams"][(args.steps - 1) % len(g["streams"])] for g in gpus]
+        cap = 1 << 18
+        scratch = np.empty((cap + 1, 4), np.float32)
+        t_host, t_rccl, n_host, n_rccl = [], [], 0, 0
+        for rep in range(6):
+            t0 = time.perf_counter()
+            n_host = 0
+            for s in last_streams:
+                n_host += s.pack_spot_centres(scratch[n_host:], cap - n_host)
+            t_host.append(time.perf_counter() - t0)
+            if transport == "rccl":
+                t0 = time.perf_counter()
+                rows = ffs_amd.api.multi_gather_rows(last_streams, root=0, cap=cap)
+                t_rccl.append(time.perf_counter() - t0)
+                n_rccl = len(rows)
+                same = n_rccl == n_host and np.array_equal(rows.view(np.uint32), scratch[:n_host].view(np.uint32))
+            else:
+                same = None
+        gather_ab = {"rows_per_step": int(n_host), "host_read_ms": round(min(t_host[1:]) * 1e3, 4),
+                     "rccl_gather_ms": (round(min(t_rccl[1:]) * 1e3, 4) if t_rccl else None), "rows_identical": same,
+                     "what": "one step's spot-centre rows of all contexts into one host array: memcpy from the library's host arrays against "
+                             "ffs_multi_gather_rows (H2D of each context's rows, ncclAllGather of counts, ncclSend / ncclRecv to the root device, D2H)"}
+    except Exception as e:  # the line must still come out
+        gather_ab = {"error": f"{type(e).__name__}: {e}"}
     out = {
         "metric": "detector frames/s (Eiger-16M 4362x4148 uint16)" if args.workload == "eiger16m" else f"detector frames/s ({args.workload})",
         "value": round(n * args.steps * B / med, 2), "unit": "frames/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
@@ -660,6 +692,7 @@ def bench_single_process(args):
         "steady_ms_per_step": round(steady * 1e3, 4), "drain_ms": round(max(0.0, med - steady * args.steps) * 1e3, 4),
         "n_contexts_seen": n,
         "results_checked": results_checked,
+        "gather_ab": gather_ab,
     }
     print(json.dumps(out), flush=True)
     return 0 if results_checked is not False else 6

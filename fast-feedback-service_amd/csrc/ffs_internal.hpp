@@ -424,3 +424,4 @@ int ahead_take(ffs_stream* s);        // waits for the AheadThread to be done wi
 void ahead_stop(ffs_ctx* c, bool destroy);   // the thread leaves and is joined (context destroy, process exit)
 // ffs_stack3d.hip
 void stack3d_free(ffs_stack3d* st);
+void gather_scratch_free(ffs_stream* s);   // what ffs_multi_gather_rows allocated for the stream, if anything

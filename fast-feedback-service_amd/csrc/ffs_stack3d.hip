@@ -235,6 +235,7 @@ struct RcclApi {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 static std::mutex g_multi_mu;
@@ -280,6 +281,7 @@ extern "C" int ffs_multi_init(const int* devices, int n_devices, const char* tra
             g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(dlsym(g_rccl.lib, "ncclGroupEnd"));
             g_rccl.Send = reinterpret_cast<decltype(g_rccl.Send)>(dlsym(g_rccl.lib, "ncclSend"));
             g_rccl.Recv = reinterpret_cast<decltype(g_rccl.Recv)>(dlsym(g_rccl.lib, "ncclRecv"));
+            g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(g_rccl.lib, "ncclAllGather"));
             g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(g_rccl.lib, "ncclGetErrorString"));
         }
     }
@@ -317,6 +319,153 @@ extern "C" int ffs_device_numa_node(int device) {
     if (std::fscanf(f, "%d", &node) != 1) node = -1;
     std::fclose(f);
     return node;
+}
+
+// ---- the gather of the per-frame spot lists over RCCL (BASELINE.json north_star) -------------------------
+// One process, one context per GPU: after a batch each context holds its reflections' centre rows (frame id, x, y, z) on the host
+// (ffs_stream_spot_centres).  The driver can simply read them there (`spotfinder --gather host`); this is the collective the
+// north star names, on the communicators ffs_multi_init built: every rank's row count by ncclAllGather, then exactly the written
+// rows by ncclSend / ncclRecv inside one group to the root's device, and one copy from there to the host.  Contexts that share a
+// GPU share its rank: their rows go out as ONE message (one send per pair of ranks and group: two sends between the same pair were
+// matched out of order with their receives in the one-GPU rehearsal).  Scratch per rank's first stream, allocated on first use, freed with it.
+struct GatherScratch {
+    float* d_rows = nullptr;            // this stream's rows on its device
+    size_t rows_cap = 0;
+    unsigned long long* d_cnt = nullptr;   // [1] this rank's count | [ranks] everybody's (behind it)
+    float* d_all = nullptr;             // root only: every rank's rows, in stream order
+    size_t all_cap = 0;
+    hipStream_t st = nullptr;
+};
+static std::mutex g_gather_mu;
+static std::map<ffs_stream*, GatherScratch> g_gather;   // (a handful of entries: one per stream that ever took part)
+
+void gather_scratch_free(ffs_stream* s) {
+    std::lock_guard<std::mutex> lock(g_gather_mu);
+    auto it = g_gather.find(s);
+    if (it == g_gather.end()) return;
+    GatherScratch& g = it->second;
+    if (g.st) (void)hipStreamSynchronize(g.st);
+    if (g.d_rows) (void)hipFree(g.d_rows);
+    if (g.d_cnt) (void)hipFree(g.d_cnt);
+    if (g.d_all) (void)hipFree(g.d_all);
+    if (g.st) (void)hipStreamDestroy(g.st);
+    g_gather.erase(it);
+}
+
+static int multi_gather_rows_impl(ffs_stream* const* streams, uint32_t n, uint32_t root, float* rows4_out, uint32_t cap, uint32_t* n_rows) {
+    ffs_ctx* rc = streams[root]->ctx;
+    std::lock_guard<std::mutex> lock_multi(g_multi_mu);   // (the communicators are not ours alone: a rotation exchange may want them too)
+    if (g_comms.empty() || !g_rccl.AllGather || !g_rccl.Send || !g_rccl.Recv) {
+        rc->err = "ffs_multi_gather_rows: no RCCL communicators (ffs_multi_init with transport \"rccl\" first; ffs_multi_transport() tells)";
+        return FFS_ERR_INVALID;
+    }
+    const int n_ranks = (int)g_comms.size();
+    std::vector<int> rank(n), leader((size_t)n_ranks, -1);
+    std::vector<uint64_t> rows(n), per_rank((size_t)n_ranks, 0), in_rank(n, 0), rank_at((size_t)n_ranks + 1, 0);
+    std::lock_guard<std::mutex> lock(g_gather_mu);
+    for (uint32_t i = 0; i < n; ++i) {
+        ffs_stream* s = streams[i];
+        if (s->busy) { rc->err = "ffs_multi_gather_rows: a stream has a batch in flight (call after ffs_wait)"; return FFS_ERR_INVALID; }
+        rank[i] = comm_rank_of(s->ctx->device);
+        if (rank[i] < 0) { rc->err = "ffs_multi_gather_rows: a stream's device is not in the communicator"; return FFS_ERR_INVALID; }
+        if (leader[(size_t)rank[i]] < 0) leader[(size_t)rank[i]] = (int)i;   // a rank's first stream holds its send buffer and its count
+        rows[i] = s->centres.size() / 4;
+        in_rank[i] = per_rank[(size_t)rank[i]];                             // where this stream's rows start inside its rank's message
+        per_rank[(size_t)rank[i]] += rows[i];
+    }
+    for (int r = 0; r < n_ranks; ++r) {
+        if (leader[(size_t)r] < 0) { rc->err = "ffs_multi_gather_rows: every rank of the communicator needs a stream (a collective)"; return FFS_ERR_INVALID; }
+        rank_at[(size_t)r + 1] = rank_at[(size_t)r] + per_rank[(size_t)r];
+    }
+    const uint64_t total = rank_at[(size_t)n_ranks];
+    if (n_rows) *n_rows = (uint32_t)std::min<uint64_t>(total, 0xFFFFFFFFull);
+    if (total > cap) { rc->err = "ffs_multi_gather_rows: the rows do not fit `cap`"; return FFS_ERR_OVERFLOW; }
+    const int root_rank = rank[root];
+    // scratch of every rank's first stream: one message per rank -- the rows of all its contexts, one behind the other -- and the count
+    for (int r = 0; r < n_ranks; ++r) {
+        ffs_stream* s = streams[(size_t)leader[(size_t)r]];
+        GatherScratch& g = g_gather[s];
+        STK_TRY(rc, hipSetDevice(s->ctx->device));
+        if (!g.st) STK_TRY(rc, hipStreamCreateWithFlags(&g.st, hipStreamNonBlocking));
+        if (!g.d_cnt) STK_TRY(rc, hipMalloc(reinterpret_cast<void**>(&g.d_cnt), (size_t)(1 + n_ranks) * 8 + 256));
+        if (per_rank[(size_t)r] > g.rows_cap) {
+            STK_TRY(rc, hipStreamSynchronize(g.st));
+            if (g.d_rows) (void)hipFree(g.d_rows);
+            g.d_rows = nullptr;
+            g.rows_cap = per_rank[(size_t)r] + per_rank[(size_t)r] / 2 + 1024;
+            STK_TRY(rc, hipMalloc(reinterpret_cast<void**>(&g.d_rows), g.rows_cap * 16));
+        }
+        if (r == root_rank && total > g.all_cap) {
+            STK_TRY(rc, hipStreamSynchronize(g.st));
+            if (g.d_all) (void)hipFree(g.d_all);
+            g.d_all = nullptr;
+            g.all_cap = total + total / 2 + 1024;
+            STK_TRY(rc, hipMalloc(reinterpret_cast<void**>(&g.d_all), g.all_cap * 16));
+        }
+        STK_TRY(rc, hipMemcpyAsync(g.d_cnt, &per_rank[(size_t)r], 8, hipMemcpyHostToDevice, g.st));
+    }
+    for (uint32_t i = 0; i < n; ++i) {   // every stream's rows onto its rank's device, into the rank's message
+        if (!rows[i]) continue;
+        GatherScratch& g = g_gather[streams[(size_t)leader[(size_t)rank[i]]]];
+        STK_TRY(rc, hipSetDevice(streams[i]->ctx->device));
+        STK_TRY(rc, hipMemcpyAsync(g.d_rows + in_rank[i] * 4, streams[i]->centres.data(), rows[i] * 16, hipMemcpyHostToDevice, g.st));
+    }
+    auto nccl_fail = [&](const char* what, ncclResult_t r) {
+        rc->err = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "failed");
+        return FFS_ERR_DEVICE;
+    };
+    {   // counts
+        ncclResult_t r = g_rccl.GroupStart();
+        for (int k = 0; k < n_ranks && r == ncclSuccess; ++k) {
+            ffs_stream* s = streams[(size_t)leader[(size_t)k]];
+            GatherScratch& g = g_gather[s];
+            (void)hipSetDevice(s->ctx->device);
+            r = g_rccl.AllGather(g.d_cnt, g.d_cnt + 1, 1, ncclUint64, g_comms[(size_t)k], g.st);
+        }
+        const ncclResult_t re = g_rccl.GroupEnd();
+        if (r != ncclSuccess || re != ncclSuccess) return nccl_fail("ncclAllGather of the row counts", r != ncclSuccess ? r : re);
+    }
+    // rows: exactly what was written, one message per rank, to the root's device.  The root's own message is a device copy; with the
+    // transport forced to RCCL (ffs_multi_init(.., "rccl") / FFS_GATHER) it is sent to its own rank, which a one-GPU box can rehearse.
+    GatherScratch& gr = g_gather[streams[(size_t)leader[(size_t)root_rank]]];
+    {
+        ncclResult_t r = g_rccl.GroupStart();
+        for (int k = 0; k < n_ranks && r == ncclSuccess; ++k) {
+            if (!per_rank[(size_t)k] || (k == root_rank && !g_gather_forced)) continue;
+            ffs_stream* s = streams[(size_t)leader[(size_t)k]];
+            GatherScratch& g = g_gather[s];
+            (void)hipSetDevice(s->ctx->device);
+            r = g_rccl.Send(g.d_rows, per_rank[(size_t)k] * 4, ncclFloat, root_rank, g_comms[(size_t)k], g.st);
+            (void)hipSetDevice(rc->device);
+            if (r == ncclSuccess) r = g_rccl.Recv(gr.d_all + rank_at[(size_t)k] * 4, per_rank[(size_t)k] * 4, ncclFloat, k, g_comms[(size_t)root_rank], gr.st);
+        }
+        const ncclResult_t re = g_rccl.GroupEnd();
+        if (r != ncclSuccess || re != ncclSuccess) return nccl_fail("ncclSend / ncclRecv of the spot rows", r != ncclSuccess ? r : re);
+    }
+    STK_TRY(rc, hipSetDevice(rc->device));
+    if (per_rank[(size_t)root_rank] && !g_gather_forced)
+        STK_TRY(rc, hipMemcpyAsync(gr.d_all + rank_at[(size_t)root_rank] * 4, gr.d_rows, per_rank[(size_t)root_rank] * 16, hipMemcpyDeviceToDevice, gr.st));
+    std::vector<unsigned long long> counts((size_t)n_ranks, 0);
+    STK_TRY(rc, hipMemcpyAsync(counts.data(), gr.d_cnt + 1, (size_t)n_ranks * 8, hipMemcpyDeviceToHost, gr.st));
+    if (total) STK_TRY(rc, hipMemcpyAsync(rows4_out, gr.d_all, total * 16, hipMemcpyDeviceToHost, gr.st));
+    for (int r = 0; r < n_ranks; ++r) {   // (the senders' streams too: their scratch is reused by the next gather)
+        ffs_stream* s = streams[(size_t)leader[(size_t)r]];
+        STK_TRY(rc, hipSetDevice(s->ctx->device));
+        STK_TRY(rc, hipStreamSynchronize(g_gather[s].st));
+    }
+    for (int r = 0; r < n_ranks; ++r)
+        if (counts[(size_t)r] != per_rank[(size_t)r]) {
+            rc->err = "ffs_multi_gather_rows: the gathered counts differ from what the ranks sent";
+            return FFS_ERR_DEVICE;
+        }
+    return FFS_OK;
+}
+
+extern "C" int ffs_multi_gather_rows(ffs_stream* const* streams, uint32_t n_streams, uint32_t root, float* rows4_out, uint32_t cap, uint32_t* n_rows) {
+    if (!streams || n_streams == 0 || root >= n_streams || !rows4_out) return FFS_ERR_INVALID;
+    for (uint32_t i = 0; i < n_streams; ++i)
+        if (!streams[i] || !handle_live(kHandleStream, streams[i])) return FFS_ERR_INVALID;
+    return guarded(streams[root]->ctx, [&] { return multi_gather_rows_impl(streams, n_streams, root, rows4_out, cap, n_rows); });
 }
 
 static const OverflowFrame* overflow_of(const ffs_stream* s, uint32_t f) {

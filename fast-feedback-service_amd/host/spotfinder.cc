@@ -62,7 +62,7 @@ struct Args {
     std::string algorithm = "dispersion", detector_json;
     std::string max_valid = "trusted";   // trusted | none | N
     uint32_t min_count = 2;
-    bool cpu_decode = false, no_numa_pinning = false, single_buffer = false, all_threads = false, read_only = false;
+    bool cpu_decode = false, no_numa_pinning = false, single_buffer = false, all_threads = false, read_only = false, clean_exit = false;
 };
 
 static void usage() {
@@ -73,7 +73,7 @@ static void usage() {
       "                  [-t S] [-fd FD] [-a ALGO] [--dmin MIN D] [--dmax MAX D] [-w \xce\xbb] [--detector JSON]\n"
       "                  [-h5] [--output-for-index] [--batch N] [--cpu-decode] [--strict-dtype]\n"
       "                  [--max-valid trusted|none|N] [--min-count N]\n"
-      "                  [--devices D0,D1,... | --gpus N] [--no-numa-pinning] [--single-buffer] [--all-threads] [--read-only]\n"
+      "                  [--devices D0,D1,... | --gpus N] [--no-numa-pinning] [--single-buffer] [--all-threads] [--read-only] [--clean-exit]\n"
       "--max-valid: a centre pixel above this value is never strong (the reference's kernels test it against the\n"
       "              data set's trusted maximum).  trusted (default) = the frame source's trusted-range maximum when it is\n"
       "              below the pixel type's maximum, none = no test (the CPU baseline's behaviour), N = this value\n"
@@ -84,6 +84,8 @@ static void usage() {
       "              (-n threads are dealt round-robin to the GPUs, at least one each); rotation sweeps send\n"
       "              their strong-pixel lists to the first GPU's 3D stack (RCCL over xGMI, else peer copies)\n"
       "--all-threads: every one of the -n threads reads (default: at most eight per GPU when chunks are decoded there)\n"
+      "--clean-exit: destroy streams and contexts and let the runtime tear itself down before the process ends (default: the\n"
+      "              process leaves as soon as its last result is out -- a request's wall time ends there)\n"
       "--batch N:   frames per GPU batch (default 16 chunks / 4 decoded frames); a batch is filled by all readers of its GPU\n"
       "--single-buffer: one batch per GPU at a time (default: four of chunks / three of decoded frames, filled while the others are on the GPU)\n"
       "--read-only: (diagnostic) read every chunk into the staging areas and submit nothing\n"
@@ -181,6 +183,7 @@ static Args parse_args(int argc, char** argv) {
         else if (s == "--single-buffer") r.single_buffer = true;
         else if (s == "--read-only") r.read_only = true;   // diagnostic: frames are read into the staging buffers and not submitted
         else if (s == "--all-threads") r.all_threads = true;
+        else if (s == "--clean-exit") r.clean_exit = true;
         else if (!s.empty() && s[0] == '-' && s.size() > 1) arg_error("Unknown argument: " + s);
         else if (r.file.empty()) r.file = s;
         else arg_error("Maximum number of positional arguments exceeded");
@@ -313,6 +316,16 @@ int main(int argc, char** argv) {
     std::printf("Spotfinder version: %s\n", FFS_VERSION);
     Args args = parse_args(argc, argv);
     const std::string file = args.file;
+    // -v: where the process's wall time goes outside the timed loop (the service starts one process per request, service.py:497,
+    // so start-up and tear-down are what a short request sees): "[+ ms since main] step (ms it took)"
+    auto stamp_prev = process_start;
+    auto stamp = [&](const char* what) {
+        if (!args.verbose) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::printf("[%7.1f ms] %s (%.1f ms)\n", std::chrono::duration<double, std::milli>(t - process_start).count(), what,
+                    std::chrono::duration<double, std::milli>(t - stamp_prev).count());
+        stamp_prev = t;
+    };
 
     int algorithm = FFS_ALGO_DISPERSION;
     {  // DispersionAlgorithm, spotfinder.cc:180-203
@@ -331,10 +344,12 @@ int main(int argc, char** argv) {
         std::printf("Error: Thread count must be >= 1\n");
         return 1;
     }
+    stamp("arguments parsed");
     if (ffs_device_count() < 1) {  // cuda_arg_parser.cc:56-61
         std::printf("\033[1;31mError: Could not select GPU device\033[0m\n");
         return 1;
     }
+    stamp("HIP runtime initialised (first device query)");
     {
         char name[256];
         if (ffs_device_name(args.device, name, sizeof name) != FFS_OK) {
@@ -456,6 +471,7 @@ int main(int argc, char** argv) {
         std::printf("Oscillation:  Start: %.2f\xc2\xb0  Width: %.2f\xc2\xb0\n", oscillation_start, oscillation_width);
 
     std::signal(SIGINT, stop_processing);
+    stamp("frame source opened, header read");
 
     // ---- device context -------------------------------------------------------------------------------
     // bitshuffle-LZ4 chunks go to the GPU as they are (read straight into the pinned staging area) unless the pixels are
@@ -487,11 +503,26 @@ int main(int argc, char** argv) {
     }
     const uint32_t n_dev = (uint32_t)devices.size();
     if (args.threads < n_dev) args.threads = n_dev;  // at least one worker per GPU
+    // The exchange between GPUs (RCCL communicators: 2-5 s to load the library and initialise, measured in round 5 -- it was what two
+    // contexts cost a 1000-image request) serves rotation sweeps only -- every frame's strong-pixel list has to reach the GPU that owns
+    // the 3D stack -- so stills never pay it, and a sweep initialises it on a helper thread beside the contexts and the first batches
+    // (joined before the first batch is added to the stack).
+    const bool need_exchange = n_dev > 1 && oscillation_width > 0;
+    struct JoinedThread {   // (an early `return` below must not meet a joinable std::thread)
+        std::thread th;
+        ~JoinedThread() { if (th.joinable()) th.join(); }
+    } multi_holder;
+    std::thread& multi_thread = multi_holder.th;
+    std::once_flag multi_joined;
+    auto join_multi = [&] { std::call_once(multi_joined, [&] { if (multi_thread.joinable()) multi_thread.join(); }); };
     if (n_dev > 1) {
         std::string list;
         for (int d : devices) list += (list.empty() ? "" : ", ") + std::to_string(d);
-        (void)ffs_multi_init(devices.data(), (int)n_dev, nullptr);
-        std::printf("GPUs:        %s (frame queue shared; exchange of rotation lists: %s)\n", list.c_str(), ffs_multi_transport());
+        if (need_exchange) multi_thread = std::thread([&devices, n_dev] { (void)ffs_multi_init(devices.data(), (int)n_dev, nullptr); });
+        const char* env = std::getenv("FFS_GATHER");
+        std::printf("GPUs:        %s (frame queue shared; exchange of rotation lists: %s)\n", list.c_str(),
+                    need_exchange ? (env ? env : "rccl") : "none needed (stills)");
+        stamp("exchange between GPUs set going");
     }
     std::vector<ffs_ctx*> ctxs(n_dev, nullptr);
     for (uint32_t di = 0; di < n_dev; ++di) {
@@ -499,6 +530,7 @@ int main(int argc, char** argv) {
             std::printf("Error: %s\n", ffs_last_error(nullptr));
             return 1;
         }
+        stamp("ffs_ctx_create (code object, mask tables, shared HIP streams)");
     }
     ffs_ctx* ctx = ctxs[0];  // owns the 3D stack; also the context the one-off steps below report from
     {  // upload_mask, spotfinder.cc:61-108
@@ -574,6 +606,7 @@ int main(int argc, char** argv) {
 
     std::unique_ptr<PipeHandler> pipe;
     if (args.pipe_fd != -1) pipe = std::make_unique<PipeHandler>(args.pipe_fd);
+    stamp("masks uploaded, parameters set: the timed loop starts");
 
     const auto all_start = std::chrono::steady_clock::now();
     std::atomic<uint32_t> next_image{0};
@@ -726,6 +759,7 @@ int main(int argc, char** argv) {
                 if (rotation) {
                     // key = image number read (rotation_slices[offset_image_num], :913-918); the stack has its own lock (the
                     // reference's rotation_slices_mutex), held only while the transfer is enqueued
+                    join_multi();   // (the exchange's communicators, initialised beside the run so far)
                     if (ffs_stack3d_add_batch(stack, A.s) != FFS_OK) { fail("", ctx); break; }
                 }
                 // what this batch prints and sends goes out in one piece each (the collector is the one thread between the GPU and a
@@ -1269,8 +1303,23 @@ int main(int argc, char** argv) {
     if (time_waiting < 10) std::printf("Total time waiting for images to appear: %.0f ms\n", time_waiting * 1000);
     else std::printf("Total time waiting for images to appear: %.2f s\n", time_waiting);
     pipe.reset();
+    join_multi();
+    stamp("timed loop and reports done");
+    const int exit_code = (args.validate && validate_mismatches.load()) ? 1 : 0;
+    if (!args.clean_exit) {
+        // Every result is out and nothing is in flight: the process ends here.  Destroying streams and contexts (35-90 ms: pinned
+        // staging areas are unregistered, device memory freed) and the runtime's own exit handlers (~100 ms) do nothing a dying
+        // process needs -- the kernel driver releases the GPU's resources -- and the service starts one process per request
+        // (service.py:497): they were a fifth of a 1000-image request's wall time.  --clean-exit keeps the full teardown.
+        std::fflush(stdout);
+        std::fflush(stderr);
+        std::_Exit(exit_code);
+    }
     for (ffs_stream* st : retired_streams) ffs_stream_destroy(st);
+    stamp("streams destroyed");
     for (ffs_ctx* cx : ctxs) ffs_ctx_destroy(cx);
     for (ffs_ctx* cx : vctxs) if (cx) ffs_ctx_destroy(cx);
-    return (args.validate && validate_mismatches.load()) ? 1 : 0;
+    stamp("contexts destroyed: main returns (the runtime's own exit handlers follow)");
+    std::fflush(stdout);
+    return exit_code;
 }

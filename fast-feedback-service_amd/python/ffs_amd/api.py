@@ -82,7 +82,7 @@ EXPORTS = [
     "ffs_submit_device", "ffs_ctx_device_layout", "ffs_wait", "ffs_stream_batch_arrays", "ffs_stream_timings",
     "ffs_submit_compressed", "ffs_decode_only", "ffs_stream_spot_centres", "ffs_bench_threshold", "ffs_bench_hbm", "ffs_stream_debug_planes", "ffs_stream_debug_bitplane", "ffs_selftest_sqrt", "ffs_stack3d_create",
     "ffs_stack3d_destroy", "ffs_stack3d_add_batch", "ffs_stack3d_add_slice", "ffs_stack3d_finish", "ffs_stack3d_signals", "ffs_stack3d_last_finish_ms", "ffs_multi_init", "ffs_multi_transport",
-    "ffs_ctx_set_tuning", "ffs_bench_pipeline", "ffs_device_numa_node", "ffs_stream_reserve_host", "ffs_stream_last_path",
+    "ffs_ctx_set_tuning", "ffs_bench_pipeline", "ffs_device_numa_node", "ffs_stream_reserve_host", "ffs_stream_last_path", "ffs_multi_gather_rows",
 ]
 
 _lib = None
@@ -476,6 +476,18 @@ def multi_init(devices, transport=None) -> str:
     if rc != 0:
         raise FfsError(rc, lib.ffs_last_error(None).decode())
     return lib.ffs_multi_transport().decode()
+
+
+def multi_gather_rows(streams, root: int = 0, cap: int = 1 << 20) -> np.ndarray:
+    """ffs_multi_gather_rows: the centre rows of the streams' last batches through RCCL (counts by all-gather, rows by send / recv to
+    the root's device, one copy to the host) -> (n, 4) float32, lane 0 = frame id bits, in the order of `streams`."""
+    lib = load_library()
+    lib.ffs_multi_gather_rows.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    arr = (C.c_void_p * len(streams))(*[s._h for s in streams])
+    out = np.empty((cap, 4), np.float32)
+    n = C.c_uint32()
+    streams[root].ctx._check(lib.ffs_multi_gather_rows(arr, len(streams), root, out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+    return out[:n.value].copy()
 
 
 class Stack3D:

@@ -356,6 +356,18 @@ int ffs_stack3d_finish(ffs_stack3d *st, const ffs_reflection **reflections,
  * overflowed its stream's lists reaches the stack from any GPU (its list goes up from the host, as on one GPU). */
 int ffs_multi_init(const int *devices, int n_devices, const char *transport);
 const char *ffs_multi_transport(void);
+/* The gather of the per-frame spot lists over RCCL (BASELINE.json north_star, SURVEY section 8(e): "ncclAllGather of per-rank record
+ * counts, then grouped ncclSend / ncclRecv of the packed spot records to rank 0, then a single D2H"; the reference has one device and
+ * no such step).  streams[i]: one stream per taking-part context, each with a completed batch (after ffs_wait) whose centre rows
+ * (frame id bits, x, y, z: ffs_stream_spot_centres) are what travels; every rank of the communicator ffs_multi_init built needs at
+ * least one stream, contexts that share a GPU share its rank (their rows travel as one message).  The rows arrive in rows4_out (host
+ * memory, room for cap rows of four floats) rank after rank, inside a rank in the order of `streams`; *n_rows = rows wanted.  FFS_ERR_OVERFLOW: they do not fit cap; FFS_ERR_INVALID: no RCCL
+ * communicators (ffs_multi_transport() != "rccl").  A stream of the root's own GPU hands its rows over by a device copy unless the
+ * transport was forced (ffs_multi_init(.., "rccl") or FFS_GATHER): then it sends to its own rank -- what a one-GPU box can rehearse.
+ * In ONE process the rows are on the host already after ffs_wait; reading them there is the faster gather:
+ * this entry point is the A/B partner and the building block for drivers that keep the rows on the devices. */
+int ffs_multi_gather_rows(ffs_stream *const *streams, uint32_t n_streams, uint32_t root, float *rows4_out, uint32_t cap,
+                          uint32_t *n_rows);
 /* NUMA node the GPU hangs off (sysfs), -1 if unknown: where a driver should keep the worker threads that feed
  * it (the reference pins nothing: one device, spotfinder.cc:725-742). */
 int ffs_device_numa_node(int device);

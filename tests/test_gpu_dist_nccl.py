@@ -82,3 +82,49 @@ def test_one_rank_nccl_gather_of_hip_spots(ffs):
             np.testing.assert_array_equal(merged[fid][1], inten)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("transport", [None, "rccl"])
+def test_native_gather_of_spot_rows(ffs, transport):
+    """ffs_multi_gather_rows: the library's own RCCL gather of 2D spot rows (counts by ncclAllGather, rows by ncclSend / ncclRecv to the
+    root device, one copy to the host) with two contexts on this one GPU -- a one-rank communicator.  transport None: the streams
+    of the root's GPU hand their rows over by device copies (the count exchange is the collective that runs); "rccl": forced, every
+    stream sends to its own rank.  An empty batch on one side, row order = stream order, too small a receiver reported."""
+    from ffs_amd import api
+    W, H, B = 517, 389, 4
+    imgs, mask = [], None
+    for i in range(2 * B):
+        img, mask = make_frame(W=W, H=H, seed=300 + i, n_spots=25)
+        imgs.append(img)
+    got_t = api.multi_init([0, 0], transport)
+    if got_t != "rccl":
+        pytest.skip("no RCCL on this machine")
+    ctxs = [ffs.Context(W, H, np.uint16, max_batch=B) for _ in range(2)]
+    streams = []
+    for c in ctxs:
+        c.set_mask(mask)
+        c.set_params(want_reflections=1)
+        streams.append(c.stream())
+    res = [streams[0].process(np.stack(imgs[:B]), first_frame_id=(1 << 24) + 1), streams[1].process(np.stack(imgs[B:]), first_frame_id=77)]
+    want = []
+    for s in streams:
+        host = np.empty((4096 + 1, 4), np.float32)
+        n = s.pack_spot_centres(host, 4096)
+        want.append(host[:n].copy())
+    assert len(want[0]) > 20 and len(want[1]) > 20
+    for root in (0, 1):
+        rows = api.multi_gather_rows(streams, root=root, cap=8192)
+        np.testing.assert_array_equal(rows.view(np.uint32), np.concatenate(want).view(np.uint32))
+    rows = api.multi_gather_rows(streams[::-1], root=0, cap=8192)          # stream order is row order
+    np.testing.assert_array_equal(rows.view(np.uint32), np.concatenate(want[::-1]).view(np.uint32))
+    with pytest.raises(ffs.FfsError):
+        api.multi_gather_rows(streams, root=0, cap=len(want[0]) + 3)
+    # one side with nothing to send
+    streams[1].process(np.zeros((B, H, W), np.uint16), first_frame_id=500)
+    rows = api.multi_gather_rows(streams, root=1, cap=8192)
+    np.testing.assert_array_equal(rows.view(np.uint32), want[0].view(np.uint32))
+    # while a batch is in flight the stream is refused
+    streams[0].submit(np.stack(imgs[:B]), first_frame_id=0)
+    with pytest.raises(ffs.FfsError):
+        api.multi_gather_rows(streams, root=0, cap=8192)
+    streams[0].wait()

@@ -87,3 +87,19 @@ def test_bench_workload_fixture(workload, algorithm, frame):
     assert (cc.num_strong_pixels, len(cc.boxes), cc.n_unfiltered_boxes, len(refl.reflections)) == (
         exp["num_strong_pixels"][frame], exp["n_boxes"][frame], exp["n_components"][frame], exp["n_reflections"][frame])
     assert fixtures.frame_digest(cc.boxes, refl.reflections) == exp["digest"][frame].tobytes()
+
+
+def test_sweep_fixture_frames():
+    """The rotation-sweep entry of tests/golden/bench_workloads.npz (BASELINE.json configs[4], bench.py --workload sweep16m): two of
+    its 100 frames through the restatement give the committed strong-pixel and box counts, and the table's counts are consistent
+    (found = calculated - filtered) -- the whole sweep is re-derived on the GPU box by tests/test_gpu_fullsize.py."""
+    from ffs_amd import fixtures, synth
+    exp = fixtures.load_expected_sweep("sweep16m")
+    assert exp is not None and len(exp["num_strong_pixels"]) == 100 and len(exp["digest"]) == 32
+    assert exp["n_reflections"] == exp["n_calculated"] - exp["n_filtered_size"] - exp["n_filtered_sep"] and exp["n_reflections"] > 300
+    p = synth.sweep_params(seed=5000, n_frames=100, n_spots=800)
+    mask = synth.mask_eiger16m()
+    for z in (3, 57):
+        img = synth.frame(p, z)
+        cc = O.cc2d(O.dispersion(img, mask), img, 3)
+        assert (cc.num_strong_pixels, len(cc.boxes)) == (exp["num_strong_pixels"][z], exp["n_boxes"][z])
