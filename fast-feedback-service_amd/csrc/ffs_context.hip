@@ -434,7 +434,7 @@ extern "C" int ffs_ctx_set_tuning(ffs_ctx* c, const char* key, long long value) 
     else if (k == "strong_log") { if ((ok = in(0, 1))) t.strong_log = (int)value; }
     else if (k == "chain_runs") { if ((ok = in(0, 2))) t.chain_runs = (int)value; }
     else if (k == "wait_ahead") { if ((ok = in(0, 1))) t.wait_ahead = (int)value; }
-    else if (k == "sparse_bands") { if ((ok = in(0, 1))) t.sparse_bands = (int)value; }
+    else if (k == "sparse_bands") { if ((ok = in(0, 2))) t.sparse_bands = (int)value; }
     else if (k == "sparse_priority") {
         // priority of the context's two sparse HIP streams: 0 = highest (default), 1 = lowest, 2 = the dense stream's; before the first stream is created
         if ((ok = in(0, 2) && c->n_streams_made == 0)) {

@@ -95,7 +95,8 @@ struct Tuning {
     int chain_runs = 1;         // sparse_stage 2: frames beyond the LDS forest of pixels stay in the one launch when their RUNS fit
                                 //    (16-bit pixels, rows up to 16383 pixels); 0 = such batches take the four grid-wide kernels; 2 = runs for every frame
     int sparse_bands = 1;       // standard path with wave logs, lists not asked for: the sparse stage in small workgroups (kernels_band.hpp: a wave per
-                                //    band of a frame + a merge per frame) instead of k_frame_chain's one workgroup per frame; 0 = k_frame_chain
+                                //    band of a frame + a merge per frame) instead of k_frame_chain's one workgroup per frame: 1 = with one or with four
+                                //    and more batches in flight (measured: ffs_submit.hip), 2 = always, 0 = never
     int wait_ahead = 1;         // a thread of the context assembles each batch's result arrays as soon as the GPU has finished it (0: ffs_wait does)
     int sparse_priority = 0;    // priority of the context's sparse HIP streams: 0 = highest, 1 = lowest, 2 = the dense stream's
 #ifdef FFS_EXPERIMENTS

@@ -263,7 +263,10 @@ extern "C" int ffs_multi_init(const int* devices, int n_devices, const char* tra
     const std::string want = transport ? transport : (env ? env : "rccl");
     g_gather_forced = transport != nullptr || env != nullptr;
     g_want_rccl = want == "rccl";
-    if (!g_comms.empty() && distinct == g_comm_devices) return FFS_OK;
+    if (!g_comms.empty() && distinct == g_comm_devices) {   // the communicators are there already: only the choice of transport may change
+        g_multi_transport = g_want_rccl ? kTransportRccl : (distinct.size() > 1 ? kTransportPeer : kTransportNone);
+        return FFS_OK;
+    }
     if (!g_comms.empty() && g_rccl.CommDestroy) {
         for (ncclComm_t cm : g_comms) (void)g_rccl.CommDestroy(cm);
         g_comms.clear();

@@ -428,7 +428,12 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
     // The sparse stage in small workgroups (kernels_band.hpp): wave logs, nobody reads the pixel lists or the byte mask, a geometry
     // its LDS plan holds, and the stream's recent batches did not overflow that plan.
     const bool need_lists = p.want_strong_list || c->tune.device_lists == 1 || (c->tune.device_lists == 2 && g_live_stacks.load() > 0);
-    const bool banded = use_log && c->tune.sparse_bands != 0 && !need_lists && !ta.dense_mask && !s->bands_once_off && s->band_backoff == 0
+    // By pipeline depth (tuning "sparse_bands" = 1): its two launches each become ready behind a streaming kernel that is already
+    // being dispatched, so a batch's results are two steps away -- hidden with four batches in flight (101 k against 95.6 k frames/s),
+    // not with two or three (79 k / 89 k against 88 k / 95 k for the one-workgroup launch with its head start); alone in flight the
+    // band waves win again (58 k against 53 k: nothing to wait behind).  profiles/r05n_bands_by_pipeline_depth.log
+    const bool depth_ok = c->tune.sparse_bands >= 2 || depth >= 4 || depth <= 1;
+    const bool banded = use_log && c->tune.sparse_bands != 0 && depth_ok && !need_lists && !ta.dense_mask && !s->bands_once_off && s->band_backoff == 0
                         && band_stage_for(s, ta_launch, n);
     if (use_log && s->band_backoff > 0 && !s->bands_once_off) --s->band_backoff;
     s->band_mode = banded;

@@ -178,6 +178,15 @@ int ffs_ctx_set_params(ffs_ctx *ctx, const ffs_params *p);
  *   "chain_runs"       (1) with "sparse_stage" 2: such dense batches of 16-bit frames stay in the one launch, its union-find
  *                          over runs of strong pixels instead of pixels (up to 16384 runs per frame); 0 = they take the grid-wide kernels;
  *                          2 = every frame of 16-bit pixels goes over runs (A/B partner: no faster on sparse frames)
+ *   "sparse_bands"     (1) standard path with wave logs when nobody reads the pixel lists or the byte mask: the sparse stage in small
+ *                          workgroups -- a wave per band of a frame, then a merge per frame (round 5) -- instead of the one workgroup per
+ *                          frame, which holds a whole CU: 1 = with one or with four and more batches in flight (where it measures faster),
+ *                          2 = always, 0 = never.  A band beyond its plan (768 strong pixels, 256 components) sends the batch back
+ *                          through the one-workgroup launch inside ffs_wait
+ *   "wait_ahead"       (1) a thread of the context turns each batch's records into the result arrays as soon as the GPU has finished
+ *                          it, so ffs_wait finds them ready (0: ffs_wait does it, as in rounds 1-4)
+ *   "sparse_priority"  (0) priority of the context's two sparse HIP streams: 0 = highest, 1 = lowest, 2 = the dense stream's (before
+ *                          the first stream is created; measured: 0 and 1 alike, 2 costs 15 %)
  *   "sched"            (3) 3 = shared dense / sparse / upload HIP streams per context, 0 = one per ffs_stream
  *                          (before the first stream is created)
  *   "direct_records"   (1) records written straight into pinned host memory (before the first stream is created)

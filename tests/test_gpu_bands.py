@@ -160,6 +160,7 @@ def test_bands_with_several_batches_in_flight(ffs):
     frames = np.concatenate([frames, frames[:1]])
     ones = np.ones((H, W), np.uint8)
     ctx = ffs.Context(W, H, np.uint16, max_batch=B)
+    ctx.set_tuning(sparse_bands=2)      # (always: by default the second and third batch of a pipeline that fills take the one-workgroup launch)
     ctx.set_params(want_strong_list=0, min_spot_size=2)
     streams = [ctx.stream() for _ in range(4)]
     want = None
@@ -174,6 +175,17 @@ def test_bands_with_several_batches_in_flight(ffs):
             else:
                 for fr, img, w in zip(res, frames, want):
                     assert_frame_matches_oracle(fr, img, ones, min_spot_size=2, precomputed=w)
+    # the default: by pipeline depth -- bands with one or four batches in flight, the one-workgroup launch with two or three
+    ctx.set_tuning(sparse_bands=1)
+    for s in streams:
+        s.submit(frames, first_frame_id=0)
+    paths = []
+    for s in streams:
+        res = s.wait()
+        paths.append("bands" in s.last_path()[0])
+        for fr, img, w in zip(res, frames, want):
+            assert_frame_matches_oracle(fr, img, ones, min_spot_size=2, precomputed=w)
+    assert paths == [True, False, False, True], paths
 
 
 def test_bands_of_two_heights(ffs):
