@@ -34,7 +34,7 @@ from ffs_amd import fixtures  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 CASES = [("eiger16m", "dispersion"), ("eiger16m", "dispersion_extended"), ("jungfrau9m", "dispersion")]
-N_FRAMES = 32
+N_FRAMES = 56     # (covers 32, 48 and 56 frames per step: bench.py --batch)
 
 
 def one_frame(img, mask, algorithm, use_ref):
