@@ -318,6 +318,8 @@ static void ctx_destroy_internal(ffs_ctx* c) {
     if (c->d_ginfo) (void)hipFree(c->d_ginfo);
     if (c->d_mmap) (void)hipFree(c->d_mmap);
     if (c->dense_st) (void)hipStreamDestroy(c->dense_st);
+    if (c->dense_st2) (void)hipStreamDestroy(c->dense_st2);
+    if (c->d_handoff) (void)hipFree(c->d_handoff);
     if (c->up_st) (void)hipStreamDestroy(c->up_st);
     for (auto st : c->sparse_st) if (st) (void)hipStreamDestroy(st);
     for (auto e : c->chain_ev) if (e) (void)hipEventDestroy(e);
@@ -433,6 +435,7 @@ extern "C" int ffs_ctx_set_tuning(ffs_ctx* c, const char* key, long long value) 
     else if (k == "device_lists") { if ((ok = in(0, 2))) t.device_lists = (int)value; }
     else if (k == "strong_log") { if ((ok = in(0, 1))) t.strong_log = (int)value; }
     else if (k == "chain_runs") { if ((ok = in(0, 2))) t.chain_runs = (int)value; }
+    else if (k == "dense_overlap") { if ((ok = in(0, 1))) t.dense_overlap = (int)value; }
     else if (k == "wait_ahead") { if ((ok = in(0, 1))) t.wait_ahead = (int)value; }
     else if (k == "sparse_bands") { if ((ok = in(0, 2))) t.sparse_bands = (int)value; }
     else if (k == "sparse_priority") {
@@ -507,6 +510,7 @@ void stream_destroy_internal(ffs_stream* s) {
     if (s->big) stream_destroy_internal(s->big);
     if (s->st_up && s->st_up != s->st) (void)hipStreamSynchronize(s->st_up);
     if (s->st) (void)hipStreamSynchronize(s->st);
+    if (s->st_shared && s->ctx->dense_st2) (void)hipStreamSynchronize(s->ctx->dense_st2);   // (the dense stream's partner may hold this stream's kernel)
     if (s->st2 && s->st2 != s->st) { (void)hipStreamSynchronize(s->st2); if (!s->st2_shared) (void)hipStreamDestroy(s->st2); }
     // (d_n_comp, d_summary and d_overflow live inside the d_num_strong allocation)
     if (s->h_pack_tab) (void)hipHostFree(s->h_pack_tab);

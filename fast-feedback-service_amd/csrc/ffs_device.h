@@ -113,6 +113,11 @@ struct ThresholdArgs {
     uint2* wlog;               // [waves][kWlogCap] (row << 16 | group, frame in super row << 16 | undecided << 8 | strong); nullptr: off
     uint32_t* wlog_n;          // [waves] entries a wave wanted to write (more than kWlogCap: overflow)
     uint4* wpix;               // [waves][kWlogCap] the entry's eight (masked) pixels: the sparse launch never gathers from the image
+    // hand-over to the next streaming kernel (ffs_submit.hip, tuning "dense_overlap"): the launch's LAST workgroup -- dispatch is in
+    // order -- writes handoff_seq here as it starts; the other dense HIP stream waits for that value before ITS kernel, which then
+    // flows into the slots this launch's last round of waves leaves.  nullptr: off.
+    uint32_t* handoff;
+    uint32_t handoff_seq;
     int dbg;                   // timing experiments (-DFFS_EXPERIMENTS builds only; results are wrong when set)
 };
 

@@ -97,6 +97,12 @@ struct Tuning {
     int sparse_bands = 1;       // standard path with wave logs, lists not asked for: the sparse stage in small workgroups (kernels_band.hpp: a wave per
                                 //    band of a frame + a merge per frame) instead of k_frame_chain's one workgroup per frame: 1 = with one or with four
                                 //    and more batches in flight (measured: ffs_submit.hip), 2 = always, 0 = never
+    int dense_overlap = 0;      // wave-log path: 1 = consecutive streaming kernels on two HIP streams, handed over by a value the launch's last workgroup
+                                //    writes as it starts (hipStreamWaitValue32); 0 = one dense stream, a barrier between its dispatches.  Measured round 5:
+                                //    the idea works in isolation (tools/ubench/wait_value.hip: 159 -> 146 us per launch of 15 064 sleeping waves) and LOSES
+                                //    8-10 % in the pipeline (0.335-0.35 against 0.307-0.313 ms per step, four or eight hardware queues:
+                                //    profiles/r05t_dense_overlap_ab.log) -- the next kernel's first waves and the band launches then fight over the same
+                                //    freed slots, and each streaming kernel takes 0.325 instead of 0.298 ms.  Off; kept as the A/B partner
     int wait_ahead = 1;         // a thread of the context assembles each batch's result arrays as soon as the GPU has finished it (0: ffs_wait does)
     int sparse_priority = 0;    // priority of the context's sparse HIP streams: 0 = highest, 1 = lowest, 2 = the dense stream's
 #ifdef FFS_EXPERIMENTS
@@ -168,6 +174,14 @@ struct ffs_ctx {
     uint8_t* d_ginfo = nullptr;  // per-group mask bits + window-count bounds (kernels_stream.hpp)
     uint8_t* d_mmap = nullptr;   // per-pixel window counts
     hipStream_t dense_st = nullptr;  // sched 3: the one stream of the dense kernels
+    // ... and its partner (tuning "dense_overlap", off: measured slower in the pipeline): the streaming kernels of the wave-log path take
+    // the two alternately, each behind a wait for the value the previous launch's last workgroup writes into `d_handoff` (signal
+    // memory) as it starts.  Both are made by the first launch that asks.  dense_mu: one launch at a time decides.
+    hipStream_t dense_st2 = nullptr;
+    uint32_t* d_handoff = nullptr;
+    std::mutex dense_mu;
+    uint32_t handoff_seq = 0;
+    int handoff_last = -1;           // which of the two streams took the last launch of the chain
     hipStream_t up_st = nullptr;     // ... and the one stream of uploads and decoding
     hipStream_t sparse_st[2] = {nullptr, nullptr};  // ... the sparse launches of the context's streams, alternating
     int n_streams_made = 0;

@@ -149,14 +149,15 @@ static dim3 stream_grid(const ThresholdArgs& a, uint32_t n_frames) {
 
 // The whole standard threshold in one kernel: final strong plane + per-tile counts (atomics into zeroed counters).
 // Start and stop events ride on the dispatch itself (its completion signal): no marker packets around it.
-static void launch_stream(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames, hipEvent_t start, hipEvent_t stop) {
+static void launch_stream(ffs_stream* s, const ThresholdArgs& a, uint32_t n_frames, hipEvent_t start, hipEvent_t stop, hipStream_t st = nullptr) {
     const dim3 grid = stream_grid(a, n_frames);
-    if (s->ctx->pixel_bytes == 4 && a.dense_mask) hipExtLaunchKernelGGL((k_stream_u32<2, true>), grid, dim3(64), 0, s->st, start, stop, 0, a);
-    else if (s->ctx->pixel_bytes == 4) hipExtLaunchKernelGGL((k_stream_u32<2, false>), grid, dim3(64), 0, s->st, start, stop, 0, a);
-    else if (a.dense_mask) hipExtLaunchKernelGGL((k_stream_u16<2, false, true>), grid, dim3(64), 0, s->st, start, stop, 0, a);
-    else if (s->ctx->tune.rows_ahead == 3) hipExtLaunchKernelGGL((k_stream_u16<3, false, false>), grid, dim3(64), 0, s->st, start, stop, 0, a);
-    else if (s->ctx->tune.rows_ahead >= 4) hipExtLaunchKernelGGL((k_stream_u16<4, false, false>), grid, dim3(64), 0, s->st, start, stop, 0, a);
-    else hipExtLaunchKernelGGL((k_stream_u16<2, false, false>), grid, dim3(64), 0, s->st, start, stop, 0, a);
+    if (!st) st = s->st;
+    if (s->ctx->pixel_bytes == 4 && a.dense_mask) hipExtLaunchKernelGGL((k_stream_u32<2, true>), grid, dim3(64), 0, st, start, stop, 0, a);
+    else if (s->ctx->pixel_bytes == 4) hipExtLaunchKernelGGL((k_stream_u32<2, false>), grid, dim3(64), 0, st, start, stop, 0, a);
+    else if (a.dense_mask) hipExtLaunchKernelGGL((k_stream_u16<2, false, true>), grid, dim3(64), 0, st, start, stop, 0, a);
+    else if (s->ctx->tune.rows_ahead == 3) hipExtLaunchKernelGGL((k_stream_u16<3, false, false>), grid, dim3(64), 0, st, start, stop, 0, a);
+    else if (s->ctx->tune.rows_ahead >= 4) hipExtLaunchKernelGGL((k_stream_u16<4, false, false>), grid, dim3(64), 0, st, start, stop, 0, a);
+    else hipExtLaunchKernelGGL((k_stream_u16<2, false, false>), grid, dim3(64), 0, st, start, stop, 0, a);
 }
 static void launch_bright_fix(ffs_stream* s, const ThresholdArgs& a, hipStream_t st) {
     if (s->ctx->pixel_bytes == 4) hipLaunchKernelGGL(k_bright_fix<uint32_t>, dim3(32), dim3(256), 0, st, a);
@@ -361,7 +362,8 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
     const bool ext = p.algorithm == FFS_ALGO_DISPERSION_EXTENDED;
 
     (void)hipGetLastError();  // drop any stale error state: the check below is for OUR launches
-    if (s->st_up != s->st && !s->dev_input) HIP_TRY(c, hipStreamWaitEvent(s->st, s->ev[1], 0));   // the frames are in place (upload / decode stream)
+    const bool wait_upload = s->st_up != s->st && !s->dev_input;   // the frames are in place behind ev[1] (upload / decode stream): waited for below,
+                                                                    // in the dense stream this batch's first kernel takes
     bool ext_plane_clean = false;
     if (ext) {
         const int rc = ensure_extended_buffers(s);
@@ -381,13 +383,20 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
     // again by the compaction); path 0 also keeps the occupancy bitmap in step with it
     const bool streamed = !ext;
     const bool list_path = streamed && !ta.bright_to_plane;
-    if (streamed && s->bits_dirty)  // (another algorithm or a failed batch left bits behind)
+    bool dense_resets = false;   // fills went into the stream's own dense stream: this batch's kernel has to follow them there
+    if (wait_upload && ext) HIP_TRY(c, hipStreamWaitEvent(s->st, s->ev[1], 0));
+    if (streamed && s->bits_dirty) {  // (another algorithm or a failed batch left bits behind)
         HIP_TRY(c, hipMemsetAsync(s->d_bits, 0, (size_t)s->max_batch * L.plane_frame_stride, s->st));
-    if (streamed && s->counts_dirty)
+        dense_resets = true;
+    }
+    if (streamed && s->counts_dirty) {
         HIP_TRY(c, hipMemsetAsync(s->d_tile_counts, 0, tile_counts_bytes(s), s->st));
+        dense_resets = true;
+    }
     if (s->occ_dirty) {
         HIP_TRY(c, hipMemsetAsync(s->d_occ, 0, (size_t)s->max_batch * occ_frame_words(L) * 4, s->st));
         s->occ_dirty = false;
+        dense_resets = true;
     }
     s->counts_dirty = true;
     s->bits_dirty = true;  // until every launch of this batch is enqueued (a failure in between leaves bits behind)
@@ -468,13 +477,53 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
     } else if (list_path && aside) {
         // the bright-window fix-up goes to the sparse stream (or into the sparse launch itself: chain_first; with wave logs the
         // sparse launch decides those pixels as it reads the logs)
-        launch_stream(s, ta_launch, n, ev_start, s->ev[2]);
+        // Wave-log path with a deep pipeline: the context's two dense HIP streams take the streaming kernels alternately (ffs_internal.hpp,
+        // "dense_overlap"): this launch waits for the value the PREVIOUS launch's last workgroup wrote as it started, not for that
+        // kernel's end, and writes its own.  Everything that must precede the kernel (the upload's event) goes into the same stream.
+        bool overlap = use_log && !chain_first && !dense_resets && c->tune.dense_overlap != 0 && s->st == c->dense_st;
+        std::unique_lock<std::mutex> dense_lock(c->dense_mu, std::defer_lock);   // (several threads submit to one context: a launch's number, stream and wait are one step)
+        if (overlap) {
+            dense_lock.lock();
+            if (!c->dense_st2) {   // the partner stream and the hand-over word: made on first use (nothing of this exists in a context that never asks)
+                int lo = 0, hi = 0, can = 0;
+                bool ok = hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device) == hipSuccess && can
+                          && hipExtMallocWithFlags(reinterpret_cast<void**>(&c->d_handoff), 8, hipMallocSignalMemory) == hipSuccess;
+                ok = ok && hipMemsetAsync(c->d_handoff, 0, 8, c->up_st) == hipSuccess && hipStreamSynchronize(c->up_st) == hipSuccess;
+                ok = ok && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess
+                     && hipStreamCreateWithPriority(&c->dense_st2, hipStreamNonBlocking, (lo + hi) / 2) == hipSuccess;
+                if (!ok) {
+                    (void)hipGetLastError();
+                    if (c->d_handoff) (void)hipFree(c->d_handoff);
+                    c->d_handoff = nullptr;
+                    c->dense_st2 = nullptr;
+                    c->tune.dense_overlap = 0;   // (not on this device)
+                    overlap = false;
+                    dense_lock.unlock();
+                }
+            }
+        }
+        if (overlap) {
+            const uint32_t seq = ++c->handoff_seq;
+            const int which = (int)(seq & 1u);
+            hipStream_t dst = which ? c->dense_st2 : c->dense_st;
+            if (wait_upload) HIP_TRY(c, hipStreamWaitEvent(dst, s->ev[1], 0));
+            if (c->handoff_last >= 0 && c->handoff_last != which)
+                HIP_TRY(c, hipStreamWaitValue32(dst, c->d_handoff, seq - 1, hipStreamWaitValueGte, 0xFFFFFFFFu));
+            ta_launch.handoff = c->d_handoff;
+            ta_launch.handoff_seq = seq;
+            launch_stream(s, ta_launch, n, ev_start, s->ev[2], dst);
+            c->handoff_last = which;
+        } else {
+            if (wait_upload) HIP_TRY(c, hipStreamWaitEvent(s->st, s->ev[1], 0));
+            launch_stream(s, ta_launch, n, ev_start, s->ev[2]);
+        }
         HIP_TRY(c, hipStreamWaitEvent(s->st2, s->ev[2], 0));
         if (!chain_first && !use_log) launch_bright_fix(s, ta, s->st2);
     } else if (ta.bright_to_plane == 2) {
         // the cross-check path of `spotfinder --validate` (tuning "threshold_path" = 2): no streaming kernel, no screen, no LDS
         // queue -- the plane starts as the valid-pixel mask, so k_exact gathers the window of EVERY valid pixel from memory and
         // applies the oracle's predicate to 64-bit sums (exact_strong).  Shares nothing with the hot path but that predicate.
+        if (wait_upload) HIP_TRY(c, hipStreamWaitEvent(s->st, s->ev[1], 0));
         if (ev_start) HIP_TRY(c, hipEventRecord(ev_start, s->st));
         HIP_TRY(c, hipMemsetAsync(s->d_sbytes, 0, (size_t)n * L.bytes_frame_stride, s->st));
         for (uint32_t f = 0; f < n; ++f)
@@ -483,6 +532,7 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
         HIP_TRY(c, hipEventRecord(s->ev[2], s->st));
         if (s->st2 != s->st) HIP_TRY(c, hipStreamWaitEvent(s->st2, s->ev[2], 0));
     } else {
+        if (wait_upload) HIP_TRY(c, hipStreamWaitEvent(s->st, s->ev[1], 0));
         launch_stream(s, ta, n, ev_start, nullptr);
         if (list_path) launch_bright_fix(s, ta, s->st);
         else launch_exact(s, ta, n, s->st);

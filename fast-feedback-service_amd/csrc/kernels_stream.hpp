@@ -175,6 +175,9 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     const int strip = qb % a.n_strips;
     const int band = xcd + 8 * (qb / a.n_strips);
     [[maybe_unused]] const uint32_t wave_id = blockIdx.y * gridDim.x + blockIdx.x;
+    if constexpr (!EXT)   // (the launch's last workgroup has started: every other one has been handed out -- see ThresholdArgs::handoff)
+        if (a.handoff && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && lane == 0)
+            __hip_atomic_store(a.handoff, a.handoff_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (band >= a.n_bands) {
         if constexpr (!EXT) if (a.wlog && lane == 0) a.wlog_n[wave_id] = 0;   // (every wave of the grid has a count)
         return;
@@ -671,6 +674,8 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
     const int strip = qb % a.n_strips;
     const int band = xcd + 8 * (qb / a.n_strips);
     [[maybe_unused]] const uint32_t wave_id = blockIdx.y * gridDim.x + blockIdx.x;
+    if (a.handoff && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && lane == 0)   // (see k_stream_u16)
+        __hip_atomic_store(a.handoff, a.handoff_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (band >= a.n_bands) {
         if (a.wlog && lane == 0) a.wlog_n[wave_id] = 0;   // (every wave of the grid has a count)
         return;

@@ -185,6 +185,9 @@ int ffs_ctx_set_params(ffs_ctx *ctx, const ffs_params *p);
  *                          through the one-workgroup launch inside ffs_wait
  *   "wait_ahead"       (1) a thread of the context turns each batch's records into the result arrays as soon as the GPU has finished
  *                          it, so ffs_wait finds them ready (0: ffs_wait does it, as in rounds 1-4)
+ *   "dense_overlap"    (0) 1 = consecutive streaming kernels of the wave-log path on two HIP streams, handed over by a value the launch's
+ *                          last workgroup writes as it starts (hipStreamWaitValue32) instead of the queue's barrier between two dispatches;
+ *                          works in isolation, measured 8-10 % slower in the pipeline: off, kept as the A/B partner
  *   "sparse_priority"  (0) priority of the context's two sparse HIP streams: 0 = highest, 1 = lowest, 2 = the dense stream's (before
  *                          the first stream is created; measured: 0 and 1 alike, 2 costs 15 %)
  *   "sched"            (3) 3 = shared dense / sparse / upload HIP streams per context, 0 = one per ffs_stream

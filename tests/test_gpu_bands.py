@@ -152,15 +152,18 @@ def test_bands_beyond_their_plan_fall_back(ffs):
             assert_frame_matches_oracle(fr, base, ones, min_spot_size=1)
 
 
-def test_bands_with_several_batches_in_flight(ffs):
-    """Four streams of one context, their batches in flight together (the bench's shape): every batch through the bands."""
+@pytest.mark.parametrize("dense_overlap", [0, 1])
+def test_bands_with_several_batches_in_flight(ffs, dense_overlap):
+    """Four streams of one context, their batches in flight together (the bench's shape): every batch through the bands.
+    dense_overlap = 1: the A/B partner that hands consecutive streaming kernels over between two HIP streams (off by default:
+    measured slower) gives the same results."""
     rng = np.random.default_rng(31)
     W, H, B = 1100, 450, 6
     frames = seam_frames(rng, W, H, np.uint16, 75)
     frames = np.concatenate([frames, frames[:1]])
     ones = np.ones((H, W), np.uint8)
     ctx = ffs.Context(W, H, np.uint16, max_batch=B)
-    ctx.set_tuning(sparse_bands=2)      # (always: by default the second and third batch of a pipeline that fills take the one-workgroup launch)
+    ctx.set_tuning(sparse_bands=2, dense_overlap=dense_overlap)      # (bands always: by default the second and third batch of a pipeline that fills take the one-workgroup launch)
     ctx.set_params(want_strong_list=0, min_spot_size=2)
     streams = [ctx.stream() for _ in range(4)]
     want = None
