@@ -575,3 +575,15 @@ def test_interrupt_wakes_readers_parked_for_a_free_assembly(tmp_path):
     assert "Running interrupted by user request" in out
     assert [json.loads(l)["file-number"] for l in lines] == list(range(N_have))
     assert f"{N_have} images in" in strip_ansi(out)
+
+
+def test_clean_exit_flag_keeps_the_full_teardown(tmp_path):
+    """By default the process leaves as soon as its last result is out (the service starts one per request); `--clean-exit`
+    destroys streams and contexts and lets the runtime tear itself down.  Same lines, same exit code, nothing on stderr either way."""
+    outs = []
+    for extra in ([], ["--clean-exit"]):
+        rc, out, err, lines = run_with_pipe(["synth:tiny:9", "--threads", "2", "--batch", "4", *extra], tmp_path)
+        assert rc == 0 and not err, (out[-300:], err)
+        outs.append([json.loads(l) for l in lines])
+        assert "9 images in" in strip_ansi(out)
+    assert outs[0] == outs[1] and [j["file-number"] for j in outs[0]] == list(range(9))
