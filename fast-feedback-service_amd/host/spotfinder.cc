@@ -59,7 +59,7 @@ struct Args {
     float max_sep = 2.0f, timeout = 30.0f, dmin = -1.f, dmax = -1.f, wavelength = 0.f, slot_margin = 2.0f;
     int pipe_fd = -1, device = 0;
     std::vector<int> devices;  // --devices / --gpus: the frame queue is dealt to all of them
-    std::string algorithm = "dispersion", detector_json;
+    std::string algorithm = "dispersion", detector_json, gather = "host";
     std::string max_valid = "trusted";   // trusted | none | N
     uint32_t min_count = 2;
     bool cpu_decode = false, no_numa_pinning = false, single_buffer = false, all_threads = false, read_only = false, clean_exit = false;
@@ -84,6 +84,9 @@ static void usage() {
       "              (-n threads are dealt round-robin to the GPUs, at least one each); rotation sweeps send\n"
       "              their strong-pixel lists to the first GPU's 3D stack (RCCL over xGMI, else peer copies)\n"
       "--all-threads: every one of the -n threads reads (default: at most eight per GPU when chunks are decoded there)\n"
+      "--gather host|rccl: with several GPUs and --output-for-index, where the spot centres of a round of batches (one per GPU) are\n"
+      "              collected: read from each context's host arrays (default: seven times cheaper inside one process), or gathered\n"
+      "              over RCCL to the first GPU (counts by all-gather, rows by send / recv, one copy to the host)\n"
       "--clean-exit: destroy streams and contexts and let the runtime tear itself down before the process ends (default: the\n"
       "              process leaves as soon as its last result is out -- a request's wall time ends there)\n"
       "--batch N:   frames per GPU batch (default 16 chunks / 4 decoded frames); a batch is filled by all readers of its GPU\n"
@@ -173,6 +176,7 @@ static Args parse_args(int argc, char** argv) {
             std::string tok;
             while (std::getline(ss, tok, ',')) r.devices.push_back((int)u32(tok, s));
         }
+        else if (s == "--gather") { r.gather = need(i, s); if (r.gather != "host" && r.gather != "rccl") arg_error("--gather takes host or rccl"); }
         else if (s == "--strict-dtype") r.strict_dtype = true;
         else if (s == "--max-valid") {
             r.max_valid = need(i, s);
@@ -507,7 +511,8 @@ int main(int argc, char** argv) {
     // contexts cost a 1000-image request) serves rotation sweeps only -- every frame's strong-pixel list has to reach the GPU that owns
     // the 3D stack -- so stills never pay it, and a sweep initialises it on a helper thread beside the contexts and the first batches
     // (joined before the first batch is added to the stack).
-    const bool need_exchange = n_dev > 1 && oscillation_width > 0;
+    const bool gather_rccl = n_dev > 1 && args.gather == "rccl" && args.output_for_index && !(oscillation_width > 0);
+    const bool need_exchange = n_dev > 1 && (oscillation_width > 0 || gather_rccl);
     struct JoinedThread {   // (an early `return` below must not meet a joinable std::thread)
         std::thread th;
         ~JoinedThread() { if (th.joinable()) th.join(); }
@@ -518,10 +523,12 @@ int main(int argc, char** argv) {
     if (n_dev > 1) {
         std::string list;
         for (int d : devices) list += (list.empty() ? "" : ", ") + std::to_string(d);
-        if (need_exchange) multi_thread = std::thread([&devices, n_dev] { (void)ffs_multi_init(devices.data(), (int)n_dev, nullptr); });
+        // (--gather rccl names the transport: contexts that share a GPU then send to their own rank, which a one-GPU box can rehearse)
+        if (need_exchange) multi_thread = std::thread([&devices, n_dev, gather_rccl] { (void)ffs_multi_init(devices.data(), (int)n_dev, gather_rccl ? "rccl" : nullptr); });
         const char* env = std::getenv("FFS_GATHER");
         std::printf("GPUs:        %s (frame queue shared; exchange of rotation lists: %s)\n", list.c_str(),
-                    need_exchange ? (env ? env : "rccl") : "none needed (stills)");
+                    oscillation_width > 0 ? (env ? env : "rccl") : "none needed (stills)");
+        if (gather_rccl) std::printf("Spot lists:  gathered over RCCL to GPU %d, one round of batches (one per GPU) at a time\n", devices[0]);
         stamp("exchange between GPUs set going");
     }
     std::vector<ffs_ctx*> ctxs(n_dev, nullptr);
@@ -722,6 +729,69 @@ int main(int argc, char** argv) {
         wake_all();
     };
 
+    // ---- --gather rccl: the spot centres of one ROUND of batches (local batch q of every GPU) through ffs_multi_gather_rows ----------
+    // The collectors meet once per round; the last to arrive runs the collective for all (counts by ncclAllGather, rows by ncclSend /
+    // ncclRecv to the first GPU, one copy to the host) and everybody takes its own batch's rows from the gathered table.  A round
+    // that cannot fill up (the data set ends, an interrupt) is served from the host arrays, as `--gather host` serves all of them.
+    struct GatherRound {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<ffs_stream*> streams;
+        std::vector<uint32_t> n_rows, row_at;   // per GPU: rows of its batch, where they start in `rows`
+        std::vector<float> rows;
+        uint32_t arrived = 0;
+        uint64_t round = 0;                      // rounds served so far
+        bool ok = false;                         // the round just served went through RCCL
+    } gr;
+    gr.streams.assign(n_dev, nullptr);
+    gr.n_rows.assign(n_dev, 0);
+    gr.row_at.assign(n_dev, 0);
+    const uint32_t gather_cap = 1u << 20;
+    if (gather_rccl) gr.rows.resize((size_t)gather_cap * 4);
+    std::vector<int> gpu_rank(n_dev, 0);   // rank of a GPU's device in the communicator: distinct devices in order of appearance (ffs_multi_init)
+    {
+        std::vector<int> distinct;
+        for (uint32_t di = 0; di < n_dev; ++di) {
+            auto it = std::find(distinct.begin(), distinct.end(), devices[di]);
+            if (it == distinct.end()) { distinct.push_back(devices[di]); gpu_rank[di] = (int)distinct.size() - 1; }
+            else gpu_rank[di] = (int)(it - distinct.begin());
+        }
+    }
+    std::atomic<uint64_t> rccl_rounds{0}, host_rounds{0};
+    // -> pointer to this GPU's rows (frame id bits, x, y, z) of the round, or nullptr: read them from the host arrays
+    auto gather_round = [&](uint32_t di, uint64_t q, ffs_stream* st, uint32_t my_rows) -> const float* {
+        const bool full_round = (q + 1) * n_dev <= total_batches;   // every GPU has a local batch q
+        if (!full_round) { host_rounds += 1; return nullptr; }
+        std::unique_lock<std::mutex> lock(gr.mu);
+        // (waits in slices: a failure or the end of the readers is announced on the GPUs' condition variables, not on this one)
+        while (!(gr.round == q || failed.load() || readers_done.load() || g_stop.load())) gr.cv.wait_for(lock, 20ms);   // the previous round has been taken by everybody
+        if (gr.round != q) { host_rounds += 1; return nullptr; }
+        gr.streams[di] = st;
+        gr.n_rows[di] = my_rows;
+        if (++gr.arrived == n_dev) {
+            join_multi();
+            // rows arrive rank after rank, inside a rank in the order of `streams` (= GPU order)
+            uint32_t at = 0;
+            for (int r = 0; r < (int)n_dev; ++r)
+                for (uint32_t g = 0; g < n_dev; ++g)
+                    if (gpu_rank[g] == r) { gr.row_at[g] = at; at += gr.n_rows[g]; }
+            uint32_t got = 0;
+            gr.ok = at <= gather_cap && ffs_multi_gather_rows(gr.streams.data(), n_dev, 0, gr.rows.data(), gather_cap, &got) == FFS_OK && got == at;
+            (gr.ok ? rccl_rounds : host_rounds) += 1;
+            gr.arrived = 0;
+            gr.round = q + 1;
+            gr.cv.notify_all();
+        } else {
+            while (!(gr.round > q || failed.load() || readers_done.load() || g_stop.load())) gr.cv.wait_for(lock, 20ms);
+            if (gr.round <= q) {   // the round cannot fill up any more (the readers have stopped): everybody reads the host arrays
+                gr.arrived = 0;
+                host_rounds += 1;
+                return nullptr;
+            }
+        }
+        return gr.ok ? gr.rows.data() + (size_t)gr.row_at[di] * 4 : nullptr;
+    };
+
     // ---- the collector of one GPU: results of its batches, in order (the reference's post-processing of an image, :901-1087) ----
     auto collector = [&](uint32_t di) {
         Gpu& G = *gpus[di];
@@ -761,6 +831,12 @@ int main(int argc, char** argv) {
                     // reference's rotation_slices_mutex), held only while the transfer is enqueued
                     join_multi();   // (the exchange's communicators, initialised beside the run so far)
                     if (ffs_stack3d_add_batch(stack, A.s) != FFS_OK) { fail("", ctx); break; }
+                }
+                const float* round_rows = nullptr;   // --gather rccl: this batch's centre rows as they came back from the collective
+                if (gather_rccl) {
+                    uint32_t my_rows = 0;
+                    for (uint32_t i = 0; i < nres; ++i) my_rows += res[i].n_reflections;
+                    round_rows = gather_round(di, q, A.s, my_rows);
                 }
                 // what this batch prints and sends goes out in one piece each (the collector is the one thread between the GPU and a
                 // free staging area: a printf and a write per image, into pipes a Python caller drains, were on that path)
@@ -823,8 +899,13 @@ int main(int argc, char** argv) {
                             j += ",\"spot_centers\":[";
                             for (uint32_t qq = 0; qq < r.n_reflections; ++qq) {
                                 if (qq) j += ",";
-                                j += json_number(r.reflections[qq].com_x) + "," + json_number(r.reflections[qq].com_y) + ","
-                                     + json_number(r.reflections[qq].com_z);
+                                if (round_rows) {   // (frame id bits, x, y, z) rows in frame order: the next n_reflections are this image's
+                                    j += json_number(round_rows[1]) + "," + json_number(round_rows[2]) + "," + json_number(round_rows[3]);
+                                    round_rows += 4;
+                                } else {
+                                    j += json_number(r.reflections[qq].com_x) + "," + json_number(r.reflections[qq].com_y) + ","
+                                         + json_number(r.reflections[qq].com_z);
+                                }
                             }
                             j += "]";
                         }
@@ -1297,6 +1378,9 @@ int main(int argc, char** argv) {
         std::printf("CPU time of the process: %.2f s user + %.2f s system over %.2f s since launch (%.1f cores busy on average)\n", user, sys,
                     since_launch, (user + sys) / since_launch);
     }
+    if (gather_rccl)
+        std::printf("Spot lists: %llu rounds of %u batches gathered over RCCL, %llu batch results read from the host arrays\n",
+                    (unsigned long long)rccl_rounds.load(), n_dev, (unsigned long long)host_rounds.load());
     if (args.validate)
         std::printf("Validation: %u of %u images differ between the hot path and the gather path\n", validate_mismatches.load(), done);
     const double time_waiting = time_waiting_acc.load();

@@ -587,3 +587,23 @@ def test_clean_exit_flag_keeps_the_full_teardown(tmp_path):
         outs.append([json.loads(l) for l in lines])
         assert "9 images in" in strip_ansi(out)
     assert outs[0] == outs[1] and [j["file-number"] for j in outs[0]] == list(range(9))
+
+
+def test_gather_rccl_gives_the_same_spot_centres_as_the_host_read(tmp_path):
+    """`--gpus N --gather rccl --output-for-index`: the spot centres of every round of batches (one per GPU) come back through
+    ffs_multi_gather_rows (counts by ncclAllGather, rows by ncclSend / ncclRecv to the first GPU) instead of being read from each
+    context's host arrays (`--gather host`, the default).  Two contexts on this one GPU (a one-rank communicator, self send / recv);
+    23 images in batches of 4: five full rounds and a last one that cannot fill up (served from the host arrays).  Same JSON lines."""
+    lines = {}
+    for how in ("host", "rccl"):
+        rc, out, err, ls = run_with_pipe(["synth:tiny:23", "--threads", "4", "--batch", "2", "--devices", "0,0", "--output-for-index", "--gather", how], tmp_path)
+        assert rc == 0 and not err, (out[-400:], err)
+        lines[how] = sorted((json.loads(l) for l in ls), key=lambda j: j["file-number"])
+        if how == "rccl":
+            m = re.search(r"Spot lists: (\d+) rounds of 2 batches gathered over RCCL", out)
+            if "exchange of rotation lists" in out and not m:
+                pytest.skip("no RCCL on this machine")
+            assert m and int(m.group(1)) >= 5, out[-600:]
+    assert [j["file-number"] for j in lines["host"]] == list(range(23))
+    assert lines["host"] == lines["rccl"]
+    assert sum(len(j["spot_centers"]) for j in lines["host"]) > 0
