@@ -86,7 +86,9 @@ struct Tuning {
                                 //    dense stream (measured round 4: no gain -- a CU full of first-pass waves has neither LDS nor registers left for the
                                 //    final pass's workgroups, so the kernels take turns either way: profiles/r04b_ext_streams_ab.txt)
     int band_taper = 0;         // streaming kernels: the last two bands per XCD are this many per cent as tall as the others (0 = uniform bands)
-    int rows_ahead = 2;         // rows of loads a wave of the 16-bit streaming kernel keeps in flight (2, 3 or 4)
+    int rows_ahead = 3;         // rows of loads a wave of the streaming kernels keeps in flight (16-bit pixels: 2, 3 or 4; 32-bit: 2 or 3).  Round 5: three.
+                                //    Alone the kernel is the same with two (round 4's measurement, and why it was two); in the pipeline, beside the
+                                //    band launches, three is 5 % faster (0.292-0.296 against 0.309-0.312 ms: profiles/r05zj_rows_ahead_ab.log)
     int device_lists = 2;       // the strong-pixel lists stay on the device after a batch: 1 = always, 0 = only when the host asked for them
                                 //    (want_strong_list), 2 = also while a 3D stack of the process is alive (ffs_stack3d_add_batch reads them)
     int strong_log = 1;         // 16-bit standard path: the streaming kernel appends its strong groups to per-wave logs and the one-launch sparse

@@ -153,6 +153,7 @@ static void launch_stream(ffs_stream* s, const ThresholdArgs& a, uint32_t n_fram
     const dim3 grid = stream_grid(a, n_frames);
     if (!st) st = s->st;
     if (s->ctx->pixel_bytes == 4 && a.dense_mask) hipExtLaunchKernelGGL((k_stream_u32<2, true>), grid, dim3(64), 0, st, start, stop, 0, a);
+    else if (s->ctx->pixel_bytes == 4 && s->ctx->tune.rows_ahead >= 3) hipExtLaunchKernelGGL((k_stream_u32<3, false>), grid, dim3(64), 0, st, start, stop, 0, a);
     else if (s->ctx->pixel_bytes == 4) hipExtLaunchKernelGGL((k_stream_u32<2, false>), grid, dim3(64), 0, st, start, stop, 0, a);
     else if (a.dense_mask) hipExtLaunchKernelGGL((k_stream_u16<2, false, true>), grid, dim3(64), 0, st, start, stop, 0, a);
     else if (s->ctx->tune.rows_ahead == 3) hipExtLaunchKernelGGL((k_stream_u16<3, false, false>), grid, dim3(64), 0, st, start, stop, 0, a);

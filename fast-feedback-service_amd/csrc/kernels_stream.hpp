@@ -962,6 +962,7 @@ template __global__ void k_stream_u16<2, false, true>(const ThresholdArgs);
 template __global__ void k_stream_u16<2, true, false>(const ThresholdArgs);
 template __global__ void k_stream_u16<2, true, true>(const ThresholdArgs);
 template __global__ void k_stream_u32<2, false>(const ThresholdArgs);
+template __global__ void k_stream_u32<3, false>(const ThresholdArgs);
 template __global__ void k_stream_u32<2, true>(const ThresholdArgs);
 
 }  // namespace ffsamd
