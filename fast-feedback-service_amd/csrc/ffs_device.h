@@ -118,6 +118,7 @@ struct ThresholdArgs {
     // flows into the slots this launch's last round of waves leaves.  nullptr: off.
     uint32_t* handoff;
     uint32_t handoff_seq;
+    int dbg_prio;              // tuning "stream_prio": the 16-bit streaming kernel raises its waves' issue priority (s_setprio 3)
     int dbg;                   // timing experiments (-DFFS_EXPERIMENTS builds only; results are wrong when set)
 };
 

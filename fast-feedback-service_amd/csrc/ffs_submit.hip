@@ -79,6 +79,7 @@ ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t pitch, 
     if (a.dbg & 16) a.dense_mask = 1;
     if (a.dbg & 8) a.dense_mask = 0;
 #endif
+    a.dbg_prio = c->tune.stream_prio;
     a.ginfo = c->d_ginfo;
     a.mmap = c->d_mmap;
     a.gpitch = (uint32_t)L.pitch_px * (uint32_t)c->pixel_bytes / 4;

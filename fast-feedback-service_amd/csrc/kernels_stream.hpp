@@ -170,6 +170,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     __shared__ uint16_t s_list[kQCap * 8];  // drain: (queue entry << 3 | pixel) of every candidate pixel
 
     const int lane = threadIdx.x;
+    if (a.dbg_prio) __builtin_amdgcn_s_setprio(3);   // (tuning "stream_prio": ahead of the band waves that share this SIMD in the issue arbitration)
     // XCD-aware block map: all strips of a band carry the same blockIdx % 8 (see k_candidates_u16)
     const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
     const int strip = qb % a.n_strips;

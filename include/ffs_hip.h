@@ -185,6 +185,7 @@ int ffs_ctx_set_params(ffs_ctx *ctx, const ffs_params *p);
  *                          through the one-workgroup launch inside ffs_wait
  *   "wait_ahead"       (1) a thread of the context turns each batch's records into the result arrays as soon as the GPU has finished
  *                          it, so ffs_wait finds them ready (0: ffs_wait does it, as in rounds 1-4)
+ *   "stream_prio"      (1) the 16-bit streaming kernel's waves run at issue priority 3 (s_setprio): ahead of the band waves on their SIMDs
  *   "dense_overlap"    (0) 1 = consecutive streaming kernels of the wave-log path on two HIP streams, handed over by a value the launch's
  *                          last workgroup writes as it starts (hipStreamWaitValue32) instead of the queue's barrier between two dispatches;
  *                          works in isolation, measured 8-10 % slower in the pipeline: off, kept as the A/B partner
