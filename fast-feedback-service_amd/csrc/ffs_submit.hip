@@ -443,7 +443,9 @@ int enqueue_batch(ffs_stream* s, const void* d_img, size_t pitch, size_t fstride
     // being dispatched, so a batch's results are two steps away -- hidden with four batches in flight (101 k against 95.6 k frames/s),
     // not with two or three (79 k / 89 k against 88 k / 95 k for the one-workgroup launch with its head start); alone in flight the
     // band waves win again (58 k against 53 k: nothing to wait behind).  profiles/r05n_bands_by_pipeline_depth.log
-    const bool depth_ok = c->tune.sparse_bands >= 2 || depth >= 4 || depth <= 1;
+    // A context with four or more streams is a pipeline that FILLS through depths two and three (the start of a run, of a timed
+    // region): there the band launches win at every depth (+1.2 % on the driver-style line, profiles/r05zo_tune_ab.log).
+    const bool depth_ok = c->tune.sparse_bands >= 2 || depth >= 4 || depth <= 1 || c->n_streams_made >= 4;
     const bool banded = use_log && c->tune.sparse_bands != 0 && depth_ok && !need_lists && !ta.dense_mask && !s->bands_once_off && s->band_backoff == 0
                         && band_stage_for(s, ta_launch, n);
     if (use_log && s->band_backoff > 0 && !s->bands_once_off) --s->band_backoff;

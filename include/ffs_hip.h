@@ -180,8 +180,8 @@ int ffs_ctx_set_params(ffs_ctx *ctx, const ffs_params *p);
  *                          2 = every frame of 16-bit pixels goes over runs (A/B partner: no faster on sparse frames)
  *   "sparse_bands"     (1) standard path with wave logs when nobody reads the pixel lists or the byte mask: the sparse stage in small
  *                          workgroups -- a wave per band of a frame, then a merge per frame (round 5) -- instead of the one workgroup per
- *                          frame, which holds a whole CU: 1 = with one or with four and more batches in flight (where it measures faster),
- *                          2 = always, 0 = never.  A band beyond its plan (768 strong pixels, 256 components) sends the batch back
+ *                          frame, which holds a whole CU: 1 = with one or with four and more batches in flight, and always on a context with
+ *                          four or more streams (where it measures faster), 2 = always, 0 = never.  A band beyond its plan (768 strong pixels, 256 components) sends the batch back
  *                          through the one-workgroup launch inside ffs_wait
  *   "wait_ahead"       (1) a thread of the context turns each batch's records into the result arrays as soon as the GPU has finished
  *                          it, so ffs_wait finds them ready (0: ffs_wait does it, as in rounds 1-4)

@@ -178,17 +178,28 @@ def test_bands_with_several_batches_in_flight(ffs, dense_overlap):
             else:
                 for fr, img, w in zip(res, frames, want):
                     assert_frame_matches_oracle(fr, img, ones, min_spot_size=2, precomputed=w)
-    # the default: by pipeline depth -- bands with one or four batches in flight, the one-workgroup launch with two or three
+    # the default: a context with four streams is a pipeline that fills -- bands at every depth
     ctx.set_tuning(sparse_bands=1)
     for s in streams:
         s.submit(frames, first_frame_id=0)
-    paths = []
     for s in streams:
+        res = s.wait()
+        assert "bands" in s.last_path()[0]
+        for fr, img, w in zip(res, frames, want):
+            assert_frame_matches_oracle(fr, img, ones, min_spot_size=2, precomputed=w)
+    # ... and one with two or three streams takes the one-workgroup launch (with its head start) when both / all are in flight
+    ctx2 = ffs.Context(W, H, np.uint16, max_batch=B)
+    ctx2.set_params(want_strong_list=0, min_spot_size=2)
+    two = [ctx2.stream() for _ in range(2)]
+    for s in two:
+        s.submit(frames, first_frame_id=0)
+    paths = []
+    for s in two:
         res = s.wait()
         paths.append("bands" in s.last_path()[0])
         for fr, img, w in zip(res, frames, want):
             assert_frame_matches_oracle(fr, img, ones, min_spot_size=2, precomputed=w)
-    assert paths == [True, False, False, True], paths
+    assert paths == [True, False], paths
 
 
 def test_bands_of_two_heights(ffs):
