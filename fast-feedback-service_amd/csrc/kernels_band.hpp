@@ -60,6 +60,7 @@ template <typename PixelT>
 __global__ __launch_bounds__(64) void k_band_cc(const BandArgs B) {
     const ThresholdArgs& T = B.A.t;
     const CclArgs& a = B.A.c;
+    if (T.dbg_prio & 2) __builtin_amdgcn_s_setprio(3);   // (tuning "stream_prio" bit 2: measured, not the default)
     __shared__ uint32_t s_lst[16];
     __shared__ uint32_t s_row[kBandMaxRows + 2];
     __shared__ __align__(16) uint32_t s_cw[kBandCw];
@@ -389,6 +390,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_frame_merge(const BandArgs B)
     const CclArgs& a = A.c;
     const SegArgs& sa = A.s;
     const ThresholdArgs& T = A.t;
+    if (T.dbg_prio & 2) __builtin_amdgcn_s_setprio(3);
     __shared__ uint32_t s_off[kMergeMaxBands + 1];
     __shared__ uint32_t s_par[kMergeCap];
     __shared__ uint16_t s_l2id[kMergeCap];          // label -> band component (the root with that label)

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     __shared__ uint16_t s_list[kQCap * 8];  // drain: (queue entry << 3 | pixel) of every candidate pixel
 
     const int lane = threadIdx.x;
-    if (a.dbg_prio) __builtin_amdgcn_s_setprio(3);   // (tuning "stream_prio": ahead of the band waves that share this SIMD in the issue arbitration)
+    if (a.dbg_prio & 1) __builtin_amdgcn_s_setprio(3);   // (tuning "stream_prio": ahead of the band waves that share this SIMD in the issue arbitration)
     // XCD-aware block map: all strips of a band carry the same blockIdx % 8 (see k_candidates_u16)
     const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
     const int strip = qb % a.n_strips;
@@ -314,7 +314,18 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     };
 
     int qn = 0;  // queued lane groups (wave-uniform)
-    [[maybe_unused]] uint32_t nlog = 0;   // entries of this wave's log (wave-uniform)
+    [[maybe_unused]] uint32_t nlog = 0;   // entries of this wave's log already in memory (wave-uniform)
+    [[maybe_unused]] uint32_t nbuf = 0;   // ... and still in lbuf
+    [[maybe_unused]] uint32_t lbuf[6] = {0, 0, 0, 0, 0, 0};   // lane e: entry nlog + e (two words) and its group's eight pixels (four)
+    [[maybe_unused]] auto flush_log = [&]() {
+        const uint32_t at = nlog + (uint32_t)lane;
+        if ((uint32_t)lane < nbuf && at < (uint32_t)kWlogCap && !FFS_DBG(a, 512)) {   // (bit 512: the log stays unwritten and empty -- what its stores cost)
+            a.wlog[(uint64_t)wave_id * kWlogCap + at] = make_uint2(lbuf[0], lbuf[1]);
+            a.wpix[(uint64_t)wave_id * kWlogCap + at] = make_uint4(lbuf[2], lbuf[3], lbuf[4], lbuf[5]);
+        }
+        nlog += nbuf;
+        nbuf = 0;
+    };
     // 64 queued groups at a time.  Phase 1, one group per lane: the conservative float32 signal test on its
     // eight pixels (a proven superset, see signal_test8).  Phase 2: the pixels still standing (a few dozen)
     // are dealt one per lane -- each lane's candidates numbered by ballot + mbcnt, bit plane by bit plane --
@@ -449,17 +460,31 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if constexpr (!EXT) if (a.wlog) {   // (wave-uniform) one dense 8-byte store per group instead of a plane byte and two atomics
+        if constexpr (!EXT) if (a.wlog) {   // (wave-uniform) one 24-byte entry per group instead of a plane byte and two atomics
+            // The entries wait in REGISTERS (entry e of the current run of 64 in lane e: lbuf) and leave the wave 64 at a time
+            // and when it ends, as whole lines.  Stored drain by drain (5 entries, two store instructions) they cost the kernel
+            // 12 us of 292 (tools/log_store_probe.py: the same kernel with the log left unwritten) -- 120 k partial-line writes
+            // whose completion the row loads behind them are counted after (vmcnt is one in-order counter on gfx9).
             const uint32_t cbm = have ? s_q[14][lane] : 0u;   // strong | undecided << 8
             const unsigned long long wm = __builtin_amdgcn_ballot_w64(cbm != 0u);
-            if (cbm != 0u) {
-                const uint32_t at = nlog + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u));
-                if (at < (uint32_t)kWlogCap) {
-                    a.wlog[(uint64_t)wave_id * kWlogCap + at] = make_uint2((row << 16) | ge, (fe << 16) | cbm);
-                    a.wpix[(uint64_t)wave_id * kWlogCap + at] = make_uint4(s_q[8][lane], s_q[9][lane], s_q[10][lane], s_q[11][lane]);   // the group's pixels
+            if (wm) {
+                const uint32_t cnt = (uint32_t)__popcll(wm);
+                if (nbuf + cnt > 64u) flush_log();
+                if (cbm != 0u) {   // the group's lane leaves its entry where the lane that will hold it finds it
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u));
+                    s_list[rank] = (uint16_t)lane;
+                    s_q[12][lane] = (row << 16) | ge;
+                    s_q[13][lane] = (fe << 16) | cbm;
                 }
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t k = (uint32_t)lane - nbuf;
+                if (k < cnt) {
+                    const uint32_t src = s_list[k];
+                    lbuf[0] = s_q[12][src]; lbuf[1] = s_q[13][src];
+                    lbuf[2] = s_q[8][src]; lbuf[3] = s_q[9][src]; lbuf[4] = s_q[10][src]; lbuf[5] = s_q[11][src];   // the group's pixels
+                }
+                nbuf += cnt;   // (queue entries are in (row, lane) order, so the log is sorted by (row, frame, group))
             }
-            nlog += (uint32_t)__popcll(wm);   // (queue entries are in (row, lane) order, so the log is sorted by (row, frame, group))
             qn = 0;
             return;
         }
@@ -628,7 +653,10 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     }
 rows_done:
     if (qn > 0) drain();
-    if constexpr (!EXT) if (a.wlog && lane == 0) a.wlog_n[wave_id] = nlog;
+    if constexpr (!EXT) if (a.wlog) {
+        flush_log();
+        if (lane == 0) a.wlog_n[wave_id] = FFS_DBG(a, 512) ? 0u : nlog;
+    }
 }
 // Pixels whose window holds sum p >= 65536 (k_stream_u16 cannot vouch for its 32-bit sum of p^2): exact
 // 64-bit sums gathered from memory, then the same predicate.  A handful per frame at most.

@@ -451,6 +451,40 @@ def test_wave_logs_and_bit_plane_agree(ffs, strong_log, want_list):
             assert_frame_matches_oracle(fr, img, mask)
 
 
+@pytest.mark.parametrize("dtype", [np.uint16, np.uint32])
+@pytest.mark.parametrize("want_list", [1, 0])
+def test_wave_log_of_several_register_runs(ffs, dtype, want_list):
+    """A streaming wave keeps its log entries in registers, 64 at a time (kernels_stream.hpp `lbuf`), and writes a run when the next
+    drain would not fit and when it ends.  Frames whose waves hold 100-200 entries each -- more than one run, fewer than the 256 a
+    log takes -- must come out as the oracle's without a second pass: the path bits say the logs served, `reruns` says once."""
+    rng = np.random.default_rng(12)
+    W, H, B = 1000, 300, 3
+    frames = []
+    for i in range(B):
+        img = rng.poisson(2.0, (H, W)).astype(dtype)
+        for _ in range(520):
+            y, x = rng.integers(0, H - 3), rng.integers(0, W - 3)
+            img[y:y + rng.integers(1, 3), x:x + rng.integers(1, 4)] = rng.integers(200, 3000)
+        for _ in range(6):
+            y, x = rng.integers(0, H - 8), rng.integers(0, W - 8)
+            img[y:y + 6, x:x + 6] = rng.integers(20000, 65535)
+        frames.append(img)
+    frames = np.stack(frames)
+    mask = np.ones((H, W), np.uint8)
+    mask[rng.random((H, W)) < 0.001] = 0
+    ctx = ffs.Context(W, H, dtype, max_batch=B)
+    ctx.set_mask(mask)
+    ctx.set_params(want_strong_list=want_list, min_spot_size=1)
+    st = ctx.stream()
+    for rep in range(2):
+        res = st.process(frames, first_frame_id=rep)
+        path, reruns = st.last_path()
+        assert "wave_logs" in path and reruns == 0, (path, reruns)
+        for fr, img in zip(res, frames):
+            assert_frame_matches_oracle(fr, img, mask, min_spot_size=1)
+    assert res[0].num_strong_pixels > 1500
+
+
 @pytest.mark.parametrize("want_list", [1, 0])
 def test_sparse_and_dense_batches_alternate_on_one_stream(ffs, want_list):
     """Which sparse stage a batch gets follows what the stream's previous batch held: wave logs for sparse data, the plane with
