@@ -459,6 +459,7 @@ extern "C" int ffs_ctx_set_tuning(ffs_ctx* c, const char* key, long long value) 
     else if (k == "bright_cap") { if ((ok = in(0, kBrightCap))) t.bright_cap = (int)value; }
     else if (k == "frames_per_group") { if ((ok = in(1, 1 << 30))) t.frames_per_group = (int)value; }
     else if (k == "target_waves") { if ((ok = in(1, 1 << 24))) t.target_waves = value; }
+    else if (k == "stream_bands") { if ((ok = in(0, 4096))) t.stream_bands = (int)value; }
     else if (k == "dense_mask") { if ((ok = in(0, 1))) t.dense_mask = (int)value; }
     else if (k == "occupancy_bitmap") { if ((ok = in(0, 1))) t.occupancy_bitmap = (int)value; }
     else if (k == "direct_records") { if ((ok = in(0, 1) && c->n_streams_made == 0)) t.direct_records = (int)value; }

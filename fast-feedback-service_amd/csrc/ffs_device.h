@@ -122,6 +122,24 @@ struct ThresholdArgs {
     int dbg;                   // timing experiments (-DFFS_EXPERIMENTS builds only; results are wrong when set)
 };
 
+// The streaming launch's units.  A unit = one wave = one band of one strip; units are numbered band after band (u = band * n_strips +
+// strip) and dealt to the eight XCDs in eight contiguous chunks (workgroup b runs on XCD b % 8): the strips of a band -- neighbours that
+// share halo columns and, frame after frame, the same rows of the mask tables -- share an L2, and ANY number of bands is balanced over
+// the XCDs.  (Rounds 1-5 dealt the bands round-robin, band = xcd + 8 k, which wanted a multiple of eight bands; the chunks measure
+// 0.5-1 % faster on the same box, profiles/r06e_map_variants.log.)
+__host__ __device__ inline uint32_t stream_units(const ThresholdArgs& a) { return (uint32_t)a.n_bands * (uint32_t)a.n_strips; }
+__host__ __device__ inline uint32_t stream_chunk(const ThresholdArgs& a) { return (stream_units(a) + 7u) / 8u; }   // units per XCD; grid.x = 8 chunks
+__device__ __forceinline__ bool stream_unit(const ThresholdArgs& a, uint32_t bid, int& strip, int& band) {
+    const uint32_t u = (bid & 7u) * stream_chunk(a) + (bid >> 3);
+    band = (int)(u / (uint32_t)a.n_strips);
+    strip = (int)(u - (uint32_t)band * (uint32_t)a.n_strips);
+    return u < stream_units(a);
+}
+// where the log of (super row y, band, strip) lies in wlog / wlog_n / wpix: the strips of a band side by side
+__host__ __device__ inline uint32_t log_slot(const ThresholdArgs& a, uint32_t y, uint32_t band, uint32_t strip) {
+    return (y * (uint32_t)a.n_bands + band) * (uint32_t)a.n_strips + strip;
+}
+
 // ---- strong-pixel lists and connected components -------------------------------------------------
 // 2D only (round 2): the accumulator of a component sits at the list index of its ROOT (its smallest
 // member, always the first pixel of a horizontal run), so no pass has to number the components before

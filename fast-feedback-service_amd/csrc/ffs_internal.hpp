@@ -69,6 +69,7 @@ struct Tuning {
     int bright_cap = 1 << 20;   // entries of the bright-window list actually used
     int frames_per_group = 1 << 30;   // frames side by side in one super row of the streaming kernels (cap)
     long long target_waves = 16384;   // waves a streaming launch aims for
+    int stream_bands = 0;             // > 0: bands of a streaming launch (0: from target_waves, a multiple of eight of at least 72 rows)
     int dense_mask = 0;         // 1: always produce the dense byte mask
     int occupancy_bitmap = 1;   // k_frame_chain reads only the plane segments the occupancy bitmap names
     int direct_records = 1;     // records and counters are written straight into pinned host memory

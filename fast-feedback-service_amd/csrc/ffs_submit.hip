@@ -101,6 +101,8 @@ ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t pitch, 
         const long long per_band = std::max<long long>(1, (long long)a.n_strips * n_groups);
         long long nb = std::max<long long>(1, std::min<long long>(c->tune.target_waves / per_band, L.H / 72));
         if (nb >= 8) nb = nb / 8 * 8;
+        // tuning "stream_bands" > 0: that many bands (any number: the unit map balances the XCDs)
+        if (c->tune.stream_bands > 0) nb = std::max<long long>(1, std::min<long long>(c->tune.stream_bands, L.H / 8));
         a.band_rows = (int)std::min<long long>(1024, (L.H + nb - 1) / nb);
         a.n_bands = (L.H + a.band_rows - 1) / a.band_rows;
         a.band_rows2 = a.band_rows;
@@ -143,9 +145,13 @@ ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t pitch, 
 
 // ---- the threshold stage's launches -----------------------------------------------------------------------------
 static dim3 stream_grid(const ThresholdArgs& a, uint32_t n_frames) {
-    const int bands8 = (a.n_bands + 7) / 8 * 8;  // the XCD-aware block map wants a multiple of 8 bands
     const unsigned n_groups = (n_frames + (unsigned)a.group_frames - 1) / (unsigned)a.group_frames;
-    return dim3((unsigned)(a.n_strips * bands8), n_groups);
+    return dim3(8u * stream_chunk(a), n_groups);   // (the units in eight equal chunks, one per XCD: ffs_device.h, stream_unit)
+}
+// logs of a launch: one per (super row, band, strip) -- log_slot()
+static size_t stream_log_slots(const ThresholdArgs& a, uint32_t n_frames) {
+    const unsigned n_groups = (n_frames + (unsigned)a.group_frames - 1) / (unsigned)a.group_frames;
+    return (size_t)n_groups * (size_t)a.n_bands * (size_t)a.n_strips;
 }
 
 // The whole standard threshold in one kernel: final strong plane + per-tile counts (atomics into zeroed counters).
@@ -249,8 +255,7 @@ bool wave_logs_for(ffs_stream* s, ThresholdArgs& a, uint32_t n_frames) {
           && s->batch_params.algorithm != FFS_ALGO_DISPERSION_EXTENDED && c->n_tiles <= kChainMaxTiles && L.H <= kChainMaxRows
           && (uint32_t)a.gpf / (uint32_t)kSOwned + 2u <= 16u && a.band_rows <= 1024 && L.W <= 65535))
         return false;
-    const dim3 g = stream_grid(a, n_frames);
-    size_t waves = (size_t)g.x * g.y;
+    size_t waves = stream_log_slots(a, n_frames);
     if (waves > s->wlog_waves) {
         // Sized ONCE, for the largest launch any batch of this stream can make (1 .. max_batch frames), so that a batch of another
         // size never re-allocates: hipFree synchronises the whole device, i.e. every other worker's batches in flight.  (A stream is
@@ -258,8 +263,7 @@ bool wave_logs_for(ffs_stream* s, ThresholdArgs& a, uint32_t n_frames) {
         // its own has to be waited for if it does happen: a tuning change between batches.)
         for (uint32_t nf = 1; nf <= s->max_batch; ++nf) {
             const ThresholdArgs t = make_threshold_args(s, a.image, a.pitch, a.frame_stride, nf);
-            const dim3 gg = stream_grid(t, nf);
-            waves = std::max(waves, (size_t)gg.x * gg.y);
+            waves = std::max(waves, stream_log_slots(t, nf));
         }
         if (s->d_wlog) {
             (void)hipFree(s->d_wlog);

@@ -79,8 +79,7 @@ __global__ __launch_bounds__(64) void k_band_cc(const BandArgs B) {
     const uint32_t gsep = (uint32_t)T.gpf + 1u, G0 = l_fe * gsep, G1 = G0 + (uint32_t)T.gpf - 1u;
     const uint32_t l_s0 = G0 / (uint32_t)kSOwned;
     const uint32_t l_ns = min(G1 / (uint32_t)kSOwned - l_s0 + 1u, 16u);
-    const uint32_t l_gridx = (uint32_t)T.n_strips * (uint32_t)((T.n_bands + 7) / 8 * 8);
-    const uint32_t wave0 = l_y * l_gridx + (((uint32_t)(band >> 3) * (uint32_t)T.n_strips + l_s0) * 8u + (uint32_t)(band & 7));   // strip k: + 8 k
+    const uint32_t wave0 = log_slot(T, l_y, (uint32_t)band, l_s0);   // strip k: + k
     const int sb1 = min(band_first_row(band + 1, T.band_rows, T.band_rows2, T.band_split), a.H);   // end of the streaming band
     const int yb0 = min(band_first_row(band, T.band_rows, T.band_rows2, T.band_split) + sub * B.sub_rows, sb1);
     const int yb1 = min(yb0 + B.sub_rows, sb1);
@@ -97,7 +96,7 @@ __global__ __launch_bounds__(64) void k_band_cc(const BandArgs B) {
     // ---- the logs of the band's strips, laid end to end ------------------------------------------------------------------------
     uint32_t cnt = 0;
     if ((uint32_t)lane < l_ns && rows != 0) {
-        cnt = T.wlog_n[wave0 + 8u * (uint32_t)lane];
+        cnt = T.wlog_n[wave0 + (uint32_t)lane];
         if (cnt > (uint32_t)kWlogCap) { atomicOr(&s_flag, 32u); cnt = (uint32_t)kWlogCap; }
     }
     const uint32_t incl0 = wave_inclusive_scan(cnt);
@@ -117,7 +116,7 @@ __global__ __launch_bounds__(64) void k_band_cc(const BandArgs B) {
                 if (f < nb) {
                     uint32_t k = 0;
                     for (uint32_t j = 1; j < l_ns; ++j) k += f >= s_lst[j] ? 1u : 0u;
-                    ent[c] = T.wlog[(uint64_t)(wave0 + 8u * k) * kWlogCap + (f - s_lst[k])];
+                    ent[c] = T.wlog[(uint64_t)(wave0 + k) * kWlogCap + (f - s_lst[k])];
                     ent[c].y = ((ent[c].y >> 16) != l_fe || (int)(ent[c].x >> 16) < yb0 || (int)(ent[c].x >> 16) >= yb1) ? 0xFFFF0000u : (k << 16) | (ent[c].y & 0xFFFFu);
                 }
             }
@@ -136,7 +135,7 @@ __global__ __launch_bounds__(64) void k_band_cc(const BandArgs B) {
             if (c < nchunks) {
                 const uint32_t f = c * 64u + (uint32_t)lane;
                 const uint2 v = s_ent[f];
-                if (f < nb && mine_of(v) && (v.y & 0xFFFFu)) px = T.wpix[(uint64_t)(wave0 + 8u * (v.y >> 16)) * kWlogCap + (f - s_lst[v.y >> 16])];
+                if (f < nb && mine_of(v) && (v.y & 0xFFFFu)) px = T.wpix[(uint64_t)(wave0 + (v.y >> 16)) * kWlogCap + (f - s_lst[v.y >> 16])];
             }
             return px;
         };

@@ -268,13 +268,13 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
     // it is one CU's share of the memory system: the frame's 2.3 MB plane at ~20 GB/s.
     // ---- L1 (LOG): the frame's entries in the wave logs -- undecided pixels decided, per-row counts ------------------------
     // Frame `frame` = frame fe of super row y; its groups are G0 .. G0 + gpf - 1 of the super row, held by strips ls0 .. ls1
-    // (kSOwned groups each); band b of strip k is wave ((b >> 3) * n_strips + k) * 8 + (b & 7) of super row y.  A log is
+    // (kSOwned groups each); the log of band b of strip k of super row y lies at log_slot(y, b, k) (ffs_device.h).  A log is
     // sorted by (row, frame, group), the strips of a band partition the groups in order: the raster order of a row is strip
     // after strip.  Chain wave w takes bands w, w + 16, ...
     [[maybe_unused]] const ThresholdArgs& T = A.t;
-    [[maybe_unused]] uint32_t l_y = 0, l_fe = 0, l_s0 = 0, l_ns = 0, l_gridx = 0;
+    [[maybe_unused]] uint32_t l_y = 0, l_fe = 0, l_s0 = 0, l_ns = 0;
     [[maybe_unused]] auto log_wave = [&](int band, uint32_t k) -> uint32_t {
-        return l_y * l_gridx + (((uint32_t)(band >> 3) * (uint32_t)T.n_strips + (l_s0 + k)) * 8u + (uint32_t)(band & 7));
+        return log_slot(T, l_y, (uint32_t)band, l_s0 + k);
     };
     // The logs of one band, read side by side: lane k fetches strip k's count (one round trip for all strips), a scan lays
     // the strips' entries end to end, and lane i of a chunk takes entry i of that row of entries -- whichever log it is in.
@@ -321,7 +321,6 @@ __global__ __launch_bounds__(kChainThreads) void k_frame_chain(const ChainArgs A
         const uint32_t gsep = (uint32_t)T.gpf + 1u, G0 = l_fe * gsep, G1 = G0 + (uint32_t)T.gpf - 1u;
         l_s0 = G0 / (uint32_t)kSOwned;
         l_ns = G1 / (uint32_t)kSOwned - l_s0 + 1u;
-        l_gridx = (uint32_t)T.n_strips * (uint32_t)((T.n_bands + 7) / 8 * 8);
         // Undecided pixels (windows with sum p >= 65536: the cores of bright spots) are listed here and decided below, one per
         // thread -- decided where they are met, a lane with eight of them kept its whole wave waiting (118 us for this phase).
         uint32_t* s_maybe = reinterpret_cast<uint32_t*>(s_dyn + kChainStageOff);   // band << 16 | strip << 12 | entry << 3 | bit

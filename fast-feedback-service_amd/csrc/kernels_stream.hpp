@@ -171,18 +171,14 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
 
     const int lane = threadIdx.x;
     if (a.dbg_prio & 1) __builtin_amdgcn_s_setprio(3);   // (tuning "stream_prio": ahead of the band waves that share this SIMD in the issue arbitration)
-    // XCD-aware block map: all strips of a band carry the same blockIdx % 8 (see k_candidates_u16)
-    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
-    const int strip = qb % a.n_strips;
-    const int band = xcd + 8 * (qb / a.n_strips);
-    [[maybe_unused]] const uint32_t wave_id = blockIdx.y * gridDim.x + blockIdx.x;
+    // XCD-aware unit map (ffs_device.h, stream_unit): a unit = one band of one strip, the strips of a band on one XCD
+    int strip, band;
+    const bool real = stream_unit(a, blockIdx.x, strip, band);
     if constexpr (!EXT)   // (the launch's last workgroup has started: every other one has been handed out -- see ThresholdArgs::handoff)
         if (a.handoff && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && lane == 0)
             __hip_atomic_store(a.handoff, a.handoff_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (band >= a.n_bands) {
-        if constexpr (!EXT) if (a.wlog && lane == 0) a.wlog_n[wave_id] = 0;   // (every wave of the grid has a count)
-        return;
-    }
+    if (!real) return;   // (the grid is eight equal chunks: up to seven workgroups beyond the last unit)
+    [[maybe_unused]] const uint32_t slot = log_slot(a, blockIdx.y, (uint32_t)band, (uint32_t)strip);   // where this wave's log lies
     const int f0 = blockIdx.y * a.group_frames;                   // first frame of this super row
     const int nf = min(a.group_frames, a.n_frames - f0);
     const int yb0 = band_first_row(band, a.band_rows, a.band_rows2, a.band_split);
@@ -215,7 +211,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
         off_byte_st = fz < (uint32_t)nf ? (uint32_t)((uint64_t)fz * a.bytes_frame_stride) + cz * 128u + ((uint32_t)lane & 15u) * 8u : kOob;
     }
 
-    const int total = (yb1 - yb0) + 6;  // incoming rows yb0-3 .. yb1+2
+    const int total = (yb1 - yb0) + (FFS_DBG(a, 1024) ? 0 : 6);  // incoming rows yb0-3 .. yb1+2   (bit 1024: six rows fewer a wave -- a launch without warm-up rows; results are wrong)
     const float kS = a.kS;
 
     // Ring of NS = 7 + KAHEAD row slots, row i in slot i % NS: the seven rows of the window AND the rows in flight.  A row's
@@ -320,8 +316,8 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     [[maybe_unused]] auto flush_log = [&]() {
         const uint32_t at = nlog + (uint32_t)lane;
         if ((uint32_t)lane < nbuf && at < (uint32_t)kWlogCap && !FFS_DBG(a, 512)) {   // (bit 512: the log stays unwritten and empty -- what its stores cost)
-            a.wlog[(uint64_t)wave_id * kWlogCap + at] = make_uint2(lbuf[0], lbuf[1]);
-            a.wpix[(uint64_t)wave_id * kWlogCap + at] = make_uint4(lbuf[2], lbuf[3], lbuf[4], lbuf[5]);
+            a.wlog[(uint64_t)slot * kWlogCap + at] = make_uint2(lbuf[0], lbuf[1]);
+            a.wpix[(uint64_t)slot * kWlogCap + at] = make_uint4(lbuf[2], lbuf[3], lbuf[4], lbuf[5]);
         }
         nlog += nbuf;
         nbuf = 0;
@@ -655,7 +651,7 @@ rows_done:
     if (qn > 0) drain();
     if constexpr (!EXT) if (a.wlog) {
         flush_log();
-        if (lane == 0) a.wlog_n[wave_id] = FFS_DBG(a, 512) ? 0u : nlog;
+        if (lane == 0) a.wlog_n[slot] = FFS_DBG(a, 512) ? 0u : nlog;
     }
 }
 // Pixels whose window holds sum p >= 65536 (k_stream_u16 cannot vouch for its 32-bit sum of p^2): exact
@@ -699,16 +695,12 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
     __shared__ uint16_t s_list[kQCap * 4];
 
     const int lane = threadIdx.x;
-    const int xcd = blockIdx.x & 7, qb = blockIdx.x >> 3;
-    const int strip = qb % a.n_strips;
-    const int band = xcd + 8 * (qb / a.n_strips);
-    [[maybe_unused]] const uint32_t wave_id = blockIdx.y * gridDim.x + blockIdx.x;
-    if (a.handoff && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && lane == 0)   // (see k_stream_u16)
+    int strip, band;   // (the unit map: see k_stream_u16)
+    const bool real = stream_unit(a, blockIdx.x, strip, band);
+    if (a.handoff && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && lane == 0)
         __hip_atomic_store(a.handoff, a.handoff_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (band >= a.n_bands) {
-        if (a.wlog && lane == 0) a.wlog_n[wave_id] = 0;   // (every wave of the grid has a count)
-        return;
-    }
+    if (!real) return;
+    const uint32_t slot = log_slot(a, blockIdx.y, (uint32_t)band, (uint32_t)strip);
     const int f0 = blockIdx.y * a.group_frames;
     const int nf = min(a.group_frames, a.n_frames - f0);
     const int yb0 = band_first_row(band, a.band_rows, a.band_rows2, a.band_split);
@@ -871,8 +863,8 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
             if (cbm != 0u) {
                 const uint32_t at = nlog + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u));
                 if (at < (uint32_t)kWlogCap) {
-                    a.wlog[(uint64_t)wave_id * kWlogCap + at] = make_uint2((row << 16) | ge, (fe << 16) | cbm);
-                    a.wpix[(uint64_t)wave_id * kWlogCap + at] = make_uint4(s_q[4][lane], s_q[5][lane], s_q[6][lane], s_q[7][lane]);   // the group's four pixels
+                    a.wlog[(uint64_t)slot * kWlogCap + at] = make_uint2((row << 16) | ge, (fe << 16) | cbm);
+                    a.wpix[(uint64_t)slot * kWlogCap + at] = make_uint4(s_q[4][lane], s_q[5][lane], s_q[6][lane], s_q[7][lane]);   // the group's four pixels
                 }
             }
             nlog += (uint32_t)__popcll(wm);
@@ -977,7 +969,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
     }
 rows_done:
     if (qn > 0) drain();
-    if (a.wlog && lane == 0) a.wlog_n[wave_id] = nlog;
+    if (a.wlog && lane == 0) a.wlog_n[slot] = nlog;
 }
 
 template __global__ void k_bright_fix<uint16_t>(const ThresholdArgs);
