@@ -462,22 +462,23 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
             // 12 us of 292 (tools/log_store_probe.py: the same kernel with the log left unwritten) -- 120 k partial-line writes
             // whose completion the row loads behind them are counted after (vmcnt is one in-order counter on gfx9).
             const uint32_t cbm = have ? s_q[14][lane] : 0u;   // strong | undecided << 8
+            const uint32_t pxw[4] = {s_q[8][lane], s_q[9][lane], s_q[10][lane], s_q[11][lane]};   // the group's pixels (asked for with cbm: one round trip)
             const unsigned long long wm = __builtin_amdgcn_ballot_w64(cbm != 0u);
             if (wm) {
                 const uint32_t cnt = (uint32_t)__popcll(wm);
                 if (nbuf + cnt > 64u) flush_log();
-                if (cbm != 0u) {   // the group's lane leaves its entry where the lane that will hold it finds it
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u));
-                    s_list[rank] = (uint16_t)lane;
-                    s_q[12][lane] = (row << 16) | ge;
-                    s_q[13][lane] = (fe << 16) | cbm;
-                }
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t k = (uint32_t)lane - nbuf;
-                if (k < cnt) {
-                    const uint32_t src = s_list[k];
-                    lbuf[0] = s_q[12][src]; lbuf[1] = s_q[13][src];
-                    lbuf[2] = s_q[8][src]; lbuf[3] = s_q[9][src]; lbuf[4] = s_q[10][src]; lbuf[5] = s_q[11][src];   // the group's pixels
+                // every lane with an entry sends its six words to the lane that will hold them (ds_permute_b32: the crossbar, no LDS
+                // memory and no second round trip); the lanes without one send to a lane outside the run's new part, which ignores it
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u));
+                const uint32_t dump = nbuf + cnt < 64u ? nbuf + cnt : 0u;
+                const int to = (int)((cbm != 0u ? nbuf + rank : dump) << 2);
+                const uint32_t e0 = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)((row << 16) | ge));
+                const uint32_t e1 = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)((fe << 16) | cbm));
+                const uint32_t p0 = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)pxw[0]), p1 = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)pxw[1]);
+                const uint32_t p2 = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)pxw[2]), p3 = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)pxw[3]);
+                if ((uint32_t)lane - nbuf < cnt) {
+                    lbuf[0] = e0; lbuf[1] = e1;
+                    lbuf[2] = p0; lbuf[3] = p1; lbuf[4] = p2; lbuf[5] = p3;   // the group's pixels
                 }
                 nbuf += cnt;   // (queue entries are in (row, lane) order, so the log is sorted by (row, frame, group))
             }
