@@ -86,28 +86,7 @@ static_assert(kChainStageOff % 8 == 0 && kChainDynBytes <= 160 * 1024 - 256, "LD
 static_assert(2 * kChainRunCap * 4 <= kChainForestBytes + (kChainDynBytes - kChainStageOff), "LDS plan (runs)");
 static_assert(kChainMaxRows < 8192, "run descriptor");
 
-// Inclusive prefix sum over the 64 lanes in six DPP adds (row_shr 1/2/4/8 inside the rows of 16, then row_bcast:15 and
-// row_bcast:31 carry the row totals on) instead of six ds_bpermute round trips.
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1 and 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2 and 3
-    return v;
-}
-
-// Inclusive running maximum over the 64 lanes, the same six DPP steps.
-__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
-    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
-    return v;
-}
+// (wave_inclusive_scan / wave_inclusive_max: kernels_threshold.hpp)
 
 struct ChainArgs {
     CclArgs c;

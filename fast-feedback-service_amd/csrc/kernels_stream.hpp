@@ -400,16 +400,18 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
             }
             if (FFS_DBG(a, 4)) todo = 0;
         }
-        int T = 0;  // candidates of the whole wave (wave-uniform)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const bool bit = (todo >> j) & 1u;
-            const unsigned long long bm = __builtin_amdgcn_ballot_w64(bit);
-            if (bit) {
-                const uint32_t pos = (uint32_t)T + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                s_list[pos] = (uint16_t)(((uint32_t)lane << 3) | (uint32_t)j);
+        // the candidates listed densely (any order will do): a scan of the lanes' counts, then every lane writes its own -- as many
+        // rounds as the busiest lane has candidates (one or two) instead of eight ballots
+        const uint32_t todo_n = (uint32_t)__popc(todo);
+        const uint32_t todo_incl = wave_inclusive_scan(todo_n);
+        const int T = __builtin_amdgcn_readlane((int)todo_incl, 63);  // candidates of the whole wave (wave-uniform)
+        {
+            uint32_t pos = todo_incl - todo_n, w = todo;
+            while (w) {
+                const uint32_t j = (uint32_t)__ffs((int)w) - 1u;
+                w &= w - 1u;
+                s_list[pos++] = (uint16_t)(((uint32_t)lane << 3) | j);
             }
-            T += __popcll(bm);
         }
         __builtin_amdgcn_wave_barrier();
         for (int base = 0; base < T; base += 64) {  // wave-uniform; one round unless the groups are full of bright pixels
