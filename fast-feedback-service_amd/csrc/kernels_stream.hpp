@@ -47,7 +47,7 @@
 namespace ffsamd {
 
 constexpr int kSQWords = 32;         // queue entry: 0-7 window sums, 8-11 centre pixels (two per word), 12-13 window counts,
-                                     // 14 result bits, 15 ginfo, 16-29 column sums of p^2, 30 tag
+                                     // 14 result bits, 15 ginfo, 16-29 column sums of p^2, 30 tag (row << 6 | lane), 31 frame in super row << 16 | group
 
 // The oracle's predicate on exact integer window sums, standalone.cc:165-170 operation for operation
 // (the same lines as exact_strong, which gets its sums by gathering the window from memory).
@@ -191,6 +191,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
     const int g = G - fl * gsep;
     const bool active = G >= 0 && fl < nf && g < a.gpf;
     const bool owned = active && lane >= 1 && lane <= kSOwned;
+    const uint32_t my_fg = ((uint32_t)fl << 16) | (uint32_t)g;   // travels with every group this lane queues
 
     const rsrc_t r_img = make_rsrc((const uint8_t*)a.image + (uint64_t)f0 * a.frame_stride,
                                    (uint32_t)((uint64_t)(nf - 1) * a.frame_stride + (uint64_t)a.H * a.pitch));
@@ -332,11 +333,10 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
         const bool have = lane < qn && !FFS_DBG(a, 2) && !FFS_DBG(a, 32);   // (bit 32 leaves the queue unwritten: nothing to read back)
         uint32_t todo = 0, row = 0, fe = 0, ge = 0;
         if (have) {
-            const uint32_t tag = s_q[30][lane], ln = tag & 63u;
-            row = tag >> 6;
-            const int Ge = strip * kSOwned + (int)ln - 1;
-            fe = (uint32_t)Ge / (uint32_t)gsep;
-            ge = (uint32_t)Ge - fe * (uint32_t)gsep;
+            row = s_q[30][lane] >> 6;
+            const uint32_t fg = s_q[31][lane];   // (the pushing lane's own frame and group: no division here)
+            fe = fg >> 16;
+            ge = fg & 0xFFFFu;
             // window counts of the eight pixels: one value for the whole group almost everywhere (then ginfo has it);
             // only groups next to masked pixels fetch their eight counts -- a dependent global round trip at the head
             // of the drain that most waves now never pay
@@ -448,9 +448,8 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                     atomicOr(&s_q[14][e], 0x100u << j);
                 } else {
                     // sum p^2 may not fit 32 bits: k_bright_fix gathers the window and decides (rare)
-                    const uint32_t tg = s_q[30][e];
-                    const int Gc = strip * kSOwned + (int)(tg & 63u) - 1;
-                    const uint32_t fc = (uint32_t)Gc / (uint32_t)gsep, gc = (uint32_t)Gc - fc * (uint32_t)gsep;
+                    const uint32_t tg = s_q[30][e], fgc = s_q[31][e];
+                    const uint32_t fc = fgc >> 16, gc = fgc & 0xFFFFu;
                     const uint32_t at = atomicAdd(a.bright_n, 1u);
                     if (at < a.bright_cap)
                         a.bright_list[at] = make_uint2(((uint32_t)(f0 + (int)fc) << 16) | (gc * 8u + j), tg >> 6);
@@ -623,7 +622,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
 #pragma unroll
                             for (int w = 0; w < 4; ++w) s_q[8 + w][e] = ring[sc][w];
                             s_q[15][e] = info;
-                            s_q[30][e] = ((uint32_t)yout << 6) | (uint32_t)lane;
+                            s_q[30][e] = ((uint32_t)yout << 6) | (uint32_t)lane; s_q[31][e] = my_fg;
                         }
                     } else {
                     // the group's 14 column sums of p^2 (own 8 + 3 from each neighbour lane)
@@ -642,7 +641,7 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                         s_q[15][e] = info;
                         s_q[16][e] = QL5; s_q[17][e] = QL6; s_q[18][e] = QL7;
                         s_q[27][e] = QR0; s_q[28][e] = QR1; s_q[29][e] = QR2;
-                        s_q[30][e] = ((uint32_t)yout << 6) | (uint32_t)lane;
+                        s_q[30][e] = ((uint32_t)yout << 6) | (uint32_t)lane; s_q[31][e] = my_fg;
                     }
                     }
                     qn += nfl;
