@@ -830,16 +830,17 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
                 }
             }
         }
-        int T = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool bit = (todo >> j) & 1u;
-            const unsigned long long bm = __builtin_amdgcn_ballot_w64(bit);
-            if (bit) {
-                const uint32_t pos = (uint32_t)T + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                s_list[pos] = (uint16_t)(((uint32_t)lane << 2) | (uint32_t)j);
+        // (listed by a scan of the lanes' counts, as in k_stream_u16)
+        const uint32_t todo_n = (uint32_t)__popc(todo);
+        const uint32_t todo_incl = wave_inclusive_scan(todo_n);
+        const int T = __builtin_amdgcn_readlane((int)todo_incl, 63);
+        {
+            uint32_t pos = todo_incl - todo_n, w = todo;
+            while (w) {
+                const uint32_t j = (uint32_t)__ffs((int)w) - 1u;
+                w &= w - 1u;
+                s_list[pos++] = (uint16_t)(((uint32_t)lane << 2) | j);
             }
-            T += __popcll(bm);
         }
         __builtin_amdgcn_wave_barrier();
         for (int base = 0; base < T; base += 64) {
@@ -983,6 +984,7 @@ template __global__ void k_stream_u16<3, false, false>(const ThresholdArgs);
 template __global__ void k_stream_u16<4, false, false>(const ThresholdArgs);
 template __global__ void k_stream_u16<2, false, true>(const ThresholdArgs);
 template __global__ void k_stream_u16<2, true, false>(const ThresholdArgs);
+template __global__ void k_stream_u16<3, true, false>(const ThresholdArgs);
 template __global__ void k_stream_u16<2, true, true>(const ThresholdArgs);
 template __global__ void k_stream_u32<2, false>(const ThresholdArgs);
 template __global__ void k_stream_u32<3, false>(const ThresholdArgs);
