@@ -751,6 +751,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-settle", action="store_true", help="no untimed settling regions between the warm-up steps and the timed repetitions")
     ap.add_argument("--reps", type=int, default=5,
                     help="repetitions of the timed `steps`-step region; `value` comes from the median one")
     ap.add_argument("--batch", type=int, default=32, help="frames per step and per GPU")
@@ -1062,6 +1063,17 @@ def main():
         ms_dense, _ = streams[0].bench_threshold(ptr, pitch, fstride, B, iters=10)
         ctx.set_params(want_reflections=1, algorithm=0, want_strong_mask=0)
     run_steps(args.warmup)
+    # Untimed, after the W warm-up steps the driver asked for: regions of the same K steps until two in a row agree within 1 % (at most
+    # eight).  The GPU's clocks follow its load over tens of milliseconds; W = 5 steps are 1.5 ms, and without this the repetitions below
+    # read 0.322, 0.311, 0.303, 0.295, 0.297 ms per step (profiles/r06q_bench_lines_steps20.jsonl) -- a ramp, not the pipeline.  Every
+    # one of these regions is listed in the line (`settling_ms_per_step`); the timed repetitions that follow are all listed too.
+    settling = []
+    if not args.no_settle:
+        for _ in range(8):
+            el, _ = timed(args.steps)
+            settling.append(el)
+            if len(settling) >= 2 and abs(settling[-1] - settling[-2]) < 0.01 * settling[-2]:
+                break
     thr_ms.clear()
     # `reps` repetitions of the same `steps`-step region: the timed region is a few ms, one slow dispatch moves a single
     # repetition by several per cent -- `value` is the median repetition
@@ -1215,6 +1227,9 @@ def main():
                             "value_from": "median repetition of the same steps-step region (barrier + synchronize on both sides of each)"},
             "steady_ms_per_step": round(steady * 1e3, 4),
             "drain_ms": round(drain * 1e3, 4),
+            "settling_ms_per_step": [round(t / args.steps * 1e3, 4) for t in settling],
+            "settling": "untimed regions of the same K steps after the W warm-up steps, until two in a row agree within 1 % (at most 8): the GPU's "
+                        "clocks follow its load over tens of ms; --no-settle switches it off",
             "order_of_legs": "memory-ceiling probe (40 iterations) and the kernel-alone legs, THEN warm-up and the timed regions: a GPU that idled "
                              "while Python loaded the fixtures needs ~30 ms of load to reach its clocks (tools/rep_probe.py); every repetition is listed",
             "n_ranks_seen": n_ranks_seen,
