@@ -185,7 +185,8 @@ int ffs_ctx_set_params(ffs_ctx *ctx, const ffs_params *p);
  *                          through the one-workgroup launch inside ffs_wait
  *   "wait_ahead"       (1) a thread of the context turns each batch's records into the result arrays as soon as the GPU has finished
  *                          it, so ffs_wait finds them ready (0: ffs_wait does it, as in rounds 1-4)
- *   "stream_prio"      (1) the 16-bit streaming kernel's waves run at issue priority 3 (s_setprio): ahead of the band waves on their SIMDs
+ *   "stream_prio"      (1) bit 1: the 16-bit streaming kernel's waves run at issue priority 3 (s_setprio), ahead of the band waves on their
+ *                      SIMDs; bit 2: the band and merge waves do (measured slower: DESIGN.md section 3.4c); 0..3
  *   "dense_overlap"    (0) 1 = consecutive streaming kernels of the wave-log path on two HIP streams, handed over by a value the launch's
  *                          last workgroup writes as it starts (hipStreamWaitValue32) instead of the queue's barrier between two dispatches;
  *                          works in isolation, measured 8-10 % slower in the pipeline: off, kept as the A/B partner
@@ -194,7 +195,7 @@ int ffs_ctx_set_params(ffs_ctx *ctx, const ffs_params *p);
  *   "sched"            (3) 3 = shared dense / sparse / upload HIP streams per context, 0 = one per ffs_stream
  *                          (before the first stream is created)
  *   "direct_records"   (1) records written straight into pinned host memory (before the first stream is created)
- *   "chain_first" (2), "bright_cap" (2^20), "frames_per_group", "target_waves" (16384), "dense_mask" (0),
+ *   "chain_first" (2), "bright_cap" (2^20), "frames_per_group", "target_waves" (16384), "stream_bands" (0: from target_waves; > 0: that many bands, any number), "dense_mask" (0),
  *   "occupancy_bitmap" (1), "decode_in_dense_stream" (1), "rows_ahead" (3: rows of loads a streaming wave keeps in flight), "ccl_grid" (32): see DESIGN.md.
  *   "band_taper" (0), "ext_rest_aside" (0), "ext_fused" (0): round 4's A/B partners (tapered bands of the streaming kernels;
  *                          extended algorithm: erosion + final pass in the sparse stream / fused into one kernel) -- measured, no
