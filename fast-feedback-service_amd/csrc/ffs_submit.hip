@@ -194,7 +194,6 @@ static void launch_ext_first(ffs_stream* s, const ThresholdArgs& a, uint32_t n_f
         if (!plane_clean) (void)hipMemsetAsync(a.dplane, 0, (size_t)n_frames * a.plane_frame_stride, s->st);
         if (!counts_clean) (void)hipMemsetAsync(a.tile_counts, 0, tile_counts_bytes(s), s->st);
         if (a.dense_mask) hipExtLaunchKernelGGL((k_stream_u16<2, true, true>), stream_grid(a, n_frames), dim3(64), 0, s->st, start, stop, 0, a);
-        else if (s->ctx->tune.rows_ahead >= 3) hipExtLaunchKernelGGL((k_stream_u16<3, true, false>), stream_grid(a, n_frames), dim3(64), 0, s->st, start, stop, 0, a);
         else hipExtLaunchKernelGGL((k_stream_u16<2, true, false>), stream_grid(a, n_frames), dim3(64), 0, s->st, start, stop, 0, a);
         if (fix_here) hipLaunchKernelGGL((k_bright_fix<uint16_t, true>), dim3(32), dim3(256), 0, s->st, a);
         return;

@@ -333,6 +333,13 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
         const bool have = lane < qn && !FFS_DBG(a, 2) && !FFS_DBG(a, 32);   // (bit 32 leaves the queue unwritten: nothing to read back)
         uint32_t todo = 0, row = 0, fe = 0, ge = 0;
         if (have) {
+            // everything phase 1 reads of the entry is asked for HERE, in one LDS round trip: left where it is used, the window sums and
+            // the pixels were fetched behind the branch on the group's counts -- a second round trip in every drain (section 3.2e)
+            uint32_t xs[8], pws[4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xs[j] = s_q[j][lane];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pws[q] = s_q[8 + q][lane];
             row = s_q[30][lane] >> 6;
             const uint32_t fg = s_q[31][lane];   // (the pushing lane's own frame and group: no division here)
             fe = fg >> 16;
@@ -367,8 +374,8 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
                 const float kq_group = a.kB * __builtin_amdgcn_sqrtf(2.0f * ((float)gmin - 1.0f));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const uint32_t x = s_q[j][lane];
-                    const uint32_t pw = s_q[8 + (j >> 1)][lane];
+                    const uint32_t x = xs[j];
+                    const uint32_t pw = pws[j >> 1];
                     const uint32_t pv = (j & 1) ? pw >> 16 : pw & 0xFFFFu;
                     const uint32_t m = ((j < 4 ? mm.x : mm.y) >> (8 * (j & 3))) & 0xFFu;
                     const float mf = (float)m, xf = (float)x, yf = (float)s_q[16 + j][lane];   // (the window's sum of p^2, as pushed)
@@ -388,8 +395,8 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const uint32_t x = s_q[j][lane];
-                    const uint32_t pw = s_q[8 + (j >> 1)][lane];
+                    const uint32_t x = xs[j];
+                    const uint32_t pw = pws[j >> 1];
                     const uint32_t pv = (j & 1) ? pw >> 16 : pw & 0xFFFFu;
                     const uint32_t m = ((j < 4 ? mm.x : mm.y) >> (8 * (j & 3))) & 0xFFu;
                     //   oracle: b = m p - x > nsig_s sqrt(x m);  here: b |b| > nsig_s^2 (1 - 2^-16) x m in float32
@@ -418,17 +425,20 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
             const int idx = base + lane;
             if (idx < T) {
                 const uint32_t ent = s_list[idx], e = ent >> 3, j = ent & 7u;
+                // (the candidate's ten words in ONE round trip: read where they were used, x came first, the branch on it next, and the
+                // column sums behind that -- three round trips)
                 const uint32_t x = s_q[j][e], pv = (s_q[8 + (j >> 1)][e] >> (16 * (j & 1))) & 0xFFFFu;
                 const uint32_t m = (s_q[12 + (j >> 2)][e] >> (8 * (j & 3))) & 0xFFu;
-                if (x < 65536u) {
-                    // sum p^2 mod 2^32 is the true sum while x < 65536 (y <= 65535 x < 2^32); window j = cq[j .. j+6]
-                    uint32_t y = 0;
-                    if constexpr (EXT) {
-                        y = s_q[16 + j][e];
-                    } else {
+                // sum p^2 mod 2^32 is the true sum while x < 65536 (y <= 65535 x < 2^32); window j = cq[j .. j+6]
+                uint32_t y = 0;
+                if constexpr (EXT) {
+                    y = s_q[16 + j][e];
+                } else {
 #pragma unroll
-                        for (uint32_t t = 0; t < 7; ++t) y += s_q[16 + j + t][e];
-                    }
+                    for (uint32_t t = 0; t < 7; ++t) y += s_q[16 + j + t][e];
+                }
+                asm volatile("" : "+v"(y));   // (keeps the reads ahead of the branch)
+                if (x < 65536u) {
                     bool certain;
                     bool strong;
                     if constexpr (EXT) {
@@ -984,7 +994,6 @@ template __global__ void k_stream_u16<3, false, false>(const ThresholdArgs);
 template __global__ void k_stream_u16<4, false, false>(const ThresholdArgs);
 template __global__ void k_stream_u16<2, false, true>(const ThresholdArgs);
 template __global__ void k_stream_u16<2, true, false>(const ThresholdArgs);
-template __global__ void k_stream_u16<3, true, false>(const ThresholdArgs);
 template __global__ void k_stream_u16<2, true, true>(const ThresholdArgs);
 template __global__ void k_stream_u32<2, false>(const ThresholdArgs);
 template __global__ void k_stream_u32<3, false>(const ThresholdArgs);
