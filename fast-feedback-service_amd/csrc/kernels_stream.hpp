@@ -101,27 +101,26 @@ __device__ __forceinline__ bool exact_predicate_nosqrt(const ThresholdArgs& a, u
 // is false and the caller evaluates exact_predicate.  A fifth of the float64 form's issue slots (v_mad_u64_u32 instead of
 // chains of v_mul_f64 / v_fma_f64 and conversions).
 __device__ __forceinline__ bool int_predicate(const ThresholdArgs& a, uint32_t m, uint32_t x, uint32_t y, uint32_t pc, bool& certain) {
-    certain = true;
-    if (!((int)m >= a.min_count && pc > a.thr_floor)) return false;
-    if (a.max_valid >= 0 && (long long)pc > a.max_valid) return false;
+    // (no early return: every `if (...) return false` was an exec-mask region of its own in each of the drain's ten inlined copies,
+    // and a wave runs all of it anyway as long as one lane goes on -- DESIGN.md section 3.2e)
+    const bool ok = (int)m >= a.min_count && pc > a.thr_floor && !(a.max_valid >= 0 && (long long)pc > a.max_valid);
     const unsigned long long my = (unsigned long long)m * y;                 // < 2^38
     const unsigned long long xx = (unsigned long long)x * (x + m - 1u);      // < 2^33
     const int32_t bv = (int32_t)__umul24(m, pc) - (int32_t)x;                // |b| < 2^22
-    if (my <= xx || bv <= 0) return false;                                   // a <= 0 or b <= 0, and c, d >= 0
-    const unsigned long long av = my - xx;
+    const bool pos = my > xx && bv > 0;                                      // else a <= 0 or b <= 0, and c, d >= 0: not strong
+    const unsigned long long av = my - xx;                                   // (wraps where !pos: unused there)
     const unsigned long long c2 = (unsigned long long)(a.ib2 * 2u * (m - 1u)) * (unsigned long long)(x * x);   // < 2^17 2^32
-    bool disp_yes = true, disp_close = false;
-    if (av < (1ull << 25)) {                                                  // (beyond: a^2 >= 2^50 > c^2)
-        const unsigned long long a2 = (unsigned long long)(uint32_t)av * (uint32_t)av;
-        disp_yes = a2 > c2;
-        disp_close = (a2 > c2 ? a2 - c2 : c2 - a2) < 16ull;
-    }
-    const unsigned long long b2 = (unsigned long long)(uint32_t)bv * (uint32_t)bv;   // < 2^44
+    const bool small = av < (1ull << 25);                                    // (beyond: a^2 >= 2^50 > c^2)
+    const unsigned long long a2 = (unsigned long long)(uint32_t)av * (uint32_t)av;
+    const bool disp_yes = !small || a2 > c2;
+    const bool disp_close = small && (a2 > c2 ? a2 - c2 : c2 - a2) < 16ull;
+    const uint32_t bu = (uint32_t)bv;
+    const unsigned long long b2 = (unsigned long long)bu * bu;               // < 2^44 where pos
     const unsigned long long d2 = (unsigned long long)a.is2 * __umul24(x, m);       // x m < 2^22
     const bool sig_yes = b2 > d2;
     const bool sig_close = (b2 > d2 ? b2 - d2 : d2 - b2) < 16ull;
-    certain = !(disp_close || sig_close);
-    return disp_yes && sig_yes;
+    certain = !(ok && pos && (disp_close || sig_close));
+    return ok && pos && disp_yes && sig_yes;
 }
 
 // First pass of the extended algorithm (baseline.cpp:468-473): the dispersion half alone, a > c, for a valid
