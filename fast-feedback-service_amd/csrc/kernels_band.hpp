@@ -66,6 +66,7 @@ __global__ __launch_bounds__(64) void k_band_cc(const BandArgs B) {
     __shared__ __align__(16) uint32_t s_cw[kBandCw];
     __shared__ __align__(8) uint2 s_ent[kBandEntries];   // the band's log entries: (row << 16 | group, strip << 16 | undecided << 8 | strong); not mine: y = 0xFFFF0000
     __shared__ uint16_t s_x[kBandPx];
+    __shared__ uint8_t s_y[kBandPx];   // the pixel's row in the band (the loops below ask for it instead of walking the rows' offsets)
     __shared__ PixelT s_i[kBandPx];
     __shared__ uint32_t s_par[kBandPx];
     __shared__ uint32_t s_flag;
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(64) void k_band_cc(const BandArgs B) {
                         if (at < (uint32_t)kBandPx) {
                             s_x[at] = (uint16_t)(ge * kGroupPx + (uint32_t)b);
                             s_i[at] = (PixelT)I;
+                            s_y[at] = (uint8_t)row;
                         }
                         ++at;
                     }
@@ -254,48 +256,51 @@ __global__ __launch_bounds__(64) void k_band_cc(const BandArgs B) {
 
             FFS_STOP_AFTER(B.A, 13);
             // ---- X / U: the forest (k_frame_chain's phases, band-local rows; edges across the band's ends are the merge's) --------
+            // (A lane takes `per` consecutive pixels; the loops run `per` times for the whole wave with the lane's share as a
+            // predicate -- a scalar counter instead of an exec-mask loop per lane -- and a pixel's row comes from s_y: round 5 measured
+            // what this half of the wave costs the streaming waves beside it)
             const uint32_t per = (n + 63u) / 64u;
             const uint32_t i0 = min((uint32_t)lane * per, n), i1 = min(i0 + per, n);
-            uint32_t yrow = 0;
-            if (i0 < i1) {
-                uint32_t lo = 0, hi = rows;   // the last row whose offset is <= i0 (rows without strong pixels share their successor's)
-                while (lo < hi) {
-                    const uint32_t mid = lo + ((hi - lo) >> 1);
-                    if (s_row[mid + 1] <= i0) lo = mid + 1; else hi = mid;
-                }
-                yrow = lo;
-            }
-            auto continues = [&](uint32_t j, uint32_t r) -> bool {
-                if (j == 0) return false;
-                const uint32_t xj = s_x[j], xp = s_x[j - 1];
-                if (j != s_row[r]) return xp + 1 == xj;                                   // same row
-                return xj == 0 && xp == W - 1 && r > 0 && s_row[r - 1] < s_row[r];        // first of its row: the row above ends the list before it
+            // pixel j continues the run of pixel j - 1: the k + 1 edge, the reference's row-wrap included (x = W - 1 of one row and
+            // x = 0 of the next: connected_components.cc:62-70); (xp, yp) = pixel j - 1
+            auto continues = [&](uint32_t j, uint32_t xj, uint32_t yj, uint32_t xp, uint32_t yp) -> bool {
+                return j != 0 && (yj == yp ? xp + 1 == xj : (xj == 0 && xp == W - 1 && yp + 1 == yj));
             };
+            const uint32_t xp0 = i0 > 0 && i0 < i1 ? (uint32_t)s_x[i0 - 1] : 0u, yp0 = i0 > 0 && i0 < i1 ? (uint32_t)s_y[i0 - 1] : 0u;
             {
-                uint32_t y = yrow;
-                for (uint32_t i = i0; i < i1; ++i) {
-                    while (s_row[y + 1] <= i) ++y;
-                    s_par[i] = (continues(i, y) && s_x[i] != 0) ? i - 1 : i;
+                uint32_t xp = xp0, yp = yp0;
+                for (uint32_t k = 0; k < per; ++k) {
+                    const uint32_t i = i0 + k;
+                    if (i < i1) {
+                        const uint32_t x = s_x[i], y = s_y[i];
+                        s_par[i] = (continues(i, x, y, xp, yp) && x != 0) ? i - 1 : i;
+                        xp = x; yp = y;
+                    }
                 }
             }
             __syncthreads();
             {
-                uint32_t y = yrow;
-                for (uint32_t i = i0; i < i1; ++i) {
-                    while (s_row[y + 1] <= i) ++y;
-                    const uint32_t x = s_x[i];
-                    const bool cont = continues(i, y);
-                    if (cont && x == 0) uf_union(s_par, i - 1, i);   // the row-wrap edge inside the band
-                    if (y + 1 >= rows) continue;
-                    uint32_t lo = max(i + 1, s_row[y + 1]);
-                    const uint32_t end = max(lo, s_row[y + 2]);
-                    uint32_t hi = end;
-                    while (lo < hi) {   // lower bound of x among the next row's entries
-                        const uint32_t mid = lo + ((hi - lo) >> 1);
-                        if ((uint32_t)s_x[mid] < x) lo = mid + 1; else hi = mid;
-                    }
-                    if (lo < end && (uint32_t)s_x[lo] == x) {
-                        if (!cont || !continues(lo, y + 1)) uf_union(s_par, i, lo);   // one edge per pair of overlapping runs is enough
+                uint32_t xp = xp0, yp = yp0;
+                for (uint32_t k = 0; k < per; ++k) {
+                    const uint32_t i = i0 + k;
+                    if (i < i1) {
+                        const uint32_t x = s_x[i], y = s_y[i];
+                        const bool cont = continues(i, x, y, xp, yp);
+                        xp = x; yp = y;
+                        if (cont && x == 0) uf_union(s_par, i - 1, i);   // the row-wrap edge inside the band
+                        if (y + 1 < rows) {
+                            uint32_t lo = max(i + 1, s_row[y + 1]);
+                            const uint32_t end = max(lo, s_row[y + 2]);
+                            uint32_t hi = end;
+                            while (lo < hi) {   // lower bound of x among the next row's entries
+                                const uint32_t mid = lo + ((hi - lo) >> 1);
+                                if ((uint32_t)s_x[mid] < x) lo = mid + 1; else hi = mid;
+                            }
+                            if (lo < end && (uint32_t)s_x[lo] == x) {
+                                // one edge per pair of overlapping runs is enough
+                                if (!cont || !continues(lo, x, y + 1, s_x[lo - 1], s_y[lo - 1])) uf_union(s_par, i, lo);
+                            }
+                        }
                     }
                 }
             }
@@ -304,21 +309,29 @@ __global__ __launch_bounds__(64) void k_band_cc(const BandArgs B) {
             // ---- P: roots, numbered in list order; every entry's component (16 bits each, in the entries' LDS: they are done with) ----
             uint16_t* s_id = reinterpret_cast<uint16_t*>(s_ent);
             uint32_t mine_roots = 0;
-            for (uint32_t i = i0; i < i1; ++i) {
-                const uint32_t root = uf_find(s_par, i);
-                s_id[i] = (uint16_t)root;
-                mine_roots += root == i ? 1u : 0u;
+            for (uint32_t k = 0; k < per; ++k) {
+                const uint32_t i = i0 + k;
+                if (i < i1) {
+                    const uint32_t root = uf_find(s_par, i);
+                    s_id[i] = (uint16_t)root;
+                    mine_roots += root == i ? 1u : 0u;
+                }
             }
             __syncthreads();   // every find is done: the root slots take the component numbers
             {
                 const uint32_t inc = wave_inclusive_scan(mine_roots);
                 ncomp = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
                 uint32_t sl = inc - mine_roots;
-                for (uint32_t i = i0; i < i1; ++i)
-                    if ((uint32_t)s_id[i] == i) s_par[i] = sl++;
+                for (uint32_t k = 0; k < per; ++k) {
+                    const uint32_t i = i0 + k;
+                    if (i < i1 && (uint32_t)s_id[i] == i) s_par[i] = sl++;
+                }
             }
             __syncthreads();
-            for (uint32_t i = i0; i < i1; ++i) s_id[i] = (uint16_t)s_par[s_id[i]];
+            for (uint32_t k = 0; k < per; ++k) {
+                const uint32_t i = i0 + k;
+                if (i < i1) s_id[i] = (uint16_t)s_par[s_id[i]];
+            }
             if (ncomp > (uint32_t)kBandCompStride) atomicOr(&s_flag, 128u);
             __syncthreads();
 
@@ -336,12 +349,11 @@ __global__ __launch_bounds__(64) void k_band_cc(const BandArgs B) {
                     }
                     __syncthreads();
                     {
-                        uint32_t yl = yrow;
-                        for (uint32_t i = i0; i < i1; ++i) {
-                            while (s_row[yl + 1] <= i) ++yl;
-                            const uint32_t c = (uint32_t)s_id[i] - c0;
+                        for (uint32_t k = 0; k < per; ++k) {
+                            const uint32_t i = i0 + k;
+                            const uint32_t c = i < i1 ? (uint32_t)s_id[i] - c0 : 0xFFFFFFFFu;
                             if (c < (uint32_t)kBandSlots) {
-                                const uint32_t y = (uint32_t)yb0 + yl, x = s_x[i];
+                                const uint32_t y = (uint32_t)yb0 + (uint32_t)s_y[i], x = s_x[i];
                                 const uint32_t ki = y * W + x;
                                 const unsigned long long I = s_i[i];
                                 ChainAcc* r = &s_acc[c];
