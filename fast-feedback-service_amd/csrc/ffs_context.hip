@@ -438,6 +438,7 @@ extern "C" int ffs_ctx_set_tuning(ffs_ctx* c, const char* key, long long value) 
     else if (k == "dense_overlap") { if ((ok = in(0, 1))) t.dense_overlap = (int)value; }
     else if (k == "stream_prio") { if ((ok = in(0, 3))) t.stream_prio = (int)value; }
     else if (k == "wait_ahead") { if ((ok = in(0, 1))) t.wait_ahead = (int)value; }
+    else if (k == "assembly_threads") { if ((ok = in(1, 31))) t.assembly_threads = (int)value; }
     else if (k == "sparse_bands") { if ((ok = in(0, 2))) t.sparse_bands = (int)value; }
     else if (k == "sparse_priority") {
         // priority of the context's two sparse HIP streams: 0 = highest (default), 1 = lowest, 2 = the dense stream's; before the first stream is created

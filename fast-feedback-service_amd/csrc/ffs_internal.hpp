@@ -108,6 +108,7 @@ struct Tuning {
                                 //    freed slots, and each streaming kernel takes 0.325 instead of 0.298 ms.  Off; kept as the A/B partner
     int stream_prio = 1;        // 1: the 16-bit streaming kernel's waves run at issue priority 3 (s_setprio), ahead of the band waves that share their SIMDs
                                 //    (+1 % on the driver-style line, six alternating pairs: profiles/r05zm_stream_prio_ab.log); 0: default priority
+    int assembly_threads = 7;   // helper threads that assemble a batch's result arrays beside the caller (made with the context's first large batch)
     int wait_ahead = 1;         // a thread of the context assembles each batch's result arrays as soon as the GPU has finished it (0: ffs_wait does)
     int sparse_priority = 0;    // priority of the context's sparse HIP streams: 0 = highest, 1 = lowest, 2 = the dense stream's
 #ifdef FFS_EXPERIMENTS

@@ -125,7 +125,7 @@ static int assemble_batch(ffs_stream* s, uint64_t total_recs, const std::vector<
                 pool = new (std::nothrow) AssemblyPool();
                 if (pool) {
                     try {
-                        pool->start(7);
+                        pool->start(std::max(1, std::min(31, c->tune.assembly_threads)));
                     } catch (...) {   // (no more threads to be had: whatever did start is joined, and this wait assembles on its own)
                         delete pool;
                         pool = nullptr;

@@ -196,7 +196,8 @@ int ffs_ctx_set_params(ffs_ctx *ctx, const ffs_params *p);
  *                          (before the first stream is created)
  *   "direct_records"   (1) records written straight into pinned host memory (before the first stream is created)
  *   "chain_first" (2), "bright_cap" (2^20), "frames_per_group", "target_waves" (16384), "stream_bands" (0: from target_waves; > 0: that many bands, any number), "dense_mask" (0),
- *   "occupancy_bitmap" (1), "decode_in_dense_stream" (1), "rows_ahead" (3: rows of loads a streaming wave keeps in flight), "ccl_grid" (32): see DESIGN.md.
+ *   "occupancy_bitmap" (1), "decode_in_dense_stream" (1), "rows_ahead" (3: rows of loads a streaming wave keeps in flight), "ccl_grid" (32),
+ *   "assembly_threads" (7: helper threads that build a batch's result arrays; 3, 12 and 15 measure the same): see DESIGN.md.
  *   "band_taper" (0), "ext_rest_aside" (0), "ext_fused" (0): round 4's A/B partners (tapered bands of the streaming kernels;
  *                          extended algorithm: erosion + final pass in the sparse stream / fused into one kernel) -- measured, no
  *                          gain, off (DESIGN.md sections 3.2c, 4)
