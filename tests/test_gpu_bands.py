@@ -24,7 +24,7 @@ def seam_frames(rng, W, H, dtype, band_rows, long_bars=True):
             img[y:y + rng.integers(1, 4), x:x + rng.integers(1, 6)] = rng.integers(200, 3000)
         frames.append(img)
     a, b, c, d = frames
-    seams = [s for s in range(band_rows, H, band_rows)]
+    seams = [s for s in range(band_rows, H - 30, band_rows)]   # (the shapes around a seam reach 29 rows below it)
     # a: vertical bars through one seam, through all of them; a bar that ends on a seam's last / first row
     for k, s in enumerate(seams):
         a[s - 3:s + 4, 40 + 17 * k] = 700
@@ -117,6 +117,39 @@ def test_bands_match_oracle_on_the_seams(ffs, dtype, W, H, target_waves):
     assert "bands" not in st.last_path()[0]
     for fr, img in zip(res, frames):
         assert_frame_matches_oracle(fr, img, mask)
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.uint32])
+@pytest.mark.parametrize("n_bands", [3, 5, 7, 11])
+def test_any_number_of_streaming_bands(ffs, dtype, n_bands):
+    """Tuning `stream_bands`: the streaming launch's units are dealt to the XCDs in eight contiguous chunks (ffs_device.h, stream_unit), so
+    the number of bands need not be a multiple of eight; the logs are addressed by (super row, band, strip).  Odd numbers of bands --
+    band heights of 173, 104, 74 and 47 rows, the first two cut into sub-bands by the band waves -- with the seams' frames, through
+    the band launches and through the one-workgroup launch."""
+    rng = np.random.default_rng(606)
+    W, H = 1203, 517
+    band_rows = -(-H // n_bands)
+    frames = seam_frames(rng, W, H, dtype, band_rows if band_rows <= 96 else band_rows // 2, long_bars=False)
+    mask = np.ones((H, W), np.uint8)
+    mask[:, 496:500] = 0
+    mask[rng.random((H, W)) < 0.001] = 0
+    ctx = ffs.Context(W, H, dtype, max_batch=len(frames))
+    ctx.set_tuning(stream_bands=n_bands)
+    ctx.set_mask(mask)
+    ctx.set_params(want_strong_list=0, min_spot_size=1)
+    st = ctx.stream()
+    for rep in range(2):
+        order = np.roll(np.arange(len(frames)), rep)
+        res = st.process(frames[order], first_frame_id=10 * rep)
+        path, reruns = st.last_path()
+        assert "bands" in path and "wave_logs" in path and reruns == 0, (path, reruns)
+        for fr, img in zip(res, frames[order]):
+            assert_frame_matches_oracle(fr, img, mask, min_spot_size=1)
+    ctx.set_tuning(sparse_bands=0)
+    res = st.process(frames)
+    assert st.last_path()[0] >= {"wave_logs", "frame_chain"}
+    for fr, img in zip(res, frames):
+        assert_frame_matches_oracle(fr, img, mask, min_spot_size=1)
 
 
 def test_bands_beyond_their_plan_fall_back(ffs):
