@@ -796,7 +796,18 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
     };
 
     int qn = 0;
-    uint32_t nlog = 0;   // entries of this wave's log (wave-uniform; ThresholdArgs::wlog)
+    uint32_t nlog = 0;   // entries of this wave's log already in memory (wave-uniform; ThresholdArgs::wlog)
+    uint32_t nbuf = 0;   // ... and still in lbuf: entry nlog + e in lane e, written out 64 at a time and when the wave ends (see k_stream_u16)
+    uint32_t lbuf[6] = {0, 0, 0, 0, 0, 0};
+    auto flush_log = [&]() {
+        const uint32_t at = nlog + (uint32_t)lane;
+        if ((uint32_t)lane < nbuf && at < (uint32_t)kWlogCap) {
+            a.wlog[(uint64_t)slot * kWlogCap + at] = make_uint2(lbuf[0], lbuf[1]);
+            a.wpix[(uint64_t)slot * kWlogCap + at] = make_uint4(lbuf[2], lbuf[3], lbuf[4], lbuf[5]);
+        }
+        nlog += nbuf;
+        nbuf = 0;
+    };
     auto drain = [&]() {
         const bool have = lane < qn && !FFS_DBG(a, 2) && !FFS_DBG(a, 32);   // (bit 32 leaves the queue unwritten, as in k_stream_u16: nothing to read back)
         uint32_t todo = 0, row = 0, fe = 0, ge = 0, info = 0;
@@ -871,15 +882,24 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
         __builtin_amdgcn_wave_barrier();
         if (a.wlog) {   // (wave-uniform) wave logs instead of plane, counters and bitmap: see k_stream_u16
             const uint32_t cbm = have ? s_q[10][lane] : 0u;   // strong | undecided << 8
+            const uint32_t pxw[4] = {s_q[4][lane], s_q[5][lane], s_q[6][lane], s_q[7][lane]};   // the group's four pixels
             const unsigned long long wm = __builtin_amdgcn_ballot_w64(cbm != 0u);
-            if (cbm != 0u) {
-                const uint32_t at = nlog + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u));
-                if (at < (uint32_t)kWlogCap) {
-                    a.wlog[(uint64_t)slot * kWlogCap + at] = make_uint2((row << 16) | ge, (fe << 16) | cbm);
-                    a.wpix[(uint64_t)slot * kWlogCap + at] = make_uint4(s_q[4][lane], s_q[5][lane], s_q[6][lane], s_q[7][lane]);   // the group's four pixels
+            if (wm) {
+                const uint32_t cnt = (uint32_t)__popcll(wm);
+                if (nbuf + cnt > 64u) flush_log();
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u));
+                const uint32_t dump = nbuf + cnt < 64u ? nbuf + cnt : 0u;   // (a lane outside the run's new part)
+                const int to = (int)((cbm != 0u ? nbuf + rank : dump) << 2);
+                const uint32_t e0 = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)((row << 16) | ge));
+                const uint32_t e1 = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)((fe << 16) | cbm));
+                const uint32_t p0 = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)pxw[0]), p1 = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)pxw[1]);
+                const uint32_t p2 = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)pxw[2]), p3 = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)pxw[3]);
+                if ((uint32_t)lane - nbuf < cnt) {
+                    lbuf[0] = e0; lbuf[1] = e1;
+                    lbuf[2] = p0; lbuf[3] = p1; lbuf[4] = p2; lbuf[5] = p3;
                 }
+                nbuf += cnt;
             }
-            nlog += (uint32_t)__popcll(wm);
             qn = 0;
             return;
         }
@@ -981,7 +1001,10 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
     }
 rows_done:
     if (qn > 0) drain();
-    if (a.wlog && lane == 0) a.wlog_n[slot] = nlog;
+    if (a.wlog) {
+        flush_log();
+        if (lane == 0) a.wlog_n[slot] = nlog;
+    }
 }
 
 template __global__ void k_bright_fix<uint16_t>(const ThresholdArgs);
