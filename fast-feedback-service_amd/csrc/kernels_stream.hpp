@@ -76,21 +76,20 @@ __device__ __forceinline__ bool exact_predicate(const ThresholdArgs& a, uint32_t
 // and the caller falls back to exact_predicate (with its correctly rounded square roots) otherwise.
 __device__ __forceinline__ bool exact_predicate_nosqrt(const ThresholdArgs& a, uint32_t m, unsigned long long sx,
                                                        unsigned long long sy, uint32_t pc, bool& certain) {
-    certain = true;
+    // (no early return, as in int_predicate: a wave runs all of it as long as one lane goes on)
     const double src = (double)pc;
-    if (!((int)m >= a.min_count && src > a.threshold)) return false;
-    if (a.max_valid >= 0 && (long long)pc > a.max_valid) return false;
+    const bool ok = (int)m >= a.min_count && src > a.threshold && !(a.max_valid >= 0 && (long long)pc > a.max_valid);
     const double md = (double)m, xd = (double)sx, yd = (double)sy;
     const double av = (md * yd - xd * xd) - xd * (md - 1.0);
     const double bv = md * src - xd;
-    if (!(av > 0.0 && bv > 0.0)) return false;  // c >= 0 and d >= 0
+    const bool pos = av > 0.0 && bv > 0.0;  // (else not strong: c >= 0 and d >= 0)
     const double a2 = av * av, c2 = (a.nsig_b2 * (xd * xd)) * (2.0 * (md - 1.0));
     const double b2 = bv * bv, d2 = a.nsig_s2 * (xd * md);
     constexpr double kEps = 9.094947017729282e-13;  // 2^-40
     const bool disp_yes = a2 > c2 + c2 * kEps, disp_no = a2 < c2 - c2 * kEps;
     const bool sig_yes = b2 > d2 + d2 * kEps, sig_no = b2 < d2 - d2 * kEps;
-    certain = (disp_yes || disp_no) && (sig_yes || sig_no);
-    return disp_yes && sig_yes;
+    certain = !(ok && pos) || ((disp_yes || disp_no) && (sig_yes || sig_no));
+    return ok && pos && disp_yes && sig_yes;
 }
 
 // The same decision in integers, for integer nsig_b, nsig_s (the defaults 6 and 3) and a window whose sums fit: x < 65536, so
@@ -820,14 +819,23 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
             fe = (uint32_t)Ge / (uint32_t)gsep;
             ge = (uint32_t)Ge - fe * (uint32_t)gsep;
             info = s_q[8][lane];
-            const uint32_t mm = *reinterpret_cast<const uint32_t*>(a.mmap + (uint64_t)min(row, (uint32_t)a.H - 1u) * a.pitch_px
-                                                                   + min(ge * 4u, (uint32_t)a.pitch_px - 4u));   // (clamped: see k_stream_u16)
+            uint32_t xs[4], pvs[4];   // (asked for here, with the tag and the counts' bounds: one LDS round trip -- see k_stream_u16)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { xs[j] = s_q[j][lane]; pvs[j] = s_q[4 + j][lane]; }
+            // window counts of the four pixels: one value for the whole group almost everywhere (then ginfo has it, as in k_stream_u16);
+            // only groups next to masked pixels fetch their counts -- until round 5 EVERY drain of this kernel began with this dependent
+            // global round trip (tag -> division -> address -> load)
+            const uint32_t gmin = (info >> 8) & 0xFFu, gmax = (info >> 16) & 0xFFu;
+            uint32_t mm = gmin * 0x01010101u;
+            if (gmin != gmax)
+                mm = *reinterpret_cast<const uint32_t*>(a.mmap + (uint64_t)min(row, (uint32_t)a.H - 1u) * a.pitch_px
+                                                        + min(ge * 4u, (uint32_t)a.pitch_px - 4u));   // (clamped: see k_stream_u16)
             s_q[9][lane] = mm;
             s_q[10][lane] = 0u;
             if (!big) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const uint32_t x = s_q[j][lane], pv = s_q[4 + j][lane];
+                    const uint32_t x = xs[j], pv = pvs[j];
                     const uint32_t m = (mm >> (8 * j)) & 0xFFu;
                     // conservative float32 signal test (b exact in 32 bits; the conversions stay far inside the 2^-16 margin of kS)
                     const int32_t b = (int32_t)(m * pv) - (int32_t)x;
