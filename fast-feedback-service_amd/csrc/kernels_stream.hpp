@@ -352,8 +352,14 @@ __global__ __launch_bounds__(64, 4) void k_stream_u16(const ThresholdArgs a) {
             // that comes out of the LDS queue -- a tag that is not what a push wrote, as under round 3's experiment bit 32 which left
             // the queue unwritten, must not become a wild address: DESIGN.md section 10.  A buffer resource for it cost four SGPRs
             // over the whole kernel, 17 spills instead of 13 and 1-3 % of the step.)
-            if (gmin != gmax)
-                mm = *reinterpret_cast<const uint2*>(a.mmap + (uint64_t)min(row, (uint32_t)a.H - 1u) * a.pitch_px + min(ge * 8u, (uint32_t)a.pitch_px - 8u));
+            if (gmin != gmax) {
+                uint2 t = *reinterpret_cast<const uint2*>(a.mmap + (uint64_t)min(row, (uint32_t)a.H - 1u) * a.pitch_px + min(ge * 8u, (uint32_t)a.pitch_px - 8u));
+                // The load is waited for HERE, inside the rare branch.  Left to the compiler the wait stood behind the branch's join --
+                // `s_waitcnt vmcnt(0)` in EVERY drain, load or no load -- and vmcnt counts the row loop's prefetched pixel rows too: each
+                // drain waited until the three rows in flight had all arrived.
+                asm volatile("" : "+v"(t.x), "+v"(t.y));
+                mm = t;
+            }
             s_q[12][lane] = mm.x;
             s_q[13][lane] = mm.y;
             s_q[14][lane] = 0u;
@@ -827,9 +833,12 @@ __global__ __launch_bounds__(64, 4) void k_stream_u32(const ThresholdArgs a) {
             // global round trip (tag -> division -> address -> load)
             const uint32_t gmin = (info >> 8) & 0xFFu, gmax = (info >> 16) & 0xFFu;
             uint32_t mm = gmin * 0x01010101u;
-            if (gmin != gmax)
-                mm = *reinterpret_cast<const uint32_t*>(a.mmap + (uint64_t)min(row, (uint32_t)a.H - 1u) * a.pitch_px
-                                                        + min(ge * 4u, (uint32_t)a.pitch_px - 4u));   // (clamped: see k_stream_u16)
+            if (gmin != gmax) {
+                uint32_t t = *reinterpret_cast<const uint32_t*>(a.mmap + (uint64_t)min(row, (uint32_t)a.H - 1u) * a.pitch_px
+                                                                + min(ge * 4u, (uint32_t)a.pitch_px - 4u));   // (clamped: see k_stream_u16)
+                asm volatile("" : "+v"(t));   // (waited for inside the branch, not behind its join: see k_stream_u16)
+                mm = t;
+            }
             s_q[9][lane] = mm;
             s_q[10][lane] = 0u;
             if (!big) {
