@@ -87,9 +87,9 @@ ThresholdArgs make_threshold_args(ffs_stream* s, const void* img, size_t pitch, 
     a.n_frames = (int)n_frames;
     {   // Streaming kernels: frames side by side in one super row, as many as keep every buffer of the group below 2 GiB.
         // Bands: enough waves to fill the 256 CUs several times over, bands no shorter than 72 rows (the 6-row warm-up of
-        // every band stays below 8 %) -- and a whole number of bands per XCD: the kernels deal the bands round-robin to the
-        // 8 XCDs (band = xcd + 8 k, so that neighbouring strips share an L2); with 29 bands three XCDs had a band less to
-        // do than the others and the launch waited for the busy five (511 us per 32 Eiger frames against 430-440 with 48 or 56).
+        // every band stays below 8 %).  The default stays a multiple of eight bands (what rounds 1-4's round-robin map, band = xcd + 8 k,
+        // needed: with 29 bands three XCDs had a band less to do than the others, 511 us per 32 Eiger frames against 430-440 with 48
+        // or 56); the unit map of round 5 (ffs_device.h, stream_unit) balances any number -- tuning "stream_bands".
         const uint64_t per_frame = std::max<uint64_t>(fstride, L.bytes_frame_stride);
         a.group_frames = (int)std::max<uint64_t>(1, std::min<uint64_t>(n_frames, ((1ull << 31) - 1) / per_frame));
         a.group_frames = std::min(a.group_frames, c->tune.frames_per_group);
