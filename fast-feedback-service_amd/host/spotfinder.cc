@@ -348,8 +348,66 @@ int main(int argc, char** argv) {
         std::printf("Error: Thread count must be >= 1\n");
         return 1;
     }
+    struct JoinedThread {   // (an early `return` below must not meet a joinable std::thread)
+        std::thread th;
+        ~JoinedThread() { if (th.joinable()) th.join(); }
+    };
+    // The frame source is opened (header, the 72 MB pixel mask of an Eiger-16M stream directory: 35 ms) on a helper thread WHILE this
+    // one initialises the HIP runtime (70-160 ms): nothing in it needs the GPU, and a request's latency is the wall time of the process
+    // (DESIGN.md section 5b).  It prints only when it has to wait for its files or fails.
+    std::unique_ptr<Reader> reader_ptr;
+    int reader_rc = 0;
+    std::atomic<bool> give_up{false};   // (no GPU after all: the helper stops waiting for files and says nothing more)
+    auto open_reader = [&]() -> int {
+        // ---- choose the reader (spotfinder.cc:438-466)
+        auto wait_ready = [&](const std::string& path, auto checker) {  // wait_for_ready_for_read, :137-175
+            const auto t0 = std::chrono::steady_clock::now();
+            bool waited = false;
+            while (!checker(path)) {
+                if (give_up.load()) return;
+                const double w = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                std::printf("\rWaiting for \033[1;35m%s\033[0m to be ready for read [%4.1f s] ", path.c_str(), w);
+                std::fflush(stdout);
+                waited = true;
+                if (w > args.timeout) {
+                    std::printf("\nError: Waited too long for read availability\n");
+                    std::exit(1);
+                }
+                std::this_thread::sleep_for(80ms);
+            }
+            if (waited) std::printf("\n");
+        };
+        try {
+            if (args.sample || file.rfind("synth:", 0) == 0) {
+                reader_ptr = make_synth_reader(args.sample ? "synth:eiger16m:6" : file);
+            } else {
+                if (!fs::exists(file) && file.find('#') == std::string::npos)
+                    wait_ready(file, [](const std::string& s) { return fs::exists(s); });
+                if (fs::is_directory(file)) {
+                    wait_ready(file, is_ready_for_read<SHMRead>);
+                    reader_ptr = make_shm_reader(file);
+                } else if (file.size() > 4 && file.compare(file.size() - 4, 4, ".cbf") == 0) {
+                    if (!args.images_set) {
+                        std::printf("Error: CBF reading must specify --images\n");
+                        return 1;
+                    }
+                    reader_ptr = make_cbf_reader(file, args.images, args.start_index);
+                } else {
+                    wait_ready(file, is_ready_for_read<H5Read>);
+                    reader_ptr = make_h5_reader(file);
+                }
+            }
+        } catch (const std::exception& e) {
+            if (!give_up.load()) std::printf("Error: %s\n", e.what());
+            return 1;
+        }
+        return 0;
+    };
+    JoinedThread reader_holder;
+    reader_holder.th = std::thread([&] { reader_rc = open_reader(); });
     stamp("arguments parsed");
     if (ffs_device_count() < 1) {  // cuda_arg_parser.cc:56-61
+        give_up.store(true);
         std::printf("\033[1;31mError: Could not select GPU device\033[0m\n");
         return 1;
     }
@@ -357,54 +415,16 @@ int main(int argc, char** argv) {
     {
         char name[256];
         if (ffs_device_name(args.device, name, sizeof name) != FFS_OK) {
+            give_up.store(true);
             std::printf("\033[1;31mError: Could not select GPU device\033[0m\n");
             return 1;
         }
         std::printf("Using %s\n", name);
     }
 
-    // ---- choose the reader (spotfinder.cc:438-466) ------------------------------------------------
-    std::unique_ptr<Reader> reader_ptr;
-    auto wait_ready = [&](const std::string& path, auto checker) {  // wait_for_ready_for_read, :137-175
-        const auto t0 = std::chrono::steady_clock::now();
-        bool waited = false;
-        while (!checker(path)) {
-            const double w = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            std::printf("\rWaiting for \033[1;35m%s\033[0m to be ready for read [%4.1f s] ", path.c_str(), w);
-            std::fflush(stdout);
-            waited = true;
-            if (w > args.timeout) {
-                std::printf("\nError: Waited too long for read availability\n");
-                std::exit(1);
-            }
-            std::this_thread::sleep_for(80ms);
-        }
-        if (waited) std::printf("\n");
-    };
-    try {
-        if (args.sample || file.rfind("synth:", 0) == 0) {
-            reader_ptr = make_synth_reader(args.sample ? "synth:eiger16m:6" : file);
-        } else {
-            if (!fs::exists(file) && file.find('#') == std::string::npos)
-                wait_ready(file, [](const std::string& s) { return fs::exists(s); });
-            if (fs::is_directory(file)) {
-                wait_ready(file, is_ready_for_read<SHMRead>);
-                reader_ptr = make_shm_reader(file);
-            } else if (file.size() > 4 && file.compare(file.size() - 4, 4, ".cbf") == 0) {
-                if (!args.images_set) {
-                    std::printf("Error: CBF reading must specify --images\n");
-                    return 1;
-                }
-                reader_ptr = make_cbf_reader(file, args.images, args.start_index);
-            } else {
-                wait_ready(file, is_ready_for_read<H5Read>);
-                reader_ptr = make_h5_reader(file);
-            }
-        }
-    } catch (const std::exception& e) {
-        std::printf("Error: %s\n", e.what());
-        return 1;
-    }
+    reader_holder.th.join();   // (opened beside the runtime's initialisation: see above)
+    if (reader_rc != 0) return reader_rc;
+    stamp("frame source opened (beside the runtime's initialisation)");
     Reader& reader = *reader_ptr;
     std::mutex reader_mutex;
 
@@ -513,10 +533,7 @@ int main(int argc, char** argv) {
     // (joined before the first batch is added to the stack).
     const bool gather_rccl = n_dev > 1 && args.gather == "rccl" && args.output_for_index && !(oscillation_width > 0);
     const bool need_exchange = n_dev > 1 && (oscillation_width > 0 || gather_rccl);
-    struct JoinedThread {   // (an early `return` below must not meet a joinable std::thread)
-        std::thread th;
-        ~JoinedThread() { if (th.joinable()) th.join(); }
-    } multi_holder;
+    JoinedThread multi_holder;
     std::thread& multi_thread = multi_holder.th;
     std::once_flag multi_joined;
     auto join_multi = [&] { std::call_once(multi_joined, [&] { if (multi_thread.joinable()) multi_thread.join(); }); };
